@@ -1,0 +1,296 @@
+"""CPU ORACLE (test infrastructure, NOT product code) -- NumPy restatement of the
+CODEJIN/GST_Tacotron inference hot path.
+
+PARITY UNPINNED: the reference is TensorFlow-2/Keras code; TensorFlow is neither
+installed nor installable in the build container and the reference ships no tests,
+golden vectors or fixtures for this path.  This file restates
+the algorithm from the reference source plus the documented Keras defaults listed in
+SURVEY.md Appendix A; it is cross-checked against an independent torch-CPU
+restatement (oracle/torch_ref.py) but has never been compared with real TF output.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The arithmetic lives in the un-vendored dependency ``tensorflow>=2.1.2``
+(reference Requirements.txt:3, no pinned version).
+
+Every function takes ``dt`` (np.float64 for the high-precision oracle, np.float32 to
+see the fp32 noise floor) and cites the reference lines it follows.
+"""
+import numpy as np
+
+BN_EPS = 1e-3   # tf.keras.layers.BatchNormalization default epsilon
+
+
+# ----------------------------------------------------------------------------- helpers
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def same_pad(n_in, k, s):
+    """TF padding='same' (SURVEY Appendix A.3, F10): out=ceil(in/s),
+    total=max((out-1)*s+k-in,0), before=total//2, after=total-before."""
+    out = -(-n_in // s)
+    total = max((out - 1) * s + k - n_in, 0)
+    before = total // 2
+    return out, before, total - before
+
+
+def batch_norm(x, w, prefix):
+    """Inference BatchNormalization on the last axis (Appendix A.4)."""
+    g, b = w[prefix + ".gamma"], w[prefix + ".beta"]
+    m, v = w[prefix + ".moving_mean"], w[prefix + ".moving_variance"]
+    return g * (x - m) / np.sqrt(v + x.dtype.type(BN_EPS)) + b
+
+
+def conv1d_same(x, kernel):
+    """Conv1D, stride 1, padding same, no bias; x [B,T,C], kernel [k,Cin,Cout]
+    (reference Taco2.py:27-33, 137-143; cross-correlation)."""
+    k = kernel.shape[0]
+    B, T, _ = x.shape
+    _, pb, pa = same_pad(T, k, 1)
+    xp = np.pad(x, ((0, 0), (pb, pa), (0, 0)))
+    y = np.zeros((B, T, kernel.shape[2]), dtype=x.dtype)
+    for j in range(k):
+        y += xp[:, j:j + T, :] @ kernel[j]
+    return y
+
+
+def conv2d_same(x, kernel, stride):
+    """Conv2D padding same (asymmetric, F10), no bias; x [B,H,W,C] NHWC with
+    H=time, W=freq; kernel [kh,kw,Cin,Cout] (reference GST.py:23-29)."""
+    kh, kw = kernel.shape[:2]
+    B, H, W, _ = x.shape
+    Ho, hb, ha = same_pad(H, kh, stride)
+    Wo, wb, wa = same_pad(W, kw, stride)
+    xp = np.pad(x, ((0, 0), (hb, ha), (wb, wa), (0, 0)))
+    y = np.zeros((B, Ho, Wo, kernel.shape[3]), dtype=x.dtype)
+    for i in range(kh):
+        for j in range(kw):
+            patch = xp[:, i:i + (Ho - 1) * stride + 1:stride, j:j + (Wo - 1) * stride + 1:stride, :]
+            y += patch @ kernel[i, j]
+    return y
+
+
+def lstm_cell(x, h, c, kernel, rec, bias):
+    """Keras LSTMCell (Appendix A.6): z=x.W+h.U+b, split i,f,c~,o."""
+    z = x @ kernel + h @ rec + bias
+    u = h.shape[-1]
+    i, f = sigmoid(z[:, :u]), sigmoid(z[:, u:2 * u])
+    g, o = np.tanh(z[:, 2 * u:3 * u]), sigmoid(z[:, 3 * u:])
+    c2 = f * c + i * g
+    return o * np.tanh(c2), c2
+
+
+def lstm_sequence(x, kernel, rec, bias, reverse=False):
+    B, T, _ = x.shape
+    u = rec.shape[0]
+    h = np.zeros((B, u), x.dtype)
+    c = np.zeros((B, u), x.dtype)
+    out = np.zeros((B, T, u), x.dtype)
+    order = range(T - 1, -1, -1) if reverse else range(T)
+    for t in order:
+        h, c = lstm_cell(x[:, t], h, c, kernel, rec, bias)
+        out[:, t] = h       # backward outputs are stored back in forward time order (A.7)
+    return out
+
+
+def gru_sequence(x, kernel, rec, bias):
+    """Keras GRU, TF2 default reset_after=True (Appendix A.8): order z,r,h;
+    bias[0] input bias, bias[1] recurrent bias."""
+    B, T, _ = x.shape
+    u = rec.shape[0]
+    h = np.zeros((B, u), x.dtype)
+    out = np.zeros((B, T, u), x.dtype)
+    for t in range(T):
+        mx = x[:, t] @ kernel + bias[0]
+        mh = h @ rec + bias[1]
+        z = sigmoid(mx[:, :u] + mh[:, :u])
+        r = sigmoid(mx[:, u:2 * u] + mh[:, u:2 * u])
+        hh = np.tanh(mx[:, 2 * u:] + r * mh[:, 2 * u:])
+        h = z * h + (1.0 - z) * hh
+        out[:, t] = h
+    return out
+
+
+def cast_weights(weights, dt):
+    return {k: np.asarray(v, dtype=dt) for k, v in weights.items()}
+
+
+# ----------------------------------------------------------------------------- modules
+def encoder(hp, w, tokens, dt):
+    """Reference Modules/Taco2.py:12-51: Embedding -> 3x(Conv1D, BN, ReLU,
+    Dropout=identity at inference) -> Bidirectional LSTM, concat [fwd, bwd]."""
+    x = w["encoder.embedding"][np.asarray(tokens)]
+    n_conv = len(hp["Tacotron2"]["Encoder"]["Conv"]["Filters"])
+    for i in range(n_conv):
+        x = conv1d_same(x, w[f"encoder.conv{i}.kernel"])
+        x = np.maximum(batch_norm(x, w, f"encoder.conv{i}.bn"), 0)
+    p = "encoder.bilstm."
+    fwd = lstm_sequence(x, w[p + "fwd.kernel"], w[p + "fwd.recurrent_kernel"], w[p + "fwd.bias"])
+    bwd = lstm_sequence(x, w[p + "bwd.kernel"], w[p + "bwd.recurrent_kernel"], w[p + "bwd.bias"], reverse=True)
+    return np.concatenate([fwd, bwd], axis=-1).astype(dt)
+
+
+def reference_encoder(hp, w, mels, mel_lengths, dt):
+    """Reference Modules/GST.py:12-70.  ``mels`` [B,T_ref,mel] (frame 0 already dropped)."""
+    ref = hp["GST"]["Reference_Encoder"]
+    x = np.asarray(mels, dt)[..., None]                       # GST.py:54
+    for i, s in enumerate(ref["Conv"]["Strides"]):
+        x = conv2d_same(x, w[f"gst.ref.conv{i}.kernel"], int(s))
+        x = np.maximum(batch_norm(x, w, f"gst.ref.conv{i}.bn"), 0)
+    B, T2, F2, C2 = x.shape
+    x = x.reshape(B, T2, F2 * C2)                             # GST.py:59-62 (index f*C+c)
+    x = gru_sequence(x, w["gst.ref.gru.kernel"], w["gst.ref.gru.recurrent_kernel"], w["gst.ref.gru.bias"])
+    prod = int(np.prod(ref["Conv"]["Strides"]))
+    idx = np.ceil(np.asarray(mel_lengths, np.int32) / prod).astype(np.int32) - 1   # GST.py:38-40,65-68
+    x = x[np.arange(B), idx]
+    return np.tanh(x @ w["gst.ref.dense.kernel"] + w["gst.ref.dense.bias"])      # GST.py:42-45,70
+
+
+def layer_norm(x, gamma, beta, eps=1e-8):
+    """Reference Layers.py:254-285: population variance, eps inside the sqrt."""
+    mean = x.mean(-1, keepdims=True)
+    var = ((x - mean) ** 2).mean(-1, keepdims=True)
+    return gamma * ((x - mean) / (var + x.dtype.type(eps)) ** 0.5) + beta
+
+
+def softmax(x):
+    e = np.exp(x - x.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+def style_token_layer(hp, w, mels_for_gst, mel_lengths, dt):
+    """Reference Modules/GST.py:91-109 + Layers.py:172-214: drop frame 0, reference
+    encoder, 4-head unscaled dot-product attention over tanh(tokens), LN(out+q)."""
+    ref = reference_encoder(hp, w, np.asarray(mels_for_gst, dt)[:, 1:], mel_lengths, dt)   # GST.py:98
+    tokens = np.tanh(w["gst.tokens"])                                        # GST.py:101
+    q = ref @ w["gst.mha.query.kernel"] + w["gst.mha.query.bias"]            # [B,A]   Layers.py:174
+    v = tokens @ w["gst.mha.value.kernel"] + w["gst.mha.value.bias"]         # [N,A]   Layers.py:175 (key=value :176)
+    heads = int(hp["GST"]["Style_Token"]["Attention"]["Head"])
+    dh = q.shape[-1] // heads
+    out = np.zeros_like(q)
+    for h in range(heads):
+        sl = slice(h * dh, (h + 1) * dh)
+        scores = q[:, sl] @ v[:, sl].T                                      # Layers.py:224, no scale (F13)
+        out[:, sl] = softmax(scores) @ v[:, sl]                             # Layers.py:235-237
+    return layer_norm(out + q, w["gst.mha.ln.gamma"], w["gst.mha.ln.beta"])  # Layers.py:211
+
+
+def gst_concat(enc, gst):
+    """Reference Modules/GST.py:111-124: memory = [tile(gst) | enc]."""
+    B, T, _ = enc.shape
+    return np.concatenate([np.broadcast_to(gst[:, None, :], (B, T, gst.shape[-1])), enc], axis=-1)
+
+
+def prenet(hp, w, x, masks):
+    """Reference Taco2.py:262-283: Dense relu + Dropout that is ALWAYS on (F3).
+    ``masks``: list of keep-masks (1 keep / 0 drop), or None for rate 0."""
+    rate = float(hp["Tacotron2"]["Decoder"]["Prenet"]["Dropout_Rate"])
+    for i in range(len(hp["Tacotron2"]["Decoder"]["Prenet"]["Size"])):
+        x = np.maximum(x @ w[f"decoder.prenet{i}.kernel"] + w[f"decoder.prenet{i}.bias"], 0)
+        if rate > 0.0:
+            x = x * x.dtype.type(1.0 / (1.0 - rate)) * masks[i]
+    return x
+
+
+def monotonic_alignment(att_type, score, prev):
+    """SMA: reference Steps.py:222-229; BMA: Steps.py:171-180,183-199."""
+    p = sigmoid(score)
+    if att_type == "SMA":
+        shifted = np.zeros_like(prev)
+        shifted[:, 1:] = prev[:, :-1] * (1.0 - p[:, :-1])
+        return prev * p + shifted
+    tiny = np.finfo(np.float32).tiny        # Steps.py:198 with a float32 model dtype
+    logs = np.log(np.clip(1.0 - p, tiny, 1.0))
+    excl = np.cumsum(logs, axis=-1) - logs                                   # exclusive cumsum
+    cp = np.exp(excl)
+    return p * cp * np.cumsum(prev / np.clip(cp, 1e-10, 1.0), axis=-1)
+
+
+def attention_step(hp, w, query_in, processed_memory, prev_align, noise):
+    """Reference Steps.py:107-166.  ``processed_memory`` is Dense_Value(memory)
+    (loop-invariant, F7); the context is a weighted sum of the PROJECTED memory."""
+    att = hp["Tacotron2"]["Decoder"]["Attention"]
+    q = query_in @ w["decoder.attention.query.kernel"] + w["decoder.attention.query.bias"]     # :122
+    score = (w["decoder.attention.v"] * np.tanh(q[:, None, :] + processed_memory)).sum(-1) \
+        + w["decoder.attention.score_bias"]                                                     # :152
+    sn = att.get("Sigmoid_Noise", 2.0 if att["Type"] == "SMA" else 0.0)
+    if sn > 0.0:
+        score = score + score.dtype.type(sn) * noise                                            # :169-170 / :220-221
+    align = monotonic_alignment(att["Type"], score, prev_align)
+    ctx = np.einsum("bt,bta->ba", align, processed_memory)                                      # :164
+    return ctx, align
+
+
+def process_memory(w, memory):
+    return memory @ w["decoder.attention.value.kernel"] + w["decoder.attention.value.bias"]     # Steps.py:123
+
+
+def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, return_states=False):
+    """Reference Taco2.py:153-228 (training=False branch).
+    prenet_masks [steps, n_prenet, B, size] keep-masks; attn_noise [steps, B, T_v] ~ N(0,1)."""
+    mel, r = int(hp["Sound"]["Mel_Dim"]), int(hp["Step_Reduction"])
+    if steps is None:
+        steps = int(hp["Max_Step"]) // r                                     # Taco2.py:213
+    B, Tv, _ = memory.shape
+    pm = process_memory(w, memory)
+    sizes = hp["Tacotron2"]["Decoder"]["RNN"]["Size"]
+    hs = [np.zeros((B, s), dt) for s in sizes]
+    cs = [np.zeros((B, s), dt) for s in sizes]
+    frame = np.zeros((B, mel), dt)                                           # Taco2.py:162-165
+    align = np.zeros((B, Tv), dt)
+    align[:, 0] = 1.0                                                        # Steps.py:201-206
+    pre = np.zeros((B, steps * r, mel), dt)
+    stops = np.zeros((B, steps), dt)
+    aligns = np.zeros((B, steps, Tv), dt)
+    for t in range(steps):
+        masks = None if prenet_masks is None else prenet_masks[t]
+        p = prenet(hp, w, frame, masks)                                      # Taco2.py:106
+        noise = None if attn_noise is None else attn_noise[t]
+        ctx, align = attention_step(hp, w, p, pm, align, noise)              # Taco2.py:107-109
+        x = np.concatenate([p, ctx], -1)                                     # :110
+        for i in range(len(sizes)):                                          # :111 StackedRNNCells
+            hs[i], cs[i] = lstm_cell(x, hs[i], cs[i], w[f"decoder.lstm{i}.kernel"],
+                                     w[f"decoder.lstm{i}.recurrent_kernel"], w[f"decoder.lstm{i}.bias"])
+            x = hs[i]
+        y = np.concatenate([x, ctx], -1) @ w["decoder.projection.kernel"] + w["decoder.projection.bias"]  # :112-113
+        pre[:, t * r:(t + 1) * r] = y[:, :mel * r].reshape(B, r, mel)        # :194-201
+        stops[:, t] = y[:, mel * r]
+        aligns[:, t] = align
+        frame = pre[:, (t + 1) * r - 1]                                      # :186 decodings[:, -1] (F14)
+    if return_states:
+        return pre, stops, aligns, (hs, cs)
+    return pre, stops, aligns
+
+
+def postnet(hp, w, pre, dt):
+    """Reference Taco2.py:131-149,230: 5x(Conv1D+BN), tanh after layers 0..2 only (F9), + residual."""
+    n = len(hp["Tacotron2"]["Decoder"]["Conv"]["Filters"]) + 1
+    x = pre
+    for i in range(n):
+        x = batch_norm(conv1d_same(x, w[f"postnet.conv{i}.kernel"]), w, f"postnet.conv{i}.bn")
+        if i < n - 2:
+            x = np.tanh(x)
+    return x + pre
+
+
+def inference_step(hp, weights, tokens, mels_for_gst=None, mel_lengths_for_gst=None,
+                   prenet_masks=None, attn_noise=None, steps=None, dt=np.float64):
+    """Reference Model.py:249-255 with the wiring of Model.py:108-129,145-156.
+    Returns (mels [B,S*r,mel] post-net, stops [B,S], None (vocoder out of scope), alignments [B,S,T_v])
+    plus a dict of intermediates for per-module parity tests."""
+    w = cast_weights(weights, dt)
+    enc = encoder(hp, w, tokens, dt)
+    inter = {"encoder": enc}
+    memory = enc
+    if hp["GST"]["Use"]:
+        gst = style_token_layer(hp, w, mels_for_gst, mel_lengths_for_gst, dt)
+        inter["gst"] = gst
+        memory = gst_concat(enc, gst)
+    if prenet_masks is not None:
+        prenet_masks = np.asarray(prenet_masks, dt)
+    if attn_noise is not None:
+        attn_noise = np.asarray(attn_noise, dt)
+    pre, stops, aligns = decoder(hp, w, memory, dt, prenet_masks, attn_noise, steps)
+    inter["pre_mel"] = pre
+    mels = postnet(hp, w, pre, dt)
+    return mels, stops, None, aligns, inter
