@@ -1,0 +1,63 @@
+"""Builds gst_tacotron_amd/lib/libgsttaco.so (C-ABI + gfx950 kernels) in-tree with hipcc.
+
+hipcc cross-compiles for gfx950 without a GPU; the built .so travels with the tree.
+``python -m gst_tacotron_amd.build [--force]``
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libgsttaco.so")
+SOURCES = ["gsttaco.cpp", "skinny_gemm.hip", "gemm_conv.hip", "attention.hip", "gst.hip"]
+HEADERS = ["kernels.h", "device_utils.h", os.path.join("..", "..", "include", "gsttaco.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    objs, jobs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp] + hdrs):
+            jobs.append([_hipcc()] + FLAGS + ["-x", "hip", "-c", sp, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn.strip():
+                print(warn)
+    if force or jobs or _stale(LIB, objs):
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

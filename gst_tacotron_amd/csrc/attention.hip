@@ -1,0 +1,206 @@
+// One decoder-step of the monotonic attentions, one workgroup per utterance.
+//
+// Replaces reference Modules/Attention/Steps.py:126-166 (score, _apply_scores, context) with
+//   SMA  StepwiseMonotonicAttention._monotonic_probability_fn  Steps.py:215-229
+//   BMA  BahdanauMonotonicAttention._monotonic_probability_fn  Steps.py:168-199 (safe_cumprod)
+// on the HOISTED processed memory pm = Dense_Value(memory) (Steps.py:123 is loop-invariant).
+//
+//   score[t] = sum_a v[a] * tanh(q[a] + pm[t,a]) + b  (+ sigmoid_noise * N(0,1))
+//   p = sigmoid(score);  align = SMA/BMA(p, prev);  ctx[a] = sum_t align[t] * pm[t,a]
+//
+// gfx950 mapping: the utterance's processed memory (Tv x A fp32 = 64 KiB at 128x128) is staged once per
+// step into LDS with coalesced 16-byte loads (row stride A+1 floats so row-per-lane reads for the score and
+// column-per-lane reads for the context are both bank-conflict-free) and is read twice from there.
+// Scores: one lane per memory row (no cross-lane reduction over a); BMA prefix sums: one wave, serial
+// chunk per lane + wave scan; context: one lane per output channel.
+#include "device_utils.h"
+#include "kernels.h"
+#include "../../include/gsttaco.h"
+
+#define ATT_THREADS 256
+
+size_t gt_attn_lds_bytes(int Tv, int A, int* rows_lds) {
+    int rows = Tv < 256 ? Tv : 256;
+    // keep the tile <= 128 KiB
+    while ((size_t)rows * (A + 1) * 4 > 128 * 1024 && rows > 16) rows /= 2;
+    if (rows_lds) *rows_lds = rows;
+    // tile + q + v + score/p + prev + align + partials
+    return ((size_t)rows * (A + 1) + 2 * (size_t)A + 3 * (size_t)Tv + 4 * 256 + 64) * sizeof(float);
+}
+
+__device__ __forceinline__ float wave_incl_scan(float x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Tv = P.Tv, A = P.A, LD = A + 1;
+    const int rows_lds = P.rows_lds;
+    float* tile = smem;                              // [rows_lds][LD]
+    float* qs = tile + (size_t)rows_lds * LD;        // [A]
+    float* vs = qs + A;                              // [A]
+    float* sc = vs + A;                              // [Tv] score -> p
+    float* pv = sc + Tv;                             // [Tv] previous alignment
+    float* al = pv + Tv;                             // [Tv] new alignment
+    float* partial = al + Tv;                        // [4*256]
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* pm = P.pm + (size_t)b * Tv * A;
+
+    for (int a = tid; a < A; a += ATT_THREADS) {
+        qs[a] = P.q[(size_t)b * P.ldq + a];
+        vs[a] = P.v[a];
+    }
+    for (int t = tid; t < Tv; t += ATT_THREADS)
+        pv[t] = P.prev ? P.prev[(size_t)b * P.ldprev + t] : (t == 0 ? 1.f : 0.f);
+
+    const float bias = P.score_bias[0];
+    const int nchunks = (Tv + rows_lds - 1) / rows_lds;
+    const int a4 = A >> 2;
+
+    auto stage = [&](int c) {
+        const int r0 = c * rows_lds;
+        const int nr = min(rows_lds, Tv - r0);
+        const float4* src = reinterpret_cast<const float4*>(pm + (size_t)r0 * A);
+        for (int f = tid; f < nr * a4; f += ATT_THREADS) {
+            const float4 v = src[f];
+            const int row = f / a4, col = (f - row * a4) * 4;
+            float* d = tile + row * LD + col;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        return nr;
+    };
+
+    // ---- pass 1: scores
+    // thread -> (row = tid % RP, part = tid / RP); RP = rows rounded to {64,128,256}
+    const int RP = rows_lds <= 64 ? 64 : (rows_lds <= 128 ? 128 : 256);
+    const int nparts = ATT_THREADS / RP;
+    const int arange = (A + nparts - 1) / nparts;
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        const int nr = stage(c);
+        __syncthreads();
+        const int row = tid % RP, part = tid / RP;
+        float s = 0.f;
+        if (row < nr) {
+            const float* tr = tile + row * LD;
+            const int abeg = part * arange, aend = min(A, abeg + arange);
+            for (int a = abeg; a < aend; ++a) s += vs[a] * gt_tanh(qs[a] + tr[a]);
+        }
+        partial[part * 256 + row] = s;
+        __syncthreads();
+        if (tid < nr) {
+            float z = partial[tid];
+            for (int p = 1; p < nparts; ++p) z += partial[p * 256 + tid];
+            sc[c * rows_lds + tid] = z + bias;
+        }
+    }
+    __syncthreads();
+
+    // ---- noise + sigmoid
+    for (int t = tid; t < Tv; t += ATT_THREADS) {
+        float s = sc[t];
+        if (P.sigmoid_noise > 0.f) {
+            float nz;
+            if (P.noise) nz = P.noise[(size_t)b * P.ldnoise + t];
+            else {
+                Philox4 r = gt_philox(*P.seed_ptr, (uint32_t)(b * Tv + t), P.rng_step, 0u, GT_RNG_NOISE);
+                nz = gt_normal(r.x, r.y);
+            }
+            s += P.sigmoid_noise * nz;
+        }
+        sc[t] = gt_sigmoid(s);
+    }
+    __syncthreads();
+
+    // ---- alignment
+    if (P.type == GSTTACO_ATT_SMA) {
+        for (int t = tid; t < Tv; t += ATT_THREADS) {
+            float v = pv[t] * sc[t];
+            if (t > 0) v += pv[t - 1] * (1.f - sc[t - 1]);
+            al[t] = v;
+        }
+    } else {
+        // BMA: cp = exp(exclusive_cumsum(log(clip(1-p, tiny, 1)))); align = p*cp*cumsum(prev/clip(cp,1e-10,1))
+        if (tid < 64) {
+            const int per = (Tv + 63) / 64;
+            const int t0 = tid * per, t1 = min(Tv, t0 + per);
+            float run = 0.f;
+            for (int t = t0; t < t1; ++t) run += logf(fminf(fmaxf(1.f - sc[t], 1.17549435e-38f), 1.f));
+            float incl = wave_incl_scan(run, tid);
+            float base = incl - run;
+            for (int t = t0; t < t1; ++t) {
+                const float lg = logf(fminf(fmaxf(1.f - sc[t], 1.17549435e-38f), 1.f));
+                al[t] = expf(base);            // exclusive cumprod
+                base += lg;
+            }
+            // second scan: cumsum(prev / clip(cp, 1e-10, 1))
+            run = 0.f;
+            for (int t = t0; t < t1; ++t) run += pv[t] / fminf(fmaxf(al[t], 1e-10f), 1.f);
+            incl = wave_incl_scan(run, tid);
+            base = incl - run;
+            for (int t = t0; t < t1; ++t) {
+                base += pv[t] / fminf(fmaxf(al[t], 1e-10f), 1.f);
+                al[t] = sc[t] * al[t] * base;
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < Tv; t += ATT_THREADS) P.align[(size_t)b * P.ldalign + t] = al[t];
+
+    // ---- pass 2: context  ctx[a] = sum_t al[t] * pm[t][a]; thread -> (a = tid % AP, part = tid / AP)
+    const int AP = A <= 64 ? 64 : (A <= 128 ? 128 : 256);
+    const int cparts = ATT_THREADS / AP;
+    float cacc = 0.f;
+    const int ca = tid % AP, cpart = tid / AP;
+    for (int c = 0; c < nchunks; ++c) {
+        int nr;
+        if (nchunks > 1) {
+            __syncthreads();
+            nr = stage(c);
+            __syncthreads();
+        } else {
+            nr = Tv;
+        }
+        if (ca < A) {
+            const float* alc = al + c * rows_lds;
+            for (int t = cpart; t < nr; t += cparts) cacc += alc[t] * tile[t * LD + ca];
+        }
+    }
+    __syncthreads();
+    partial[cpart * 256 + ca] = cacc;
+    __syncthreads();
+    if (tid < A && A <= 256) {
+        float z = partial[tid];
+        for (int p = 1; p < cparts; ++p) z += partial[p * 256 + tid];
+        P.ctx[(size_t)b * P.ldctx + tid] = z;
+    }
+}
+
+hipError_t gt_attn_init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gt_attn_step_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+__global__ void gt_set_seed_kernel(uint64_t* dst, uint64_t seed) { *dst = seed; }
+
+hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream) {
+    hipLaunchKernelGGL(gt_set_seed_kernel, dim3(1), dim3(1), 0, stream, dst, seed);
+    return hipGetLastError();
+}
+
+hipError_t gt_launch_attn_step(const AttnStepArgs& a, hipStream_t stream) {
+    if (a.A > 256 || (a.A & 3)) return hipErrorInvalidValue;
+    int rows;
+    size_t lds = gt_attn_lds_bytes(a.Tv, a.A, &rows);
+    AttnStepArgs p = a;
+    p.rows_lds = rows;
+    hipLaunchKernelGGL(gt_attn_step_kernel, dim3(a.B), dim3(ATT_THREADS), lds, stream, p);
+    return hipGetLastError();
+}

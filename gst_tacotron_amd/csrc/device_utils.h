@@ -1,0 +1,55 @@
+// Device-side helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GT_WAVE 64
+
+// tanh via one v_exp_f32 + one v_rcp_f32: tanh(x) = 1 - 2/(exp(2x)+1).
+// abs error <= ~2e-7 over the whole range (checked against tanh() in tests/test_gpu_kernels.py).
+__device__ __forceinline__ float gt_tanh(float x) {
+    float xc = fminf(fmaxf(x, -15.0f), 15.0f);
+    float e = __expf(2.0f * xc);
+    return 1.0f - __fdividef(2.0f, e + 1.0f);
+}
+
+__device__ __forceinline__ float gt_sigmoid(float x) {
+    float xc = fminf(fmaxf(x, -30.0f), 30.0f);
+    return __fdividef(1.0f, 1.0f + __expf(-xc));
+}
+
+// Philox4x32-10 counter RNG: throughput-mode randomness (prenet dropout, SMA noise) is generated
+// on the device; parity runs inject the tensors instead.
+struct Philox4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ Philox4 gt_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ float gt_u01(uint32_t r) {        // (0,1]
+    return ((float)(r >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float gt_normal(uint32_t r0, uint32_t r1) {   // Box-Muller
+    float u1 = gt_u01(r0), u2 = gt_u01(r1);
+    return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
+}
+
+// stream ids for the Philox counter's 4th word
+#define GT_RNG_PRENET0 0x1000u
+#define GT_RNG_NOISE   0x2000u

@@ -1,0 +1,974 @@
+// Host side of the C-ABI declared in include/gsttaco.h: context, weight manifest, BN folding and
+// MFMA-fragment repacking, HBM workspace, per-phase kernel enqueue and the hipGraph cache.
+//
+// Call-stack mirrored (reference Model.py:249-255 -> Model.py:145-156):
+//   encoder (Taco2.py:12-51) -> style tokens (GST.py:72-109) -> [gst|enc] memory (GST.py:111-124, never
+//   materialised) -> decoder loop (Taco2.py:153-228) -> postnet (Taco2.py:131-149,230).
+// There is no CPU fallback: every compute entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gsttaco.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr float kBnEps = 1e-3f;   // tf.keras.layers.BatchNormalization default epsilon
+
+struct HostTensor {
+    std::string name;
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    bool loaded = false;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct PackedLinear {       // skinny-GEMM operand set
+    float* wp = nullptr;
+    float* bias = nullptr;
+    int nkb = 0, ntiles = 0, N = 0;
+};
+
+struct ConvLayer {
+    float* w = nullptr;     // [taps*Cin, Cout]
+    float* scale = nullptr;
+    float* shift = nullptr;
+    int taps = 0, cin = 0, cout = 0;
+};
+
+struct GraphKey {
+    int kind, B, Tv, Tref1, steps, has_mask, has_noise, prof;
+    bool operator<(const GraphKey& o) const {
+        return memcmp(this, &o, sizeof(GraphKey)) < 0;
+    }
+};
+
+std::string g_create_error;
+
+}  // namespace
+
+struct gsttaco_ctx {
+    gsttaco_config cfg{};
+    std::vector<HostTensor> tensors;
+    std::map<std::string, int> index;
+    mutable std::string err;
+    bool finalized = false;
+    bool use_graph = true;
+
+    // derived dims
+    int r = 0, steps_max = 0, enc_out = 0, mem_dim = 0, proj_out = 0, conv_c = 0;
+    int P0 = 0, P1 = 0, H1 = 0, H2 = 0, att = 0;
+
+    // device memory
+    std::vector<void*> allocs;
+    hipStream_t cap_stream = nullptr;
+
+    // weights on device
+    float* d_emb = nullptr;
+    std::vector<ConvLayer> enc_conv, post_conv;
+    PackedLinear bilstm[2];
+    struct { float *w, *scale, *shift; int k, cin, cout, stride; } ref_conv[GSTTACO_MAX_LAYERS]{};
+    float *gru_w = nullptr, *gru_u = nullptr, *gru_b = nullptr, *dense_w = nullptr, *dense_b = nullptr;
+    float *mq_w = nullptr, *mq_b = nullptr, *v_tok = nullptr, *ln_g = nullptr, *ln_b = nullptr;
+    PackedLinear prenet0, prenet1, query, val_gst, lstm0, lstm1, proj;
+    float *val_enc_w = nullptr, *val_bias = nullptr, *att_v = nullptr, *att_sb = nullptr;
+
+    // workspace
+    int32_t *w_tokens = nullptr, *w_mel_len = nullptr;
+    float *w_mels_in = nullptr, *w_masks = nullptr, *w_noise = nullptr;
+    uint64_t* w_seed = nullptr;
+    float *w_act[2] = {nullptr, nullptr}, *w_enc = nullptr, *w_cenc = nullptr, *w_zero = nullptr;
+    float *w_gconv[2] = {nullptr, nullptr}, *w_gst = nullptr, *w_rowbias = nullptr, *w_pm = nullptr;
+    float *w_p1 = nullptr, *w_xa = nullptr, *w_q = nullptr, *w_h1[2] = {nullptr, nullptr},
+          *w_h2[2] = {nullptr, nullptr}, *w_c1 = nullptr, *w_c2 = nullptr;
+    float *w_pre = nullptr, *w_stop = nullptr, *w_align = nullptr, *w_post[2] = {nullptr, nullptr},
+          *w_mel = nullptr;
+    size_t zero_floats = 0;
+
+    // graphs
+    std::map<GraphKey, hipGraphExec_t> graphs;
+
+    // profiling
+    int prof_every = 0;
+    int prof_count[2] = {0, 0};
+    std::vector<hipEvent_t> prof_ev[2];     // pairs (start, stop) per bracketed launch, per LSTM layer
+};
+
+namespace {
+
+int fail(const gsttaco_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define HIPCHECK(ctx, expr)                                                                   \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(ctx, GSTTACO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+void add_tensor(gsttaco_ctx* c, const std::string& name, std::vector<int64_t> shape) {
+    HostTensor t;
+    t.name = name;
+    t.shape = std::move(shape);
+    c->index[name] = (int)c->tensors.size();
+    c->tensors.push_back(std::move(t));
+}
+
+void add_bn(gsttaco_ctx* c, const std::string& prefix, int64_t n) {
+    for (const char* f : {"gamma", "beta", "moving_mean", "moving_variance"}) add_tensor(c, prefix + ".bn." + f, {n});
+}
+
+// Same names/shapes/order as gst_tacotron_amd/weights.py::manifest.
+void build_manifest(gsttaco_ctx* c) {
+    const gsttaco_config& g = c->cfg;
+    add_tensor(c, "encoder.embedding", {g.vocab, g.emb});
+    int64_t cin = g.emb;
+    for (int i = 0; i < g.n_enc_conv; ++i) {
+        std::string p = "encoder.conv" + std::to_string(i);
+        add_tensor(c, p + ".kernel", {g.enc_kernels[i], cin, g.enc_filters[i]});
+        add_bn(c, p, g.enc_filters[i]);
+        cin = g.enc_filters[i];
+    }
+    for (const char* d : {"fwd", "bwd"}) {
+        std::string p = std::string("encoder.bilstm.") + d;
+        add_tensor(c, p + ".kernel", {cin, 4 * (int64_t)g.enc_rnn});
+        add_tensor(c, p + ".recurrent_kernel", {g.enc_rnn, 4 * (int64_t)g.enc_rnn});
+        add_tensor(c, p + ".bias", {4 * (int64_t)g.enc_rnn});
+    }
+    if (g.gst_use) {
+        cin = 1;
+        int freq = g.mel_dim;
+        for (int i = 0; i < g.n_ref_conv; ++i) {
+            std::string p = "gst.ref.conv" + std::to_string(i);
+            add_tensor(c, p + ".kernel", {g.ref_kernels[i], g.ref_kernels[i], cin, g.ref_filters[i]});
+            add_bn(c, p, g.ref_filters[i]);
+            cin = g.ref_filters[i];
+            freq = (freq + g.ref_strides[i] - 1) / g.ref_strides[i];
+        }
+        const int64_t gru_in = (int64_t)freq * cin;
+        add_tensor(c, "gst.ref.gru.kernel", {gru_in, 3 * (int64_t)g.ref_rnn});
+        add_tensor(c, "gst.ref.gru.recurrent_kernel", {g.ref_rnn, 3 * (int64_t)g.ref_rnn});
+        add_tensor(c, "gst.ref.gru.bias", {2, 3 * (int64_t)g.ref_rnn});
+        add_tensor(c, "gst.ref.dense.kernel", {g.ref_rnn, g.ref_dense});
+        add_tensor(c, "gst.ref.dense.bias", {g.ref_dense});
+        add_tensor(c, "gst.tokens", {g.n_tokens, g.token_emb});
+        add_tensor(c, "gst.mha.query.kernel", {g.ref_dense, g.gst_att});
+        add_tensor(c, "gst.mha.query.bias", {g.gst_att});
+        add_tensor(c, "gst.mha.value.kernel", {g.token_emb, g.gst_att});
+        add_tensor(c, "gst.mha.value.bias", {g.gst_att});
+        add_tensor(c, "gst.mha.ln.gamma", {g.gst_att});
+        add_tensor(c, "gst.mha.ln.beta", {g.gst_att});
+    }
+    cin = g.mel_dim;
+    for (int i = 0; i < g.n_prenet; ++i) {
+        std::string p = "decoder.prenet" + std::to_string(i);
+        add_tensor(c, p + ".kernel", {cin, g.prenet[i]});
+        add_tensor(c, p + ".bias", {g.prenet[i]});
+        cin = g.prenet[i];
+    }
+    add_tensor(c, "decoder.attention.query.kernel", {cin, g.att_size});
+    add_tensor(c, "decoder.attention.query.bias", {g.att_size});
+    add_tensor(c, "decoder.attention.value.kernel", {c->mem_dim, g.att_size});
+    add_tensor(c, "decoder.attention.value.bias", {g.att_size});
+    add_tensor(c, "decoder.attention.v", {g.att_size});
+    add_tensor(c, "decoder.attention.score_bias", {});
+    cin = cin + g.att_size;
+    for (int i = 0; i < g.n_dec_rnn; ++i) {
+        std::string p = "decoder.lstm" + std::to_string(i);
+        add_tensor(c, p + ".kernel", {cin, 4 * (int64_t)g.dec_rnn[i]});
+        add_tensor(c, p + ".recurrent_kernel", {g.dec_rnn[i], 4 * (int64_t)g.dec_rnn[i]});
+        add_tensor(c, p + ".bias", {4 * (int64_t)g.dec_rnn[i]});
+        cin = g.dec_rnn[i];
+    }
+    add_tensor(c, "decoder.projection.kernel", {cin + g.att_size, c->proj_out});
+    add_tensor(c, "decoder.projection.bias", {c->proj_out});
+    cin = g.mel_dim;
+    for (int i = 0; i < g.n_post; ++i) {
+        std::string p = "postnet.conv" + std::to_string(i);
+        add_tensor(c, p + ".kernel", {g.post_kernels[i], cin, g.post_filters[i]});
+        add_bn(c, p, g.post_filters[i]);
+        cin = g.post_filters[i];
+    }
+}
+
+const HostTensor& T(const gsttaco_ctx* c, const std::string& name) { return c->tensors[c->index.at(name)]; }
+
+int dev_alloc(gsttaco_ctx* c, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    HIPCHECK(c, hipMalloc(p, bytes));
+    c->allocs.push_back(*p);
+    return 0;
+}
+
+int upload(gsttaco_ctx* c, float** dst, const float* src, size_t n) {
+    int rc = dev_alloc(c, (void**)dst, n * sizeof(float));
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Fold inference BatchNorm into y = x*scale + shift (Appendix A.4).
+void fold_bn(const gsttaco_ctx* c, const std::string& prefix, std::vector<float>& scale, std::vector<float>& shift) {
+    const auto& g = T(c, prefix + ".bn.gamma").data;
+    const auto& b = T(c, prefix + ".bn.beta").data;
+    const auto& m = T(c, prefix + ".bn.moving_mean").data;
+    const auto& v = T(c, prefix + ".bn.moving_variance").data;
+    scale.resize(g.size());
+    shift.resize(g.size());
+    for (size_t i = 0; i < g.size(); ++i) {
+        const double s = (double)g[i] / std::sqrt((double)v[i] + (double)kBnEps);
+        scale[i] = (float)s;
+        shift[i] = (float)((double)b[i] - (double)m[i] * s);
+    }
+}
+
+// Pack rows of (possibly several row-concatenated) [K_i, ncols] matrices into MFMA 16x16x4 B-fragment
+// order: out[((tile*nkb + kb)*64 + lane)*4 + s] = W[kb*16 + 4*(lane>>4) + s][colmap(tile, lane&15)].
+// lstm_units > 0: tile-local column g*4+u maps to source column g*H + tile*4 + u (gate-major Keras
+// layout i,f,c,o -> unit-major tiles so a workgroup owns whole hidden units).
+int pack_linear(gsttaco_ctx* c, PackedLinear* out, const std::vector<std::pair<const float*, int>>& mats,
+                int ncols, const float* bias, int lstm_units) {
+    int K = 0;
+    for (auto& m : mats) {
+        if (m.second % 16) return fail(c, GSTTACO_E_INVALID, "skinny GEMM segment length must be a multiple of 16");
+        K += m.second;
+    }
+    const int nkb = K / 16;
+    const int ntiles = lstm_units > 0 ? (lstm_units + 3) / 4 : (ncols + 15) / 16;
+    std::vector<float> wp((size_t)ntiles * nkb * 256, 0.f), bp((size_t)ntiles * 16, 0.f);
+    auto colmap = [&](int tile, int cl) -> int {
+        if (lstm_units > 0) {
+            const int g = cl >> 2, u = tile * 4 + (cl & 3);
+            return u < lstm_units ? g * lstm_units + u : -1;
+        }
+        const int col = tile * 16 + cl;
+        return col < ncols ? col : -1;
+    };
+    std::vector<const float*> rowptr(K);
+    {
+        int k = 0;
+        for (auto& m : mats)
+            for (int i = 0; i < m.second; ++i) rowptr[k++] = m.first + (size_t)i * ncols;
+    }
+    for (int tile = 0; tile < ntiles; ++tile) {
+        for (int cl = 0; cl < 16; ++cl) {
+            const int sc = colmap(tile, cl);
+            if (sc >= 0 && bias) bp[(size_t)tile * 16 + cl] = bias[sc];
+        }
+        for (int kb = 0; kb < nkb; ++kb)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int sc = colmap(tile, lane & 15);
+                if (sc < 0) continue;
+                for (int s = 0; s < 4; ++s) {
+                    const int k = kb * 16 + 4 * (lane >> 4) + s;
+                    wp[(((size_t)tile * nkb + kb) * 64 + lane) * 4 + s] = rowptr[k][sc];
+                }
+            }
+    }
+    out->nkb = nkb;
+    out->ntiles = ntiles;
+    out->N = lstm_units > 0 ? lstm_units : ncols;
+    int rc = upload(c, &out->wp, wp.data(), wp.size());
+    if (rc) return rc;
+    return upload(c, &out->bias, bp.data(), bp.size());
+}
+
+int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
+    const HostTensor& k = T(c, prefix + ".kernel");
+    L->taps = (int)k.shape[0];
+    L->cin = (int)k.shape[1];
+    L->cout = (int)k.shape[2];
+    std::vector<float> sc, sh;
+    fold_bn(c, prefix, sc, sh);
+    int rc = upload(c, &L->w, k.data.data(), k.data.size());
+    if (!rc) rc = upload(c, &L->scale, sc.data(), sc.size());
+    if (!rc) rc = upload(c, &L->shift, sh.data(), sh.size());
+    return rc;
+}
+
+int same_pad_before(int n_in, int k, int s, int* out_n) {
+    const int out = (n_in + s - 1) / s;
+    int total = (out - 1) * s + k - n_in;
+    if (total < 0) total = 0;
+    if (out_n) *out_n = out;
+    return total / 2;      // TF: before = total // 2, after = rest
+}
+
+// ------------------------------------------------------------------------------------------------ enqueue
+int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
+    const gsttaco_config& g = c->cfg;
+    const float* x = c->d_emb;
+    const int32_t* tok = c->w_tokens;
+    int cur = 0;
+    for (int i = 0; i < g.n_enc_conv; ++i) {
+        const ConvLayer& L = c->enc_conv[i];
+        ConvGemmArgs a{};
+        a.x = x; a.tokens = tok; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
+        a.out = c->w_act[cur]; a.ldo = L.cout;
+        a.B = B; a.T = Tv; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;
+        a.pad_before = same_pad_before(Tv, L.taps, 1, nullptr);
+        a.act = ACT_RELU;
+        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        x = c->w_act[cur]; tok = nullptr; cur ^= 1;
+    }
+    // BiLSTM: one launch per time step, both directions in grid.z; h is written straight into enc_out.
+    const int H = g.enc_rnn, C = c->conv_c, EO = c->enc_out;
+    HIPCHECK(c, hipMemsetAsync(c->w_cenc, 0, (size_t)2 * B * H * sizeof(float), s));
+    for (int t = 0; t < Tv; ++t) {
+        SkinnyArgs a[2];
+        for (int d = 0; d < 2; ++d) {
+            const int tt = d == 0 ? t : Tv - 1 - t;
+            const int tp = d == 0 ? tt - 1 : tt + 1;
+            SkinnyArgs& k = a[d];
+            memset(&k, 0, sizeof(k));
+            k.wp = c->bilstm[d].wp; k.bias = c->bilstm[d].bias;
+            k.seg[0] = SkinnySeg{x + (size_t)tt * C, (int64_t)Tv * C, C / 16, 0};
+            if (t == 0) k.seg[1] = SkinnySeg{c->w_zero, 0, H / 16, 0};
+            else k.seg[1] = SkinnySeg{c->w_enc + (size_t)tp * EO + d * H, (int64_t)Tv * EO, H / 16, 0};
+            k.nkb = c->bilstm[d].nkb; k.M = B; k.N = H;
+            k.c = c->w_cenc + (size_t)d * B * H;
+            k.h = c->w_enc + (size_t)tt * EO + d * H; k.ldh = (int64_t)Tv * EO;
+        }
+        HIPCHECK(c, gt_launch_skinny(EPI_LSTM, a[0], &a[1], c->bilstm[0].ntiles, s));
+    }
+    return 0;
+}
+
+int enqueue_gst(gsttaco_ctx* c, hipStream_t s, int B, int Tref1) {
+    const gsttaco_config& g = c->cfg;
+    int H = Tref1 - 1, W = g.mel_dim;
+    const float* x = c->w_mels_in + g.mel_dim;          // drop frame 0 (GST.py:98)
+    int64_t xb = (int64_t)Tref1 * g.mel_dim;
+    int cur = 0;
+    for (int i = 0; i < g.n_ref_conv; ++i) {
+        Conv2dArgs a{};
+        a.x = x; a.xb = xb;
+        a.w = c->ref_conv[i].w; a.scale = c->ref_conv[i].scale; a.shift = c->ref_conv[i].shift;
+        a.out = c->w_gconv[cur];
+        a.B = B; a.H = H; a.W = W; a.Cin = c->ref_conv[i].cin; a.Cout = c->ref_conv[i].cout;
+        a.k = c->ref_conv[i].k; a.stride = c->ref_conv[i].stride;
+        a.pad_h = same_pad_before(H, a.k, a.stride, &a.Ho);
+        a.pad_w = same_pad_before(W, a.k, a.stride, &a.Wo);
+        HIPCHECK(c, gt_launch_conv2d_bn_relu(a, s));
+        x = a.out; H = a.Ho; W = a.Wo; xb = (int64_t)H * W * a.Cout; cur ^= 1;
+    }
+    GstTailArgs t{};
+    t.x = x; t.mel_len = c->w_mel_len;
+    t.gru_w = c->gru_w; t.gru_u = c->gru_u; t.gru_b = c->gru_b;
+    t.dense_w = c->dense_w; t.dense_b = c->dense_b;
+    t.q_w = c->mq_w; t.q_b = c->mq_b; t.v_tok = c->v_tok; t.ln_g = c->ln_g; t.ln_b = c->ln_b;
+    t.gst = c->w_gst;
+    t.B = B; t.T2 = H; t.gru_in = W * c->ref_conv[g.n_ref_conv - 1].cout; t.u = g.ref_rnn;
+    t.D = g.ref_dense; t.A = g.gst_att; t.ntok = g.n_tokens; t.heads = g.heads;
+    t.stride_prod = 1;
+    for (int i = 0; i < g.n_ref_conv; ++i) t.stride_prod *= g.ref_strides[i];
+    HIPCHECK(c, gt_launch_gst_tail(t, s));
+    return 0;
+}
+
+// processed memory pm = [gst|enc].Wv + bv, with the gst half folded into a per-utterance bias row
+int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
+    const gsttaco_config& g = c->cfg;
+    const float* rowbias = nullptr;
+    if (g.gst_use) {
+        SkinnyArgs k;
+        memset(&k, 0, sizeof(k));
+        k.wp = c->val_gst.wp; k.bias = c->val_gst.bias;
+        k.seg[0] = SkinnySeg{c->w_gst, g.gst_att, g.gst_att / 16, 0};
+        k.nkb = c->val_gst.nkb; k.M = B; k.N = g.att_size; k.n_split = g.att_size;
+        k.out = c->w_rowbias; k.ldo = g.att_size;
+        HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->val_gst.ntiles, s));
+        rowbias = c->w_rowbias;
+    }
+    ConvGemmArgs a{};
+    a.x = c->w_enc; a.w = c->val_enc_w;
+    a.shift = g.gst_use ? nullptr : c->val_bias;
+    a.rowbias = rowbias;
+    a.out = c->w_pm; a.ldo = g.att_size;
+    a.B = B; a.T = Tv; a.Cin = c->enc_out; a.N = g.att_size; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
+    HIPCHECK(c, gt_launch_conv_gemm(a, s));
+    return 0;
+}
+
+int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool has_mask, bool has_noise) {
+    const gsttaco_config& g = c->cfg;
+    const int mel = g.mel_dim, r = c->r, P0 = c->P0, P1 = c->P1, att = c->att, H1 = c->H1, H2 = c->H2;
+    const int XA = P1 + att;
+    const int64_t ld_pre = (int64_t)steps * r * mel;
+    HIPCHECK(c, hipMemsetAsync(c->w_h1[1], 0, (size_t)B * H1 * sizeof(float), s));
+    HIPCHECK(c, hipMemsetAsync(c->w_h2[1], 0, (size_t)B * H2 * sizeof(float), s));
+    HIPCHECK(c, hipMemsetAsync(c->w_c1, 0, (size_t)B * H1 * sizeof(float), s));
+    HIPCHECK(c, hipMemsetAsync(c->w_c2, 0, (size_t)B * H2 * sizeof(float), s));
+    const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
+    const size_t mask_step = (size_t)B * (P0 + P1);
+    int nprof[2] = {0, 0};
+    for (int t = 0; t < steps; ++t) {
+        const int p = t & 1;
+        SkinnyArgs k;
+        // 1. prenet layer 0 on the last emitted frame (Taco2.py:186: decodings[:, -1]; zeros at t=0)
+        memset(&k, 0, sizeof(k));
+        k.wp = c->prenet0.wp; k.bias = c->prenet0.bias;
+        if (t == 0) k.seg[0] = SkinnySeg{c->w_zero, 0, mel / 16, 0};
+        else k.seg[0] = SkinnySeg{c->w_pre + ((size_t)(t - 1) * r + (r - 1)) * mel, ld_pre, mel / 16, 0};
+        k.nkb = c->prenet0.nkb; k.M = B; k.N = P0; k.n_split = P0;
+        k.out = c->w_p1; k.ldo = P0;
+        k.mask = has_mask ? c->w_masks + (size_t)t * mask_step : nullptr; k.ldm = P0;
+        k.drop_rate = g.prenet_rate; k.drop_scale = drop_scale;
+        k.seed_ptr = c->w_seed; k.rng_step = (uint32_t)t; k.rng_stream = 0x1000u;
+        HIPCHECK(c, gt_launch_skinny(EPI_RELU_DROP, k, nullptr, c->prenet0.ntiles, s));
+        // 2. prenet layer 1 -> xa[:, 0:P1]
+        memset(&k, 0, sizeof(k));
+        k.wp = c->prenet1.wp; k.bias = c->prenet1.bias;
+        k.seg[0] = SkinnySeg{c->w_p1, P0, P0 / 16, 0};
+        k.nkb = c->prenet1.nkb; k.M = B; k.N = P1; k.n_split = P1;
+        k.out = c->w_xa; k.ldo = XA;
+        k.mask = has_mask ? c->w_masks + (size_t)t * mask_step + (size_t)B * P0 : nullptr; k.ldm = P1;
+        k.drop_rate = g.prenet_rate; k.drop_scale = drop_scale;
+        k.seed_ptr = c->w_seed; k.rng_step = (uint32_t)t; k.rng_stream = 0x1001u;
+        HIPCHECK(c, gt_launch_skinny(EPI_RELU_DROP, k, nullptr, c->prenet1.ntiles, s));
+        // 3. attention query projection (Steps.py:122)
+        memset(&k, 0, sizeof(k));
+        k.wp = c->query.wp; k.bias = c->query.bias;
+        k.seg[0] = SkinnySeg{c->w_xa, XA, P1 / 16, 0};
+        k.nkb = c->query.nkb; k.M = B; k.N = att; k.n_split = att;
+        k.out = c->w_q; k.ldo = att;
+        HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->query.ntiles, s));
+        // 4. score / monotonic alignment / context -> xa[:, P1:P1+att]
+        AttnStepArgs a{};
+        a.q = c->w_q; a.ldq = att; a.pm = c->w_pm; a.v = c->att_v; a.score_bias = c->att_sb;
+        a.prev = t == 0 ? nullptr : c->w_align + (size_t)(t - 1) * Tv; a.ldprev = (int64_t)steps * Tv;
+        a.noise = has_noise ? c->w_noise + (size_t)t * B * Tv : nullptr; a.ldnoise = Tv;
+        a.align = c->w_align + (size_t)t * Tv; a.ldalign = (int64_t)steps * Tv;
+        a.ctx = c->w_xa + P1; a.ldctx = XA;
+        a.B = B; a.Tv = Tv; a.A = att; a.type = g.att_type; a.sigmoid_noise = g.sigmoid_noise;
+        a.seed_ptr = c->w_seed; a.rng_step = (uint32_t)t;
+        HIPCHECK(c, gt_launch_attn_step(a, s));
+        // 5/6. the two LSTM cells (StackedRNNCells, Taco2.py:111)
+        const bool prof = c->prof_every > 0 && (t % c->prof_every) == 0;
+        for (int layer = 0; layer < 2; ++layer) {
+            memset(&k, 0, sizeof(k));
+            const PackedLinear& L = layer == 0 ? c->lstm0 : c->lstm1;
+            k.wp = L.wp; k.bias = L.bias;
+            if (layer == 0) {
+                k.seg[0] = SkinnySeg{c->w_xa, XA, XA / 16, 0};
+                k.seg[1] = SkinnySeg{c->w_h1[p ^ 1], H1, H1 / 16, 0};
+                k.N = H1; k.c = c->w_c1; k.h = c->w_h1[p]; k.ldh = H1;
+            } else {
+                k.seg[0] = SkinnySeg{c->w_h1[p], H1, H1 / 16, 0};
+                k.seg[1] = SkinnySeg{c->w_h2[p ^ 1], H2, H2 / 16, 0};
+                k.N = H2; k.c = c->w_c2; k.h = c->w_h2[p]; k.ldh = H2;
+            }
+            k.nkb = L.nkb; k.M = B;
+            if (prof) {
+                const size_t need = (size_t)2 * (nprof[layer] + 1);
+                while (c->prof_ev[layer].size() < need) {
+                    hipEvent_t e;
+                    HIPCHECK(c, hipEventCreate(&e));
+                    c->prof_ev[layer].push_back(e);
+                }
+                HIPCHECK(c, hipEventRecord(c->prof_ev[layer][2 * nprof[layer]], s));
+            }
+            HIPCHECK(c, gt_launch_skinny(EPI_LSTM, k, nullptr, L.ntiles, s));
+            if (prof) {
+                HIPCHECK(c, hipEventRecord(c->prof_ev[layer][2 * nprof[layer] + 1], s));
+                nprof[layer]++;
+            }
+        }
+        // 7. projection [h2, ctx] -> r mel frames + stop logit, written in place (Taco2.py:112-118,194-205)
+        memset(&k, 0, sizeof(k));
+        k.wp = c->proj.wp; k.bias = c->proj.bias;
+        k.seg[0] = SkinnySeg{c->w_h2[p], H2, H2 / 16, 0};
+        k.seg[1] = SkinnySeg{c->w_xa + P1, XA, att / 16, 0};
+        k.nkb = c->proj.nkb; k.M = B; k.N = c->proj_out; k.n_split = mel * r;
+        k.out = c->w_pre + (size_t)t * r * mel; k.ldo = ld_pre;
+        k.out2 = c->w_stop + t; k.ldo2 = steps;
+        HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->proj.ntiles, s));
+    }
+    c->prof_count[0] = nprof[0];
+    c->prof_count[1] = nprof[1];
+    return 0;
+}
+
+int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* pre, float* out) {
+    const gsttaco_config& g = c->cfg;
+    const float* x = pre;
+    int cur = 0;
+    for (int i = 0; i < g.n_post; ++i) {
+        const ConvLayer& L = c->post_conv[i];
+        const bool last = i == g.n_post - 1;
+        ConvGemmArgs a{};
+        a.x = x; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
+        a.out = last ? out : c->w_post[cur]; a.ldo = L.cout;
+        a.res = last ? pre : nullptr;                       // post = postnet(x) + x (Taco2.py:230)
+        a.B = B; a.T = Tf; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;
+        a.pad_before = same_pad_before(Tf, L.taps, 1, nullptr);
+        a.act = i < g.post_tanh ? ACT_TANH : ACT_NONE;     // tanh on the first post_tanh layers only (F9)
+        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        x = a.out; cur ^= 1;
+    }
+    return 0;
+}
+
+int check_ready(gsttaco_ctx* c) {
+    if (!c) return GSTTACO_E_INVALID;
+    if (!c->finalized) return fail(c, GSTTACO_E_WEIGHTS, "weights not finalized (call gsttaco_finalize_weights)");
+    return 0;
+}
+
+int check_shape(gsttaco_ctx* c, int B, int Tv, int Tref1, int steps) {
+    const gsttaco_config& g = c->cfg;
+    if (B < 1 || Tv < 1 || steps < 0 || steps > c->steps_max)
+        return fail(c, GSTTACO_E_INVALID, "bad B / Tv / steps");
+    if (B > g.max_batch || Tv > g.max_tokens || Tref1 > g.max_ref_frames)
+        return fail(c, GSTTACO_E_CAPACITY, "batch / tokens / reference frames exceed the capacity given at create");
+    return 0;
+}
+
+// Runs `body` either eagerly on `stream` or through a cached hipGraph captured on the internal stream.
+template <typename F>
+int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key, F body) {
+    if (!c->use_graph) return body(stream);
+    auto it = c->graphs.find(key);
+    if (it == c->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        HIPCHECK(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed));
+        int rc = body(c->cap_stream);
+        hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (e != hipSuccess) return fail(c, GSTTACO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return fail(c, GSTTACO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        it = c->graphs.emplace(key, exec).first;
+    }
+    HIPCHECK(c, hipGraphLaunch(it->second, stream));
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ ABI
+extern "C" {
+
+int gsttaco_abi_version(void) { return GSTTACO_ABI_VERSION; }
+
+const char* gsttaco_last_error(const gsttaco_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, GSTTACO_E_INVALID, "null argument");
+    *out = nullptr;
+    const gsttaco_config& g = *cfg;
+    if (g.abi_version != GSTTACO_ABI_VERSION) return fail(nullptr, GSTTACO_E_INVALID, "ABI version mismatch");
+    auto bad = [&](const char* m) { return fail(nullptr, GSTTACO_E_INVALID, m); };
+    if (g.mel_dim < 16 || g.mel_dim % 16) return bad("Sound.Mel_Dim must be a positive multiple of 16");
+    if (g.step_reduction < 1 || g.max_step < g.step_reduction) return bad("bad Step_Reduction / Max_Step");
+    if (g.vocab < 2 || g.emb < 4 || g.emb % 4) return bad("bad vocabulary / Embedding.Size (multiple of 4)");
+    if (g.n_enc_conv < 1 || g.n_enc_conv > GSTTACO_MAX_LAYERS) return bad("bad encoder conv count");
+    for (int i = 0; i < g.n_enc_conv; ++i)
+        if (g.enc_filters[i] % 16 || g.enc_filters[i] < 16 || g.enc_kernels[i] < 1)
+            return bad("encoder Conv.Filters must be multiples of 16");
+    if (g.enc_rnn < 16 || g.enc_rnn % 16) return bad("Encoder.RNN.Size must be a multiple of 16");
+    if (g.n_prenet != 2) return bad("Decoder.Prenet.Size must have exactly 2 layers");
+    if (g.prenet[0] % 16 || g.prenet[1] % 16 || g.prenet[0] < 16 || g.prenet[1] < 16)
+        return bad("Prenet sizes must be multiples of 16");
+    if (!(g.prenet_rate >= 0.f && g.prenet_rate < 1.f)) return bad("Prenet.Dropout_Rate must be in [0,1)");
+    if (g.n_dec_rnn != 2) return bad("Decoder.RNN.Size must have exactly 2 layers");
+    if (g.dec_rnn[0] % 16 || g.dec_rnn[1] % 16 || g.dec_rnn[0] < 16 || g.dec_rnn[1] < 16)
+        return bad("Decoder.RNN sizes must be multiples of 16");
+    if (g.att_type != GSTTACO_ATT_BMA && g.att_type != GSTTACO_ATT_SMA)
+        return bad("Unsupported attention type");            // reference Taco2.py:74-75
+    if (g.att_size < 16 || g.att_size % 16 || g.att_size > 256) return bad("Attention.Size must be a multiple of 16, <= 256");
+    if (g.n_post < 1 || g.n_post > GSTTACO_MAX_LAYERS) return bad("bad postnet layer count");
+    for (int i = 0; i < g.n_post; ++i)
+        if (g.post_filters[i] % 4 || g.post_filters[i] < 4 || g.post_kernels[i] < 1) return bad("postnet filters must be multiples of 4");
+    if (g.post_filters[g.n_post - 1] != g.mel_dim) return bad("last postnet filter count must equal Mel_Dim");
+    if (g.gst_use) {
+        if (g.n_ref_conv < 1 || g.n_ref_conv > GSTTACO_MAX_LAYERS) return bad("bad reference-encoder conv count");
+        for (int i = 0; i < g.n_ref_conv; ++i)
+            if (g.ref_filters[i] < 1 || g.ref_kernels[i] < 1 || g.ref_strides[i] < 1) return bad("bad reference-encoder conv");
+        if (g.ref_rnn < 1 || g.ref_dense < 1 || g.n_tokens < 1 || g.token_emb < 1) return bad("bad GST sizes");
+        if (g.heads < 1 || g.gst_att % g.heads)
+            return bad("size must be divisible by num_heads.");   // reference Layers.py:155-156
+        if (g.gst_att % 16) return bad("Style_Token.Attention.Size must be a multiple of 16");
+    }
+    if (g.max_batch < 1 || g.max_tokens < 1 || (g.gst_use && g.max_ref_frames < 2)) return bad("bad capacity");
+
+    gsttaco_ctx* c = new gsttaco_ctx();
+    c->cfg = g;
+    c->r = g.step_reduction;
+    c->steps_max = g.max_step / g.step_reduction;
+    c->enc_out = 2 * g.enc_rnn;
+    c->mem_dim = c->enc_out + (g.gst_use ? g.gst_att : 0);
+    c->proj_out = g.mel_dim * g.step_reduction + 1;
+    c->conv_c = g.enc_filters[g.n_enc_conv - 1];
+    c->P0 = g.prenet[0]; c->P1 = g.prenet[1]; c->H1 = g.dec_rnn[0]; c->H2 = g.dec_rnn[1]; c->att = g.att_size;
+    const char* eg = getenv("GSTTACO_GRAPH");
+    c->use_graph = !(eg && eg[0] == '0');
+    build_manifest(c);
+    *out = c;
+    return 0;
+}
+
+void gsttaco_destroy(gsttaco_ctx* c) {
+    if (!c) return;
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (int l = 0; l < 2; ++l)
+        for (auto e : c->prof_ev[l]) (void)hipEventDestroy(e);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    delete c;
+}
+
+int gsttaco_num_weights(const gsttaco_ctx* c) { return c ? (int)c->tensors.size() : GSTTACO_E_INVALID; }
+
+int gsttaco_weight_info(const gsttaco_ctx* c, int i, const char** name, int64_t shape[4], int* ndim) {
+    if (!c || i < 0 || i >= (int)c->tensors.size()) return GSTTACO_E_INVALID;
+    const HostTensor& t = c->tensors[i];
+    if (name) *name = t.name.c_str();
+    if (ndim) *ndim = (int)t.shape.size();
+    if (shape)
+        for (size_t d = 0; d < 4; ++d) shape[d] = d < t.shape.size() ? t.shape[d] : 1;
+    return 0;
+}
+
+int gsttaco_load_weight(gsttaco_ctx* c, const char* name, const float* host, const int64_t* shape, int ndim) {
+    if (!c || !name || !host) return fail(c, GSTTACO_E_INVALID, "null argument");
+    if (c->finalized) return fail(c, GSTTACO_E_WEIGHTS, "weights already finalized");
+    auto it = c->index.find(name);
+    if (it == c->index.end()) return fail(c, GSTTACO_E_WEIGHTS, std::string("unknown weight '") + name + "'");
+    HostTensor& t = c->tensors[it->second];
+    bool ok = ndim == (int)t.shape.size();
+    for (int d = 0; ok && d < ndim; ++d) ok = shape[d] == t.shape[d];
+    if (!ok) return fail(c, GSTTACO_E_WEIGHTS, std::string("weight '") + name + "' has the wrong shape");
+    t.data.assign(host, host + t.numel());
+    t.loaded = true;
+    return 0;
+}
+
+int gsttaco_finalize_weights(gsttaco_ctx* c) {
+    if (!c) return GSTTACO_E_INVALID;
+    if (c->finalized) return 0;
+    for (auto& t : c->tensors)
+        if (!t.loaded) return fail(c, GSTTACO_E_WEIGHTS, "missing weight '" + t.name + "'");
+    const gsttaco_config& g = c->cfg;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= g.device)
+        return fail(c, GSTTACO_E_NO_DEVICE, "no HIP device: the gfx950 kernels are the only compute path (no CPU fallback)");
+    HIPCHECK(c, hipSetDevice(g.device));
+    hipDeviceProp_t prop;
+    HIPCHECK(c, hipGetDeviceProperties(&prop, g.device));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(c, GSTTACO_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    HIPCHECK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+
+    int rc = 0;
+    // ---- encoder
+    {
+        const HostTensor& e = T(c, "encoder.embedding");
+        if ((rc = upload(c, &c->d_emb, e.data.data(), e.data.size()))) return rc;
+        c->enc_conv.resize(g.n_enc_conv);
+        for (int i = 0; i < g.n_enc_conv; ++i)
+            if ((rc = upload_conv(c, &c->enc_conv[i], "encoder.conv" + std::to_string(i)))) return rc;
+        int d = 0;
+        for (const char* dir : {"fwd", "bwd"}) {
+            std::string p = std::string("encoder.bilstm.") + dir;
+            const HostTensor &k = T(c, p + ".kernel"), &u = T(c, p + ".recurrent_kernel"), &b = T(c, p + ".bias");
+            if ((rc = pack_linear(c, &c->bilstm[d], {{k.data.data(), (int)k.shape[0]}, {u.data.data(), (int)u.shape[0]}},
+                                  4 * g.enc_rnn, b.data.data(), g.enc_rnn))) return rc;
+            ++d;
+        }
+    }
+    // ---- GST
+    if (g.gst_use) {
+        for (int i = 0; i < g.n_ref_conv; ++i) {
+            std::string p = "gst.ref.conv" + std::to_string(i);
+            const HostTensor& k = T(c, p + ".kernel");
+            std::vector<float> sc, sh;
+            fold_bn(c, p, sc, sh);
+            auto& L = c->ref_conv[i];
+            L.k = (int)k.shape[0]; L.cin = (int)k.shape[2]; L.cout = (int)k.shape[3]; L.stride = g.ref_strides[i];
+            if ((rc = upload(c, &L.w, k.data.data(), k.data.size()))) return rc;
+            if ((rc = upload(c, &L.scale, sc.data(), sc.size()))) return rc;
+            if ((rc = upload(c, &L.shift, sh.data(), sh.size()))) return rc;
+        }
+        auto up = [&](float** dst, const char* name) {
+            const HostTensor& t = T(c, name);
+            return upload(c, dst, t.data.data(), t.data.size());
+        };
+        if ((rc = up(&c->gru_w, "gst.ref.gru.kernel"))) return rc;
+        if ((rc = up(&c->gru_u, "gst.ref.gru.recurrent_kernel"))) return rc;
+        if ((rc = up(&c->gru_b, "gst.ref.gru.bias"))) return rc;
+        if ((rc = up(&c->dense_w, "gst.ref.dense.kernel"))) return rc;
+        if ((rc = up(&c->dense_b, "gst.ref.dense.bias"))) return rc;
+        if ((rc = up(&c->mq_w, "gst.mha.query.kernel"))) return rc;
+        if ((rc = up(&c->mq_b, "gst.mha.query.bias"))) return rc;
+        if ((rc = up(&c->ln_g, "gst.mha.ln.gamma"))) return rc;
+        if ((rc = up(&c->ln_b, "gst.mha.ln.beta"))) return rc;
+        // v_tok = tanh(tokens).Wv + bv  (GST.py:100-101, Layers.py:175; batch-invariant)
+        const HostTensor &tok = T(c, "gst.tokens"), &wv = T(c, "gst.mha.value.kernel"), &bv = T(c, "gst.mha.value.bias");
+        std::vector<float> vt((size_t)g.n_tokens * g.gst_att);
+        for (int n = 0; n < g.n_tokens; ++n)
+            for (int a = 0; a < g.gst_att; ++a) {
+                double s = bv.data[a];
+                for (int e = 0; e < g.token_emb; ++e)
+                    s += std::tanh((double)tok.data[(size_t)n * g.token_emb + e]) * (double)wv.data[(size_t)e * g.gst_att + a];
+                vt[(size_t)n * g.gst_att + a] = (float)s;
+            }
+        if ((rc = upload(c, &c->v_tok, vt.data(), vt.size()))) return rc;
+    }
+    // ---- decoder step
+    {
+        const HostTensor &k0 = T(c, "decoder.prenet0.kernel"), &b0 = T(c, "decoder.prenet0.bias");
+        const HostTensor &k1 = T(c, "decoder.prenet1.kernel"), &b1 = T(c, "decoder.prenet1.bias");
+        if ((rc = pack_linear(c, &c->prenet0, {{k0.data.data(), (int)k0.shape[0]}}, c->P0, b0.data.data(), 0))) return rc;
+        if ((rc = pack_linear(c, &c->prenet1, {{k1.data.data(), (int)k1.shape[0]}}, c->P1, b1.data.data(), 0))) return rc;
+        const HostTensor &qk = T(c, "decoder.attention.query.kernel"), &qb = T(c, "decoder.attention.query.bias");
+        if ((rc = pack_linear(c, &c->query, {{qk.data.data(), (int)qk.shape[0]}}, c->att, qb.data.data(), 0))) return rc;
+        const HostTensor &vk = T(c, "decoder.attention.value.kernel"), &vb = T(c, "decoder.attention.value.bias");
+        const int goff = g.gst_use ? g.gst_att : 0;     // memory channel order [gst | enc] (GST.py:121-124)
+        if (g.gst_use)
+            if ((rc = pack_linear(c, &c->val_gst, {{vk.data.data(), g.gst_att}}, c->att, vb.data.data(), 0))) return rc;
+        if ((rc = upload(c, &c->val_enc_w, vk.data.data() + (size_t)goff * c->att, (size_t)c->enc_out * c->att))) return rc;
+        if ((rc = upload(c, &c->val_bias, vb.data.data(), vb.data.size()))) return rc;
+        const HostTensor& av = T(c, "decoder.attention.v");
+        if ((rc = upload(c, &c->att_v, av.data.data(), av.data.size()))) return rc;
+        const HostTensor& sb = T(c, "decoder.attention.score_bias");
+        if ((rc = upload(c, &c->att_sb, sb.data.data(), 1))) return rc;
+        for (int l = 0; l < 2; ++l) {
+            std::string p = "decoder.lstm" + std::to_string(l);
+            const HostTensor &k = T(c, p + ".kernel"), &u = T(c, p + ".recurrent_kernel"), &b = T(c, p + ".bias");
+            if ((rc = pack_linear(c, l == 0 ? &c->lstm0 : &c->lstm1,
+                                  {{k.data.data(), (int)k.shape[0]}, {u.data.data(), (int)u.shape[0]}},
+                                  4 * g.dec_rnn[l], b.data.data(), g.dec_rnn[l]))) return rc;
+        }
+        const HostTensor &pk = T(c, "decoder.projection.kernel"), &pb = T(c, "decoder.projection.bias");
+        if ((rc = pack_linear(c, &c->proj, {{pk.data.data(), (int)pk.shape[0]}}, c->proj_out, pb.data.data(), 0))) return rc;
+    }
+    // ---- postnet
+    c->post_conv.resize(g.n_post);
+    for (int i = 0; i < g.n_post; ++i)
+        if ((rc = upload_conv(c, &c->post_conv[i], "postnet.conv" + std::to_string(i)))) return rc;
+
+    // ---- workspace, sized once for the capacity given at create
+    const size_t B = g.max_batch, Tv = g.max_tokens, S = c->steps_max, Tf = S * c->r, mel = g.mel_dim;
+    auto fa = [&](float** p, size_t n) { return dev_alloc(c, (void**)p, n * sizeof(float)); };
+    if ((rc = dev_alloc(c, (void**)&c->w_tokens, B * Tv * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&c->w_mel_len, B * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&c->w_seed, 16))) return rc;
+    if ((rc = fa(&c->w_masks, S * B * (c->P0 + c->P1)))) return rc;
+    if ((rc = fa(&c->w_noise, S * B * Tv))) return rc;
+    size_t actc = g.emb;
+    for (int i = 0; i < g.n_enc_conv; ++i) actc = std::max<size_t>(actc, g.enc_filters[i]);
+    for (int i = 0; i < 2; ++i)
+        if ((rc = fa(&c->w_act[i], B * Tv * actc))) return rc;
+    if ((rc = fa(&c->w_enc, B * Tv * c->enc_out))) return rc;
+    if ((rc = fa(&c->w_cenc, 2 * B * g.enc_rnn))) return rc;
+    c->zero_floats = B * std::max<size_t>({(size_t)mel, (size_t)g.enc_rnn, (size_t)c->H1, (size_t)c->H2});
+    if ((rc = fa(&c->w_zero, c->zero_floats))) return rc;
+    HIPCHECK(c, hipMemset(c->w_zero, 0, c->zero_floats * sizeof(float)));
+    if (g.gst_use) {
+        const size_t Tr = g.max_ref_frames;
+        if ((rc = fa(&c->w_mels_in, B * Tr * mel))) return rc;
+        size_t big = 0;
+        int H = (int)Tr - 1, W = (int)mel;
+        for (int i = 0; i < g.n_ref_conv; ++i) {
+            H = (H + g.ref_strides[i] - 1) / g.ref_strides[i];
+            W = (W + g.ref_strides[i] - 1) / g.ref_strides[i];
+            big = std::max(big, (size_t)H * W * g.ref_filters[i]);
+        }
+        for (int i = 0; i < 2; ++i)
+            if ((rc = fa(&c->w_gconv[i], B * big))) return rc;
+        if ((rc = fa(&c->w_gst, B * g.gst_att))) return rc;
+        if ((rc = fa(&c->w_rowbias, B * c->att))) return rc;
+    }
+    if ((rc = fa(&c->w_pm, B * Tv * c->att))) return rc;
+    if ((rc = fa(&c->w_p1, B * c->P0))) return rc;
+    if ((rc = fa(&c->w_xa, B * (c->P1 + c->att)))) return rc;
+    if ((rc = fa(&c->w_q, B * c->att))) return rc;
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = fa(&c->w_h1[i], B * c->H1))) return rc;
+        if ((rc = fa(&c->w_h2[i], B * c->H2))) return rc;
+    }
+    if ((rc = fa(&c->w_c1, B * c->H1))) return rc;
+    if ((rc = fa(&c->w_c2, B * c->H2))) return rc;
+    if ((rc = fa(&c->w_pre, B * Tf * mel))) return rc;
+    if ((rc = fa(&c->w_stop, B * S))) return rc;
+    if ((rc = fa(&c->w_align, B * S * Tv))) return rc;
+    size_t postc = mel;
+    for (int i = 0; i < g.n_post; ++i) postc = std::max<size_t>(postc, g.post_filters[i]);
+    for (int i = 0; i < 2; ++i)
+        if ((rc = fa(&c->w_post[i], B * Tf * postc))) return rc;
+    if ((rc = fa(&c->w_mel, B * Tf * mel))) return rc;
+    HIPCHECK(c, gt_attn_init());
+    HIPCHECK(c, hipDeviceSynchronize());
+    // host copies are no longer needed
+    for (auto& t : c->tensors) std::vector<float>().swap(t.data);
+    c->finalized = true;
+    return 0;
+}
+
+int gsttaco_encode(gsttaco_ctx* c, const int32_t* tokens, int B, int Tv, float* enc, void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!tokens || !enc) return fail(c, GSTTACO_E_INVALID, "null argument");
+    if ((rc = check_shape(c, B, Tv, 0, 0))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(c, hipMemcpyAsync(c->w_tokens, tokens, (size_t)B * Tv * 4, hipMemcpyDeviceToDevice, s));
+    GraphKey key{1, B, Tv, 0, 0, 0, 0, 0};
+    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv); }))) return rc;
+    HIPCHECK(c, hipMemcpyAsync(enc, c->w_enc, (size_t)B * Tv * c->enc_out * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int gsttaco_gst(gsttaco_ctx* c, const float* mels, const int32_t* lens, int B, int Tref1, float* gst, void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!c->cfg.gst_use) return fail(c, GSTTACO_E_INVALID, "GST is not used");     // reference Model.py:258-259
+    if (!mels || !lens || !gst) return fail(c, GSTTACO_E_INVALID, "null argument");
+    if (Tref1 < 2) return fail(c, GSTTACO_E_INVALID, "mels_for_gst needs at least one frame after the prepended zero frame");
+    if ((rc = check_shape(c, B, 1, Tref1, 0))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(c, hipMemcpyAsync(c->w_mels_in, mels, (size_t)B * Tref1 * c->cfg.mel_dim * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(c, hipMemcpyAsync(c->w_mel_len, lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    GraphKey key{2, B, 0, Tref1, 0, 0, 0, 0};
+    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_gst(c, st, B, Tref1); }))) return rc;
+    HIPCHECK(c, hipMemcpyAsync(gst, c->w_gst, (size_t)B * c->cfg.gst_att * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+static int stage_randomness(gsttaco_ctx* c, hipStream_t s, const float* mask, const float* noise, uint64_t seed,
+                            int B, int Tv, int steps) {
+    if (mask)
+        HIPCHECK(c, hipMemcpyAsync(c->w_masks, mask, (size_t)steps * B * (c->P0 + c->P1) * 4, hipMemcpyDeviceToDevice, s));
+    if (noise)
+        HIPCHECK(c, hipMemcpyAsync(c->w_noise, noise, (size_t)steps * B * Tv * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(c, gt_launch_set_seed(c->w_seed, seed, s));
+    return 0;
+}
+
+int gsttaco_decode(gsttaco_ctx* c, const float* enc, const float* gst, const float* mask, const float* noise,
+                   uint64_t seed, int B, int Tv, int steps, float* pre_mel, float* stop, float* align, void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!enc || !pre_mel || !stop || !align || (c->cfg.gst_use && !gst)) return fail(c, GSTTACO_E_INVALID, "null argument");
+    if ((rc = check_shape(c, B, Tv, 0, steps))) return rc;
+    if (steps == 0) steps = c->steps_max;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(c, hipMemcpyAsync(c->w_enc, enc, (size_t)B * Tv * c->enc_out * 4, hipMemcpyDeviceToDevice, s));
+    if (c->cfg.gst_use)
+        HIPCHECK(c, hipMemcpyAsync(c->w_gst, gst, (size_t)B * c->cfg.gst_att * 4, hipMemcpyDeviceToDevice, s));
+    if ((rc = stage_randomness(c, s, mask, noise, seed, B, Tv, steps))) return rc;
+    GraphKey key{3, B, Tv, 0, steps, mask != nullptr, noise != nullptr, c->prof_every};
+    rc = run_cached(c, s, key, [&](hipStream_t st) {
+        int r2 = enqueue_value_proj(c, st, B, Tv);
+        return r2 ? r2 : enqueue_decode(c, st, B, Tv, steps, mask != nullptr, noise != nullptr);
+    });
+    if (rc) return rc;
+    const size_t mel = c->cfg.mel_dim;
+    HIPCHECK(c, hipMemcpyAsync(pre_mel, c->w_pre, (size_t)B * steps * c->r * mel * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(c, hipMemcpyAsync(stop, c->w_stop, (size_t)B * steps * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(c, hipMemcpyAsync(align, c->w_align, (size_t)B * steps * Tv * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int gsttaco_postnet(gsttaco_ctx* c, const float* pre_mel, int B, int Tf, float* mel, void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!pre_mel || !mel) return fail(c, GSTTACO_E_INVALID, "null argument");
+    if (B < 1 || Tf < 1) return fail(c, GSTTACO_E_INVALID, "bad B / T");
+    if (B > c->cfg.max_batch || Tf > c->steps_max * c->r) return fail(c, GSTTACO_E_CAPACITY, "batch / frames exceed capacity");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)B * Tf * c->cfg.mel_dim;
+    HIPCHECK(c, hipMemcpyAsync(c->w_pre, pre_mel, n * 4, hipMemcpyDeviceToDevice, s));
+    GraphKey key{4, B, 0, 0, Tf, 0, 0, 0};
+    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_postnet(c, st, B, Tf, c->w_pre, c->w_mel); }))) return rc;
+    HIPCHECK(c, hipMemcpyAsync(mel, c->w_mel, n * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const float* mels_for_gst, const int32_t* mel_lengths,
+                           const float* mask, const float* noise, uint64_t seed, int B, int Tv, int Tref1, int steps,
+                           float* mel, float* stop, float* align, float* pre_mel, void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    const bool gst = c->cfg.gst_use != 0;
+    if (!tokens || !mel || !stop || !align) return fail(c, GSTTACO_E_INVALID, "null argument");
+    if (gst && (!mels_for_gst || !mel_lengths)) return fail(c, GSTTACO_E_INVALID, "GST is enabled, but no mel information.");
+    if (!gst) Tref1 = 0;
+    if (gst && Tref1 < 2) return fail(c, GSTTACO_E_INVALID, "mels_for_gst needs at least one frame after the prepended zero frame");
+    if ((rc = check_shape(c, B, Tv, Tref1, steps))) return rc;
+    if (steps == 0) steps = c->steps_max;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t meld = c->cfg.mel_dim;
+    HIPCHECK(c, hipMemcpyAsync(c->w_tokens, tokens, (size_t)B * Tv * 4, hipMemcpyDeviceToDevice, s));
+    if (gst) {
+        HIPCHECK(c, hipMemcpyAsync(c->w_mels_in, mels_for_gst, (size_t)B * Tref1 * meld * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(c, hipMemcpyAsync(c->w_mel_len, mel_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if ((rc = stage_randomness(c, s, mask, noise, seed, B, Tv, steps))) return rc;
+    GraphKey key{0, B, Tv, Tref1, steps, mask != nullptr, noise != nullptr, c->prof_every};
+    rc = run_cached(c, s, key, [&](hipStream_t st) {
+        int r2 = enqueue_encoder(c, st, B, Tv);
+        if (!r2 && gst) r2 = enqueue_gst(c, st, B, Tref1);
+        if (!r2) r2 = enqueue_value_proj(c, st, B, Tv);
+        if (!r2) r2 = enqueue_decode(c, st, B, Tv, steps, mask != nullptr, noise != nullptr);
+        if (!r2) r2 = enqueue_postnet(c, st, B, steps * c->r, c->w_pre, c->w_mel);
+        return r2;
+    });
+    if (rc) return rc;
+    const size_t nf = (size_t)B * steps * c->r * meld;
+    HIPCHECK(c, hipMemcpyAsync(mel, c->w_mel, nf * 4, hipMemcpyDeviceToDevice, s));
+    if (pre_mel) HIPCHECK(c, hipMemcpyAsync(pre_mel, c->w_pre, nf * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(c, hipMemcpyAsync(stop, c->w_stop, (size_t)B * steps * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHECK(c, hipMemcpyAsync(align, c->w_align, (size_t)B * steps * Tv * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int gsttaco_set_profiling(gsttaco_ctx* c, int every) {
+    if (!c || every < 0) return GSTTACO_E_INVALID;
+    c->prof_every = every;
+    return 0;
+}
+
+int gsttaco_get_profile(gsttaco_ctx* c, int layer, float* avg_ms, int* count) {
+    if (!c || layer < 0 || layer > 1 || !avg_ms || !count) return GSTTACO_E_INVALID;
+    const int n = c->prof_count[layer];
+    double sum = 0;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        HIPCHECK(c, hipEventElapsedTime(&ms, c->prof_ev[layer][2 * i], c->prof_ev[layer][2 * i + 1]));
+        sum += ms;
+    }
+    *count = n;
+    *avg_ms = n ? (float)(sum / n) : 0.f;
+    return 0;
+}
+
+int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int layer, int B) {
+    if (!c || layer < 0 || layer > 1) return GSTTACO_E_INVALID;
+    // weights (kernel + recurrent kernel + bias) read once + activations in (x, h_prev, c) and out (h, c)
+    const int64_t H = layer == 0 ? c->H1 : c->H2;
+    const int64_t K = layer == 0 ? (c->P1 + c->att + c->H1) : (c->H1 + c->H2);
+    return 4 * (K * 4 * H + 4 * H) + 4 * (int64_t)B * (K + 3 * H);
+}
+
+}  // extern "C"

@@ -1,0 +1,193 @@
+"""``GST_Tacotron`` -- host-side mirror of the reference class of the same name
+(reference Model.py:37-459), inference methods only:
+
+    GST_Tacotron(is_Training=False).Restore(path)
+    .Inference_Step(tokens, token_lengths, initial_mels, mels_for_gst, mel_lengths_for_gst)
+    .Inference_GST_Step(mels_for_gst, mel_lengths_for_gst)
+    .Inference(sentence_List, mel_List_for_GST)
+
+Same names, argument order/meaning and error behaviour; the Keras functional model
+behind them (Model.py:145-156) is replaced by the HIP kernels behind include/gsttaco.h.
+PyTorch is used for device memory and streams only.  Differences, all additive:
+  * the config is passed explicitly instead of being read from the CWD at import time;
+  * randomness the reference draws unseeded (prenet dropout that is live at inference,
+    Taco2.py:283; SMA sigmoid noise, Steps.py:220-221) can be injected (``prenet_masks``,
+    ``attn_noise``) for parity runs, otherwise it is generated on the GPU from ``seed``;
+  * ``token_lengths`` / ``initial_mels`` are accepted and ignored exactly like the
+    reference ignores them at inference (Model.py:249-253, Taco2.py:161);
+  * the CBHG vocoder output (3rd element of the returned tuple) is out of scope for this
+    path and returned as None.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import capi, weights as weights_mod
+from .feeder import Feeder
+from .hparams import Dims, load_hp, load_token_dict
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class GST_Tacotron:
+    def __init__(self, is_Training=False, hyper_parameters=None, device=None,
+                 max_batch=32, max_tokens=256, max_ref_frames=1025):
+        if is_Training:
+            raise NotImplementedError("only the inference hot path is implemented (training is out of scope)")
+        self.hp_Dict = load_hp(hyper_parameters)
+        self.token_Index_Dict = load_token_dict(self.hp_Dict)
+        self.dims = Dims(self.hp_Dict, vocab=len(self.token_Index_Dict))
+        self.feeder = Feeder(self.hp_Dict, self.token_Index_Dict)
+        if device is None:
+            dev = self.hp_Dict.get("Device", "0")
+            device = int(dev) if str(dev).lstrip("-").isdigit() and int(dev) >= 0 else 0
+        self.device_index = int(device)
+        self.ctx = capi.Context(self.hp_Dict, vocab=len(self.token_Index_Dict), device=self.device_index,
+                                max_batch=max_batch, max_tokens=max_tokens, max_ref_frames=max_ref_frames)
+        self._ready = False
+        self.seed = 0
+
+    # ------------------------------------------------------------------ weights
+    def Restore(self, checkpoint_File_Path=None, weights=None):
+        """reference Model.py:267-276.  Loads a flat ``.npz`` weight file (names/shapes:
+        gst_tacotron_amd.weights.manifest) or an in-memory dict; prints and returns like the
+        reference when nothing is found."""
+        if weights is None:
+            if checkpoint_File_Path is None or not __import__("os").path.exists(checkpoint_File_Path):
+                print("There is no checkpoint.")
+                return self
+            weights = weights_mod.load_npz(checkpoint_File_Path)
+            print("Checkpoint '{}' is loaded.".format(checkpoint_File_Path))
+        weights_mod.check_weights(self.hp_Dict, weights, vocab=len(self.token_Index_Dict))
+        if not torch.cuda.is_available():
+            raise capi.GstTacoError(-2, "no HIP device: the gfx950 kernels are the only compute path (no CPU fallback)")
+        self.ctx.load_weights(weights)
+        self.ctx.finalize()
+        self._ready = True
+        return self
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def device(self):
+        return torch.device("cuda", self.device_index)
+
+    def _dev(self, a, dtype):
+        if a is None:
+            return None
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _require_ready(self):
+        if not self._ready:
+            raise capi.GstTacoError(-4, "weights not loaded (call Restore first)")
+
+    # ------------------------------------------------------------------ hot path
+    def Inference_Step(self, tokens, token_lengths=None, initial_mels=None, mels_for_gst=None,
+                       mel_lengths_for_gst=None, prenet_masks=None, attn_noise=None, seed=None,
+                       steps=None, return_pre_mel=False):
+        """reference Model.py:249-255.  Returns (mel_Logits [B,S*r,mel], stop_Logits [B,S],
+        spectrogram_Logits (None), alignments [B,S,T_v]) as CUDA tensors on the current stream."""
+        self._require_ready()
+        d = self.dims
+        tok = self._dev(tokens, torch.int32)
+        if tok.dim() != 2:
+            raise ValueError("tokens must be [batch, time]")
+        B, Tv = tok.shape
+        mels = lens = None
+        Tref1 = 0
+        if d.gst:
+            if mels_for_gst is None or mel_lengths_for_gst is None:
+                raise ValueError("GST is enabled, but no mel information.")
+            mels = self._dev(mels_for_gst, torch.float32)
+            lens = self._dev(mel_lengths_for_gst, torch.int32)
+            if mels.dim() != 3 or mels.shape[0] != B or mels.shape[2] != d.mel or lens.shape != (B,):
+                raise ValueError("mels_for_gst must be [batch, frames+1, Mel_Dim] with mel_lengths_for_gst [batch]")
+            Tref1 = mels.shape[1]
+        S = d.steps if steps is None else int(steps)
+        masks = self._dev(prenet_masks, torch.float32)
+        noise = self._dev(attn_noise, torch.float32)
+        if masks is not None and masks.numel() != S * B * sum(d.prenet):
+            raise ValueError("prenet_masks must be [steps, 2, batch, prenet]")
+        if noise is not None and tuple(noise.shape) != (S, B, Tv):
+            raise ValueError("attn_noise must be [steps, batch, T_v]")
+        mel = torch.empty((B, S * d.r, d.mel), dtype=torch.float32, device=self.device)
+        pre = torch.empty_like(mel) if return_pre_mel else None
+        stop = torch.empty((B, S), dtype=torch.float32, device=self.device)
+        align = torch.empty((B, S, Tv), dtype=torch.float32, device=self.device)
+        if seed is None:
+            self.seed += 1
+            seed = self.seed
+        with torch.cuda.device(self.device):
+            self.ctx.check(self.ctx.lib.gsttaco_inference_step(
+                self.ctx.handle, _ptr(tok), _ptr(mels), _ptr(lens), _ptr(masks), _ptr(noise),
+                ctypes.c_uint64(int(seed)), B, Tv, Tref1, S, _ptr(mel), _ptr(stop), _ptr(align), _ptr(pre),
+                self._stream()))
+        if return_pre_mel:
+            return mel, stop, None, align, pre
+        return mel, stop, None, align
+
+    def Inference_GST_Step(self, mels_for_gst, mel_lengths_for_gst):
+        """reference Model.py:257-265"""
+        if not self.hp_Dict["GST"]["Use"]:
+            raise NotImplementedError("GST is not used")
+        self._require_ready()
+        mels = self._dev(mels_for_gst, torch.float32)
+        lens = self._dev(mel_lengths_for_gst, torch.int32)
+        B, Tref1 = mels.shape[0], mels.shape[1]
+        gst = torch.empty((B, self.dims.gst_att), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.ctx.check(self.ctx.lib.gsttaco_gst(self.ctx.handle, _ptr(mels), _ptr(lens), B, Tref1, _ptr(gst), self._stream()))
+        return gst
+
+    def Inference(self, sentence_List, mel_List_for_GST=None, label=None, **kwargs):
+        """reference Model.py:342-367 (the export thread -- plots / Griffin-Lim wavs -- is out of scope)."""
+        print("Inference running...")
+        pattern_Dict = self.feeder.Get_Inference_Pattern(sentence_List, mel_List_for_GST)
+        if pattern_Dict is None:
+            print("Inference fail.")
+            return None
+        return self.Inference_Step(**pattern_Dict, **kwargs)
+
+    # ------------------------------------------------------------------ per-phase entry points (tests / profiling)
+    def encode(self, tokens):
+        self._require_ready()
+        tok = self._dev(tokens, torch.int32)
+        B, Tv = tok.shape
+        enc = torch.empty((B, Tv, self.dims.enc_out), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.ctx.check(self.ctx.lib.gsttaco_encode(self.ctx.handle, _ptr(tok), B, Tv, _ptr(enc), self._stream()))
+        return enc
+
+    def decode(self, enc, gst=None, prenet_masks=None, attn_noise=None, seed=0, steps=None):
+        self._require_ready()
+        d = self.dims
+        enc = self._dev(enc, torch.float32)
+        gst = self._dev(gst, torch.float32)
+        B, Tv = enc.shape[0], enc.shape[1]
+        S = d.steps if steps is None else int(steps)
+        masks = self._dev(prenet_masks, torch.float32)
+        noise = self._dev(attn_noise, torch.float32)
+        pre = torch.empty((B, S * d.r, d.mel), dtype=torch.float32, device=self.device)
+        stop = torch.empty((B, S), dtype=torch.float32, device=self.device)
+        align = torch.empty((B, S, Tv), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.ctx.check(self.ctx.lib.gsttaco_decode(
+                self.ctx.handle, _ptr(enc), _ptr(gst), _ptr(masks), _ptr(noise), ctypes.c_uint64(int(seed)),
+                B, Tv, S, _ptr(pre), _ptr(stop), _ptr(align), self._stream()))
+        return pre, stop, align
+
+    def postnet(self, pre_mel):
+        self._require_ready()
+        pre = self._dev(pre_mel, torch.float32)
+        B, T = pre.shape[0], pre.shape[1]
+        mel = torch.empty_like(pre)
+        with torch.cuda.device(self.device):
+            self.ctx.check(self.ctx.lib.gsttaco_postnet(self.ctx.handle, _ptr(pre), B, T, _ptr(mel), self._stream()))
+        return mel

@@ -115,7 +115,7 @@ def synthetic_weights(hp, seed=0, vocab=None, gain=1.0):
             fan_in, fan_out = rf * shape[-2], rf * shape[-1]
             lim = gain * np.sqrt(6.0 / (fan_in + fan_out))
             a = rng.uniform(-lim, lim, shape)
-        w[name] = np.ascontiguousarray(a, dtype=np.float32)
+        w[name] = np.require(np.asarray(a, dtype=np.float32), requirements="C").reshape(shape)
     return w
 
 
@@ -135,4 +135,4 @@ def save_npz(path, weights):
 
 def load_npz(path):
     with np.load(path) as z:
-        return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files}
+        return {k: np.asarray(z[k], dtype=np.float32, order="C") for k in z.files}

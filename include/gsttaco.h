@@ -1,0 +1,161 @@
+/*
+ * gsttaco.h -- C-ABI of the MI355X-native GST-Tacotron inference hot path.
+ *
+ * The reference (CODEJIN/GST_Tacotron, TF2/Keras) has no FFI/plugin interface: its
+ * boundary is the Python class GST_Tacotron (reference Model.py:37) and
+ * Hyper_Parameters.json.  This header is what a binding for that class calls instead
+ * of the Keras functional model `model_Dict['Inference']` (reference Model.py:145-156):
+ *
+ *   gsttaco_create / gsttaco_load_weight / gsttaco_finalize_weights
+ *       <- GST_Tacotron.__init__ + Model_Generate + Restore   (Model.py:38-40, 42-189, 267-276)
+ *   gsttaco_inference_step
+ *       <- GST_Tacotron.Inference_Step                        (Model.py:249-255)
+ *   gsttaco_encode      <- Modules/Taco2.py:12-51   Encoder.call
+ *   gsttaco_gst         <- Modules/GST.py:91-109    Style_Token_Layer.call
+ *                          (== GST_Tacotron.Inference_GST_Step, Model.py:257-265)
+ *   gsttaco_decode      <- Modules/Taco2.py:153-228 Decoder.call loop (training=False),
+ *                          Decoder_Step :96-120, Prenet :262-283,
+ *                          Modules/Attention/Steps.py:107-229 (BMA / SMA)
+ *   gsttaco_postnet     <- Modules/Taco2.py:131-149, 230
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative GSTTACO_E_* code; nothing throws
+ *     across the ABI; gsttaco_last_error() returns a message for the last failure.
+ *   - tensor arguments are DEVICE pointers (HIP) owned by the caller, dense row-major,
+ *     innermost dimension contiguous, float32 unless stated; weights are HOST pointers.
+ *   - all work is enqueued on the given hipStream_t (passed as void*); no implicit sync.
+ *   - one ctx per device; a ctx is not thread-safe; distinct ctxs are independent.
+ *   - there is NO CPU fallback: without a gfx950 device every compute call fails with
+ *     GSTTACO_E_NO_DEVICE.
+ */
+#ifndef GSTTACO_H
+#define GSTTACO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSTTACO_ABI_VERSION 1
+#define GSTTACO_MAX_LAYERS 8
+
+enum {
+    GSTTACO_OK = 0,
+    GSTTACO_E_INVALID = -1,     /* bad argument / unsupported configuration */
+    GSTTACO_E_NO_DEVICE = -2,   /* no HIP device (the product path has no CPU fallback) */
+    GSTTACO_E_HIP = -3,         /* a HIP runtime call failed */
+    GSTTACO_E_WEIGHTS = -4,     /* missing / mis-shaped weight, or weights not finalized */
+    GSTTACO_E_CAPACITY = -5     /* batch / tokens / frames exceed the capacity given at create */
+};
+
+enum { GSTTACO_ATT_BMA = 0, GSTTACO_ATT_SMA = 1 };   /* reference Taco2.py:66-75 */
+
+/* Mirrors the hot-path keys of Hyper_Parameters.json (reference file of that name). */
+typedef struct gsttaco_config {
+    int32_t abi_version;        /* GSTTACO_ABI_VERSION */
+    int32_t device;             /* HIP device ordinal */
+    /* Sound / loop */
+    int32_t mel_dim;            /* Sound.Mel_Dim */
+    int32_t step_reduction;     /* Step_Reduction */
+    int32_t max_step;           /* Max_Step (decoder runs Max_Step // Step_Reduction iterations, Taco2.py:213) */
+    /* Tacotron2.Encoder */
+    int32_t vocab;              /* len(Token_Index_Dict) */
+    int32_t emb;                /* Embedding.Size */
+    int32_t n_enc_conv;
+    int32_t enc_filters[GSTTACO_MAX_LAYERS];
+    int32_t enc_kernels[GSTTACO_MAX_LAYERS];
+    int32_t enc_rnn;            /* RNN.Size (per direction) */
+    /* Tacotron2.Decoder */
+    int32_t n_prenet;           /* must be 2 */
+    int32_t prenet[GSTTACO_MAX_LAYERS];
+    float   prenet_rate;        /* Prenet.Dropout_Rate -- live at inference (Taco2.py:283) */
+    int32_t n_dec_rnn;          /* must be 2 */
+    int32_t dec_rnn[GSTTACO_MAX_LAYERS];
+    int32_t att_type;           /* GSTTACO_ATT_* */
+    int32_t att_size;           /* Attention.Size */
+    float   sigmoid_noise;      /* SMA 2.0 (Steps.py:212), BMA 0.0 (Steps.py:58) */
+    int32_t n_post;             /* len(Decoder.Conv.Filters)+1 */
+    int32_t post_filters[GSTTACO_MAX_LAYERS];
+    int32_t post_kernels[GSTTACO_MAX_LAYERS];
+    int32_t post_tanh;          /* number of leading postnet layers followed by tanh (Taco2.py:145) */
+    /* GST */
+    int32_t gst_use;
+    int32_t n_ref_conv;
+    int32_t ref_filters[GSTTACO_MAX_LAYERS];
+    int32_t ref_kernels[GSTTACO_MAX_LAYERS];
+    int32_t ref_strides[GSTTACO_MAX_LAYERS];
+    int32_t ref_rnn;            /* Reference_Encoder.RNN.Size */
+    int32_t ref_dense;          /* Reference_Encoder.Dense.Size */
+    int32_t n_tokens;           /* Style_Token.Size */
+    int32_t token_emb;          /* Style_Token.Embedding.Size */
+    int32_t heads;              /* Style_Token.Attention.Head */
+    int32_t gst_att;            /* Style_Token.Attention.Size */
+    /* capacity: workspace is sized once, at finalize */
+    int32_t max_batch;
+    int32_t max_tokens;
+    int32_t max_ref_frames;     /* frames of mels_for_gst INCLUDING the prepended zero frame */
+} gsttaco_config;
+
+typedef struct gsttaco_ctx gsttaco_ctx;
+
+int gsttaco_abi_version(void);
+
+/* Validates cfg and creates a context.  Does not touch the GPU (so the host logic is
+ * testable without one); the device is first used by gsttaco_finalize_weights. */
+int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out);
+void gsttaco_destroy(gsttaco_ctx* ctx);
+const char* gsttaco_last_error(const gsttaco_ctx* ctx);   /* ctx may be NULL: last create error */
+
+/* Weight manifest (names/shapes in the TF variable layouts). */
+int gsttaco_num_weights(const gsttaco_ctx* ctx);
+int gsttaco_weight_info(const gsttaco_ctx* ctx, int index, const char** name, int64_t shape[4], int* ndim);
+/* Copies one tensor (HOST float32 pointer) into the context. */
+int gsttaco_load_weight(gsttaco_ctx* ctx, const char* name, const float* host_data,
+                        const int64_t* shape, int ndim);
+/* BN folding, MFMA-fragment repack, upload to HBM, workspace allocation. */
+int gsttaco_finalize_weights(gsttaco_ctx* ctx);
+
+/* tokens [B,Tv] int32  ->  enc [B,Tv,2*enc_rnn] */
+int gsttaco_encode(gsttaco_ctx* ctx, const int32_t* tokens, int B, int Tv, float* enc, void* stream);
+
+/* mels_for_gst [B,Tref1,mel] (frame 0 = the prepended zero frame, dropped inside as GST.py:98 does),
+ * mel_lengths [B] int32 (excluding that frame)  ->  gst [B,gst_att] */
+int gsttaco_gst(gsttaco_ctx* ctx, const float* mels_for_gst, const int32_t* mel_lengths,
+                int B, int Tref1, float* gst, void* stream);
+
+/* enc [B,Tv,2*enc_rnn], gst [B,gst_att] (NULL when GST is off)
+ * prenet_mask: NULL (on-device Philox, `seed`) or keep-masks [steps,2,B,prenet] float32 (1 keep / 0 drop)
+ * attn_noise : NULL (on-device Philox, `seed`) or N(0,1) samples [steps,B,Tv]
+ * steps      : 0 = Max_Step // Step_Reduction, else 1..that
+ * outputs    : pre_mel [B,steps*r,mel], stop [B,steps], align [B,steps,Tv] */
+int gsttaco_decode(gsttaco_ctx* ctx, const float* enc, const float* gst,
+                   const float* prenet_mask, const float* attn_noise, uint64_t seed,
+                   int B, int Tv, int steps, float* pre_mel, float* stop, float* align, void* stream);
+
+/* pre_mel [B,T,mel] -> mel [B,T,mel] (5 x Conv1D+BN, tanh on the first post_tanh layers, + residual) */
+int gsttaco_postnet(gsttaco_ctx* ctx, const float* pre_mel, int B, int T, float* mel, void* stream);
+
+/* The whole Inference_Step (Model.py:249-255) minus the CBHG vocoder: encoder, GST, decode loop,
+ * postnet, replayed from one cached hipGraph per (B,Tv,Tref1,steps) shape.
+ * mels_for_gst / mel_lengths are ignored (may be NULL) when GST is off; pre_mel may be NULL. */
+int gsttaco_inference_step(gsttaco_ctx* ctx, const int32_t* tokens,
+                           const float* mels_for_gst, const int32_t* mel_lengths,
+                           const float* prenet_mask, const float* attn_noise, uint64_t seed,
+                           int B, int Tv, int Tref1, int steps,
+                           float* mel, float* stop, float* align, float* pre_mel, void* stream);
+
+/* Measurement support (bench.py): per-kernel timing of the last gsttaco_inference_step replay.
+ * When enabled, HIP event-record nodes bracket every `every`-th launch of the dominant decode
+ * kernel (the LSTM gate GEMM) inside the graph. */
+int gsttaco_set_profiling(gsttaco_ctx* ctx, int every);
+/* After the stream has been synchronised by the caller: average duration (ms) of the bracketed
+ * launches of decode-LSTM layer `layer` (0/1) and how many were bracketed. */
+int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
+/* Algorithmic bytes one launch of decode-LSTM layer `layer` moves at batch B (weights + activations). */
+int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* ctx, int layer, int B);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSTTACO_H */

@@ -1,0 +1,4 @@
+set -x
+cd $GRAFT_REPO_ROOT
+python -c "import torch;print(torch.cuda.is_available(), torch.cuda.get_device_name(0))"
+GSTTACO_GRAPH=0 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -s 2>&1 | tail -40

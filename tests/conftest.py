@@ -1,0 +1,39 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+GOLDEN_CASES = ["tiny_sma_r2_gst", "tiny_bma_r1_gst", "tiny_sma_r1_nogst", "tiny_bma_r3_nodrop",
+                "full_sma_r2_short", "full_cfg1_short"]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Returns (hp, weights, fixture dict).  Weights are regenerated from the stored seed and verified
+    against the per-tensor checksums stored with the vectors."""
+    from gst_tacotron_amd import weights as W
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {k: z[k] for k in z.files}
+    hp = json.loads(str(g["hp_json"]))
+    w = W.synthetic_weights(hp, seed=int(g["wseed"]))
+    names = sorted(w)
+    sums = np.array([[float(np.sum(w[n], dtype=np.float64)), float(np.sum(np.abs(w[n]), dtype=np.float64))] for n in names])
+    np.testing.assert_allclose(sums, g["weight_checksums"], rtol=1e-12, atol=1e-12)
+    g["prenet_masks"] = g["prenet_masks"].astype(np.float32)
+    return hp, w, g
+
+
+@pytest.fixture(scope="session")
+def has_gpu():
+    import torch
+    return torch.cuda.is_available()
