@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/s of the whole Inference_Step (encoder + GST + decode loop +
+postnet; CBHG vocoder excluded) on BASELINE.json configs[1]: GST on, batch 32 per GPU, 128-token
+utterances, Step_Reduction 2, Max_Step 1000, LJSpeech 80-mel hyper-parameters, fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one Inference_Step over one synthetic batch per rank (inputs resident in HBM, weights
+random-init of the reference architecture, randomness from the on-device Philox generator).
+Utterances shard over ranks with no data-path collective; the only exchange is the final RCCL
+gather of the mels to rank 0, which is inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from gst_tacotron_amd import distributed as gdist  # noqa: E402
+from gst_tacotron_amd import synthetic, weights  # noqa: E402
+from gst_tacotron_amd.model import GST_Tacotron  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BATCH_PER_GPU = 32
+PROFILE_EVERY = 20             # bracket every 20th decode step's LSTM launches with HIP events
+
+
+def cpu_baseline(hp, w, inputs, budget_s=15.0):
+    """The torch-CPU restatement of the TF2 graph (oracle/torch_ref.py, kind "port"; TensorFlow is not
+    installable here) timed on this box's host cores on a bounded sample of the same workload.  The thread
+    count is the fastest of a short calibration (eager per-op dispatch does not scale to every core)."""
+    from oracle.torch_ref import TorchReference
+    B, Tv = inputs["tokens"].shape
+    d_r = int(hp["Step_Reduction"])
+    total_steps = int(hp["Max_Step"]) // d_r
+    rng = np.random.default_rng(123)
+    masks, noise = synthetic.make_randomness(rng, total_steps, B, Tv, hp["Tacotron2"]["Decoder"]["Prenet"]["Size"])
+    ref = TorchReference(hp, w, torch.float32)
+
+    def run(steps):
+        t0 = time.perf_counter()
+        ref.inference_step(inputs["tokens"], inputs.get("mels_for_gst"), inputs.get("mel_lengths_for_gst"),
+                           masks[:steps], noise[:steps], steps=steps)
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    best = None
+    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
+        torch.set_num_threads(nt)
+        run(1)
+        t1, t5 = run(1), run(5)
+        per_step = max((t5 - t1) / 4.0, 1e-4)
+        if best is None or per_step < best[1]:
+            best = (nt, per_step, t1)
+    nt, per_step, t_fixed = best
+    torch.set_num_threads(nt)
+    steps_sample = int(max(10, min(total_steps, (budget_s - t_fixed) / per_step)))
+    dt = run(steps_sample)
+    frames = B * steps_sample * d_r
+    return {"value": frames / dt, "unit": "mel-frames/s", "cores": nt, "kind": "port",
+            "sample": "cfg2 batch {} x {} tokens: encoder+GST once, {} of {} decode steps, postnet on those {} frames; "
+                      "{:.1f} s wall on {} of {} host CPUs (fastest of 8/16/32/64 threads); torch-CPU eager restatement "
+                      "of the TF2 graph (TF not installable)".format(B, Tv, steps_sample, total_steps, steps_sample * d_r,
+                                                                      dt, nt, ncpu)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the bounded CPU-baseline sample")
+    args = ap.parse_args()
+
+    rank, local_rank, world = gdist.init_process_group()
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
+    torch.cuda.set_device(local_rank)
+
+    hp, inputs = synthetic.config_inputs("cfg2", batch=BATCH_PER_GPU, seed=1 + rank)
+    w = weights.synthetic_weights(hp, seed=0)
+    B, Tv = inputs["tokens"].shape
+    Tref1 = inputs["mels_for_gst"].shape[1]
+    model = GST_Tacotron(hyper_parameters=hp, device=local_rank, max_batch=B, max_tokens=Tv, max_ref_frames=Tref1)
+    model.Restore(weights=w)
+    lib, handle = model.ctx.lib, model.ctx.handle
+    model.ctx.check(lib.gsttaco_set_profiling(handle, PROFILE_EVERY))
+
+    dev = model.device
+    tok = torch.as_tensor(inputs["tokens"]).to(dev)
+    mels = torch.as_tensor(inputs["mels_for_gst"]).to(dev)
+    lens = torch.as_tensor(inputs["mel_lengths_for_gst"]).to(dev)
+    n_total = B * world
+
+    def one_step(i):
+        mel, stop, _, align = model.Inference_Step(tok, None, None, mels, lens, seed=1000 + i)
+        return gdist.gather_to_root(mel, n_total=n_total)
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(args.steps):
+        out = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel = the decode-loop LSTM gate GEMM (gt_skinny_kernel<EPI_LSTM>, layer 2: [B,2048]x[2048,4096]);
+    # HIP event nodes inside the graph, on the stream the kernel runs on, last timed replay
+    prof = {}
+    for layer in (0, 1):
+        ms, cnt = ctypes.c_float(), ctypes.c_int()
+        model.ctx.check(lib.gsttaco_get_profile(handle, layer, ctypes.byref(ms), ctypes.byref(cnt)))
+        prof[layer] = (ms.value, cnt.value, int(lib.gsttaco_lstm_launch_bytes(handle, layer, B)))
+
+    if rank == 0:
+        assert out is not None and tuple(out.shape) == (n_total, model.dims.steps * model.dims.r, model.dims.mel)
+        assert bool(torch.isfinite(out).all())
+        frames = n_total * model.dims.max_step * args.steps
+        ms1, cnt1, bytes1 = prof[1]
+        achieved = (bytes1 / (ms1 * 1e-3)) / 1e9 if ms1 > 0 else 0.0
+        line = {
+            "metric": "mel-frames/s", "value": frames / elapsed, "unit": "mel-frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: GST on, batch 32 per GPU, 128-token utterances, "
+                                   "Step_Reduction 2, Max_Step 1000, LJSpeech 80-mel hparams; whole Inference_Step "
+                                   "(encoder+GST+decode+postnet, vocoder excluded)",
+                       "global_batch": n_total, "tokens": Tv, "ref_frames": Tref1 - 1,
+                       "parallelism": "utterance-sharded x{} + final RCCL gather".format(world)},
+            "roofline": {"bound": "hbm", "kernel": "gt_skinny_kernel<EPI_LSTM> decode LSTM layer 2 (33.6 MB fp32 weights/launch)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": bytes1, "avg_launch_us": ms1 * 1e3, "launches_timed": cnt1,
+                         "layer1_avg_launch_us": prof[0][0] * 1e3, "layer1_bytes_per_launch": prof[0][2]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(hp, w, inputs, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

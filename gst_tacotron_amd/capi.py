@@ -9,6 +9,8 @@ import ctypes
 import os
 
 import numpy as np
+import torch  # noqa: F401  -- must be imported BEFORE the dlopen below: torch bundles the HIP runtime that owns the
+#                     tensors/streams handed to the C-ABI, and libgsttaco.so has to bind to that same libamdhip64
 
 from .hparams import Dims
 
@@ -24,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "gsttaco_abi_version", "gsttaco_create", "gsttaco_destroy", "gsttaco_last_error",
     "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight", "gsttaco_finalize_weights",
     "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_inference_step",
-    "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_lstm_launch_bytes",
+    "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_lstm_launch_bytes", "gsttaco_debug_stamps",
 )
 
 _I32A = ctypes.c_int32 * MAX_LAYERS
@@ -89,6 +91,8 @@ def load_library(path=None):
     lib.gsttaco_get_profile.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     lib.gsttaco_lstm_launch_bytes.argtypes = [vp, i32, i32]
     lib.gsttaco_lstm_launch_bytes.restype = ctypes.c_int64
+    lib.gsttaco_debug_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.gsttaco_debug_stamps.restype = ctypes.c_int
     for fn in ("gsttaco_create", "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight",
                "gsttaco_finalize_weights", "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet",
                "gsttaco_inference_step", "gsttaco_set_profiling", "gsttaco_get_profile"):

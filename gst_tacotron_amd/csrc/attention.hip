@@ -179,7 +179,8 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
     if (tid < A && A <= 256) {
         float z = partial[tid];
         for (int p = 1; p < cparts; ++p) z += partial[p * 256 + tid];
-        P.ctx[(size_t)b * P.ldctx + tid] = z;
+        if (P.ctx_mt > 0) P.ctx[gt_blk_off(b, tid, P.ctx_mt)] = z;
+        else P.ctx[(size_t)b * P.ldctx + tid] = z;
     }
 }
 
@@ -189,6 +190,23 @@ hipError_t gt_attn_init() {
 }
 
 __global__ void gt_set_seed_kernel(uint64_t* dst, uint64_t seed) { *dst = seed; }
+
+// State re-initialisation inside captured graphs is a KERNEL node, not a memset node: on ROCm 7.x a
+// hipMemsetAsync node was observed to race with the kernel node that follows it (stale LSTM state after a
+// replay with a different batch), while kernel->kernel edges are always honoured.
+__global__ __launch_bounds__(256) void gt_zero_kernel(float4* p, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+hipError_t gt_launch_zero(float* p, size_t n_floats, hipStream_t stream) {
+    const size_t n4 = (n_floats + 3) / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gt_zero_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<float4*>(p), n4);
+    return hipGetLastError();
+}
 
 hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream) {
     hipLaunchKernelGGL(gt_set_seed_kernel, dim3(1), dim3(1), 0, stream, dst, seed);

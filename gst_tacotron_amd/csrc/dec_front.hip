@@ -1,0 +1,371 @@
+// Fused decoder-step front end, one 1024-thread workgroup per utterance:
+//   prenet Dense+ReLU+Dropout x2 (reference Modules/Taco2.py:262-283, dropout live at inference :283)
+//   attention Query Dense                        (Modules/Attention/Steps.py:122)
+//   score / SMA|BMA alignment / context          (Steps.py:126-166, 168-199, 215-229)
+// on the hoisted processed memory (Steps.py:123 is loop-invariant).
+//
+// Why one kernel: on MI355X a dependent kernel boundary costs ~1.5 us and a tiny kernel ~3-5 us of pure
+// latency; the four separate launches of v1 (prenet0, prenet1, query, attention) cost ~31 us per decoder
+// step.  Everything here is per-utterance, so one workgroup can run the whole chain with only
+// workgroup barriers in between.  The price is that each workgroup pulls the prenet/query weights
+// (475 KB fp32) from L2 itself; to hide that, EVERY weight load of prenet0/prenet1 and the utterance's
+// processed-memory rows are issued before the first dependent instruction (~25 x 16-byte loads in flight
+// per lane, 16 waves per CU), and the query weights are requested while prenet0 computes.
+//
+// GEMV mapping: lane = 4 consecutive output columns (one coalesced 16-byte load per k row), the K range
+// is split over the remaining lanes and reduced through LDS.  Attention mapping: L lanes per memory row,
+// each holding NP float4 pieces of the row in REGISTERS for both the score and the context pass (the
+// processed memory is read from L2 exactly once per step); row reduction by DPP/shuffle, context
+// reduction by shuffle across the wave's rows and LDS across waves.
+#include "device_utils.h"
+#include "kernels.h"
+#include "../../include/gsttaco.h"
+
+#define FT 1024            // threads per workgroup
+#define FMAXR 16           // max weight rows (float4 loads) per lane per GEMV phase (two register blocks of 8)
+#define FKEEP 1            // row chunks of the processed memory kept in registers
+
+struct GemvPlan {
+    int ncg, kparts, rows, cg, kp;
+};
+
+__device__ __forceinline__ GemvPlan make_plan(int K, int N, int tid) {
+    GemvPlan p;
+    p.ncg = N >> 2;
+    p.kparts = FT / p.ncg;
+    if (p.kparts > K) p.kparts = K;
+    p.rows = (K + p.kparts - 1) / p.kparts;
+    p.cg = tid % p.ncg;
+    p.kp = tid / p.ncg;
+    return p;
+}
+
+// loads rows [i0, i0+MAXR) of this lane's k range
+template <int MAXR>
+__device__ __forceinline__ void gemv_load(const float* __restrict__ W, int K, int N, const GemvPlan& p, int i0, float4 (&r)[MAXR]) {
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int k = p.kp * p.rows + i0 + i;
+        r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i0 + i < p.rows && p.kp < p.kparts && k < K)
+            r[i] = *reinterpret_cast<const float4*>(W + (size_t)k * N + p.cg * 4);
+    }
+}
+
+template <int MAXR>
+__device__ __forceinline__ void gemv_acc(const float* xs, int K, const GemvPlan& p, int i0, const float4 (&r)[MAXR], float4& acc) {
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) {
+        const int k = p.kp * p.rows + i0 + i;
+        if (i0 + i < p.rows && p.kp < p.kparts && k < K) {
+            const float x = xs[k];
+            acc.x += x * r[i].x; acc.y += x * r[i].y; acc.z += x * r[i].z; acc.w += x * r[i].w;
+        }
+    }
+}
+
+// partial[kp][N] <- this lane's partial sums; caller syncs and reduces
+__device__ __forceinline__ void gemv_store(const GemvPlan& p, int N, const float4& acc, float* partial) {
+    if (p.kp < p.kparts) *reinterpret_cast<float4*>(partial + (size_t)p.kp * N + p.cg * 4) = acc;
+}
+
+__device__ __forceinline__ float reduce_partial(const float* partial, int kparts, int N, int col) {
+    float z = 0.f;
+    for (int p = 0; p < kparts; ++p) z += partial[(size_t)p * N + col];
+    return z;
+}
+
+__device__ __forceinline__ float front_wave_incl_scan(float x, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        float y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+
+template <int L, int NP>
+__global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
+    constexpr int A = 4 * L * NP;
+    constexpr int ROWS = FT / L;            // memory rows per pass
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int mel = P.mel, P0 = P.P0, P1 = P.P1, Tv = P.Tv;
+
+    // LDS carve (floats): xs[max(mel,P0,P1)] | y0[P0] | y1[P1] | q[A] | vv[A] | sc[Tv] | pv[Tv] | al[Tv] | red[16*A] | partial[...]
+    int mx = mel > P0 ? mel : P0; if (P1 > mx) mx = P1;
+    float* xs = smem;
+    float* y0 = xs + ((mx + 3) & ~3);
+    float* y1 = y0 + P0;
+    float* qs = y1 + P1;
+    float* vs = qs + A;
+    float* sc = vs + A;
+    float* pv = sc + Tv;
+    float* al = pv + Tv;
+    float* red = al + ((Tv + 3) & ~3);
+    float* partial = red + 16 * A;
+
+    // ---- issue every independent global load first
+    const GemvPlan g0 = make_plan(mel, P0, tid);
+    const GemvPlan g1 = make_plan(P0, P1, tid);
+    const GemvPlan g2 = make_plan(P1, A, tid);
+    // register budget (128 VGPRs at 16 waves/CU): at most two 8-row weight blocks + the memory rows live at once
+    float4 r0a[8], r1a[8];
+    gemv_load<8>(P.w0, mel, P0, g0, 0, r0a);
+    gemv_load<8>(P.w1, P0, P1, g1, 0, r1a);
+
+    const int row = tid / L, li = tid % L;
+    const float* pm = P.pm + (size_t)b * Tv * A;
+    float4 vreg[FKEEP][NP];
+#pragma unroll
+    for (int c = 0; c < FKEEP; ++c) {
+        const int t = c * ROWS + row;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            vreg[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < Tv) vreg[c][j] = *reinterpret_cast<const float4*>(pm + (size_t)t * A + 4 * (li + L * j));
+        }
+    }
+    for (int i = tid; i < mel; i += FT) xs[i] = P.frame[(size_t)b * P.ldframe + i];
+    for (int a = tid; a < A; a += FT) vs[a] = P.v[a];
+    for (int t = tid; t < Tv; t += FT) pv[t] = P.prev ? P.prev[(size_t)b * P.ldprev + t] : (t == 0 ? 1.f : 0.f);
+    GT_STAMP(P.dbg, 0);
+    const float sbias = P.score_bias[0];
+    const uint64_t seed = *P.seed_ptr;
+    __syncthreads();
+    GT_STAMP(P.dbg, 1);
+
+    // ---- prenet layer 0
+    {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        gemv_acc<8>(xs, mel, g0, 0, r0a, acc);
+        gemv_store(g0, P0, acc, partial);
+    }
+    float4 r1b[8];
+    gemv_load<8>(P.w1, P0, P1, g1, 8, r1b);         // second half of prenet1, in flight while prenet0 finishes
+    __syncthreads();
+    for (int c = tid; c < P0; c += FT) {
+        float v = fmaxf(reduce_partial(partial, g0.kparts, P0, c) + P.b0[c], 0.f);
+        if (P.drop_rate > 0.f) {
+            float keep;
+            if (P.mask0) keep = P.mask0[(size_t)b * P0 + c];
+            else {
+                Philox4 ph = gt_philox(seed, (uint32_t)(b * P0 + c), P.rng_step, 0u, 0x1000u);
+                keep = (gt_u01(ph.x) > P.drop_rate) ? 1.f : 0.f;
+            }
+            v = v * P.drop_scale * keep;
+        }
+        y0[c] = v;
+    }
+    __syncthreads();
+    GT_STAMP(P.dbg, 2);
+    // ---- prenet layer 1
+    float4 r2a[8];
+    {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        gemv_acc<8>(y0, P0, g1, 0, r1a, acc);
+        gemv_load<8>(P.wq, P1, A, g2, 0, r2a);      // query weights: in flight while prenet1 computes
+        gemv_acc<8>(y0, P0, g1, 8, r1b, acc);
+        gemv_store(g1, P1, acc, partial);
+    }
+    __syncthreads();
+    for (int c = tid; c < P1; c += FT) {
+        float v = fmaxf(reduce_partial(partial, g1.kparts, P1, c) + P.b1[c], 0.f);
+        if (P.drop_rate > 0.f) {
+            float keep;
+            if (P.mask1) keep = P.mask1[(size_t)b * P1 + c];
+            else {
+                Philox4 ph = gt_philox(seed, (uint32_t)(b * P1 + c), P.rng_step, 0u, 0x1001u);
+                keep = (gt_u01(ph.x) > P.drop_rate) ? 1.f : 0.f;
+            }
+            v = v * P.drop_scale * keep;
+        }
+        y1[c] = v;
+        P.xa[gt_blk_off(b, c, P.MT)] = v;           // LSTM-1 input (blocked), k in [0, P1)
+    }
+    __syncthreads();
+    GT_STAMP(P.dbg, 3);
+    // ---- query projection
+    {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        gemv_acc<8>(y1, P1, g2, 0, r2a, acc);
+        gemv_store(g2, A, acc, partial);
+    }
+    __syncthreads();
+    for (int c = tid; c < A; c += FT) qs[c] = reduce_partial(partial, g2.kparts, A, c) + P.bq[c];
+    __syncthreads();
+    GT_STAMP(P.dbg, 4);
+
+    // ---- scores: L lanes per memory row, NP float4 pieces per lane
+    const int nchunks = (Tv + ROWS - 1) / ROWS;
+    auto score_rows = [&](const float4 (&v)[NP], int c) {
+        const int t = c * ROWS + row;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int a0 = 4 * (li + L * j);
+            s += vs[a0 + 0] * gt_tanh(qs[a0 + 0] + v[j].x);
+            s += vs[a0 + 1] * gt_tanh(qs[a0 + 1] + v[j].y);
+            s += vs[a0 + 2] * gt_tanh(qs[a0 + 2] + v[j].z);
+            s += vs[a0 + 3] * gt_tanh(qs[a0 + 3] + v[j].w);
+        }
+#pragma unroll
+        for (int d = 1; d < L; d <<= 1) s += __shfl_xor(s, d, 64);
+        if (li == 0 && t < Tv) sc[t] = s + sbias;
+    };
+    auto load_rows = [&](float4 (&v)[NP], int c) {
+        const int t = c * ROWS + row;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < Tv) v[j] = *reinterpret_cast<const float4*>(pm + (size_t)t * A + 4 * (li + L * j));
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < FKEEP; ++c)
+        if (c < nchunks) score_rows(vreg[c], c);
+    for (int c = FKEEP; c < nchunks; ++c) {
+        float4 v[NP];
+        load_rows(v, c);
+        score_rows(v, c);
+    }
+    __syncthreads();
+    GT_STAMP(P.dbg, 5);
+    // ---- noise + sigmoid
+    for (int t = tid; t < Tv; t += FT) {
+        float s = sc[t];
+        if (P.sigmoid_noise > 0.f) {
+            float nz;
+            if (P.noise) nz = P.noise[(size_t)b * P.ldnoise + t];
+            else {
+                Philox4 r = gt_philox(seed, (uint32_t)(b * Tv + t), P.rng_step, 0u, GT_RNG_NOISE);
+                nz = gt_normal(r.x, r.y);
+            }
+            s += P.sigmoid_noise * nz;
+        }
+        sc[t] = gt_sigmoid(s);
+    }
+    __syncthreads();
+    // ---- alignment
+    if (P.type == GSTTACO_ATT_SMA) {
+        for (int t = tid; t < Tv; t += FT) {
+            float v = pv[t] * sc[t];
+            if (t > 0) v += pv[t - 1] * (1.f - sc[t - 1]);
+            al[t] = v;
+        }
+    } else if (wave == 0) {
+        const int per = (Tv + 63) / 64;
+        const int t0 = lane * per, t1 = min(Tv, t0 + per);
+        float run = 0.f;
+        for (int t = t0; t < t1; ++t) run += logf(fminf(fmaxf(1.f - sc[t], 1.17549435e-38f), 1.f));
+        float base = front_wave_incl_scan(run, lane) - run;
+        for (int t = t0; t < t1; ++t) {
+            const float lg = logf(fminf(fmaxf(1.f - sc[t], 1.17549435e-38f), 1.f));
+            al[t] = expf(base);
+            base += lg;
+        }
+        run = 0.f;
+        for (int t = t0; t < t1; ++t) run += pv[t] / fminf(fmaxf(al[t], 1e-10f), 1.f);
+        base = front_wave_incl_scan(run, lane) - run;
+        for (int t = t0; t < t1; ++t) {
+            base += pv[t] / fminf(fmaxf(al[t], 1e-10f), 1.f);
+            al[t] = sc[t] * al[t] * base;
+        }
+    }
+    __syncthreads();
+    GT_STAMP(P.dbg, 6);
+    for (int t = tid; t < Tv; t += FT) P.align[(size_t)b * P.ldalign + t] = al[t];
+
+    // ---- context: ctx[a] = sum_t al[t] * pm[t][a]
+    float4 cacc[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) cacc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ctx_rows = [&](const float4 (&v)[NP], int c) {
+        const int t = c * ROWS + row;
+        const float w = t < Tv ? al[t] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            cacc[j].x += w * v[j].x; cacc[j].y += w * v[j].y; cacc[j].z += w * v[j].z; cacc[j].w += w * v[j].w;
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < FKEEP; ++c)
+        if (c < nchunks) ctx_rows(vreg[c], c);
+    for (int c = FKEEP; c < nchunks; ++c) {
+        float4 v[NP];
+        load_rows(v, c);
+        ctx_rows(v, c);
+    }
+    // rows of one wave: lanes with equal li differ by multiples of L
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+#pragma unroll
+        for (int d = L; d < 64; d <<= 1) {
+            cacc[j].x += __shfl_xor(cacc[j].x, d, 64);
+            cacc[j].y += __shfl_xor(cacc[j].y, d, 64);
+            cacc[j].z += __shfl_xor(cacc[j].z, d, 64);
+            cacc[j].w += __shfl_xor(cacc[j].w, d, 64);
+        }
+        if (lane < L) *reinterpret_cast<float4*>(red + wave * A + 4 * (lane + L * j)) = cacc[j];
+    }
+    __syncthreads();
+    for (int a = tid; a < A; a += FT) {
+        float z = 0.f;
+#pragma unroll
+        for (int w = 0; w < FT / 64; ++w) z += red[w * A + a];
+        P.xa[gt_blk_off(b, P1 + a, P.MT)] = z;      // context, k in [P1, P1+A)
+    }
+    GT_STAMP(P.dbg, 7);
+}
+
+static size_t front_lds_bytes(const DecFrontArgs& a) {
+    int mx = a.mel > a.P0 ? a.mel : a.P0; if (a.P1 > mx) mx = a.P1;
+    size_t fl = ((mx + 3) & ~3) + a.P0 + a.P1 + 2 * (size_t)a.A + 2 * (size_t)a.Tv + ((a.Tv + 3) & ~3) + 16 * (size_t)a.A;
+    // partial: kparts*N floats for the largest phase (kparts*N <= FT*4)
+    fl += (size_t)FT * 4;
+    return fl * sizeof(float);
+}
+
+bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv) {
+    if (!(A == 16 || A == 32 || A == 64 || A == 128 || A == 256)) return false;
+    auto ok = [](int K, int N, int maxr) {
+        if (N % 4 || N / 4 > FT) return false;
+        int kparts = FT / (N / 4);
+        if (kparts > K) kparts = K;
+        return (K + kparts - 1) / kparts <= maxr;
+    };
+    // register blocks: prenet0 and query one 8-row block per lane, prenet1 two
+    if (!ok(mel, P0, 8) || !ok(P0, P1, FMAXR) || !ok(P1, A, 8)) return false;
+    DecFrontArgs t{};
+    t.mel = mel; t.P0 = P0; t.P1 = P1; t.A = A; t.Tv = Tv;
+    return front_lds_bytes(t) <= 150 * 1024;
+}
+
+template <int L, int NP>
+static hipError_t front_launch(const DecFrontArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((gt_dec_front_kernel<L, NP>), dim3(a.B), dim3(FT), front_lds_bytes(a), s, a);
+    return hipGetLastError();
+}
+
+hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t s) {
+    switch (a.A) {
+        case 16: return front_launch<4, 1>(a, s);
+        case 32: return front_launch<8, 1>(a, s);
+        case 64: return front_launch<8, 2>(a, s);
+        case 128: return front_launch<8, 4>(a, s);
+        case 256: return front_launch<8, 8>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t gt_dec_front_init() {
+    hipError_t e;
+#define FRONT_ATTR(L, NP)                                                                         \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP>),          \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
+    if (e != hipSuccess) return e;
+    FRONT_ATTR(4, 1) FRONT_ATTR(8, 1) FRONT_ATTR(8, 2) FRONT_ATTR(8, 4) FRONT_ATTR(8, 8)
+#undef FRONT_ATTR
+    return hipSuccess;
+}

@@ -53,3 +53,10 @@ __device__ __forceinline__ float gt_normal(uint32_t r0, uint32_t r1) {   // Box-
 // stream ids for the Philox counter's 4th word
 #define GT_RNG_PRENET0 0x1000u
 #define GT_RNG_NOISE   0x2000u
+
+// diagnostic: phase stamp (constant 100 MHz counter) written by thread 0 of block 0 when dbg != NULL
+#define GT_STAMP(dbg, slot)                                                                    \
+    do {                                                                                       \
+        if ((dbg) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
+            (dbg)[slot] = __builtin_amdgcn_s_memrealtime();                                    \
+    } while (0)

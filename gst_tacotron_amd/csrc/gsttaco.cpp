@@ -66,6 +66,7 @@ struct gsttaco_ctx {
     mutable std::string err;
     bool finalized = false;
     bool use_graph = true;
+    bool capturing = false;     // inside hipStreamBeginCapture..EndCapture (event records become external event nodes)
 
     // derived dims
     int r = 0, steps_max = 0, enc_out = 0, mem_dim = 0, proj_out = 0, conv_c = 0;
@@ -83,12 +84,17 @@ struct gsttaco_ctx {
     float *gru_w = nullptr, *gru_u = nullptr, *gru_b = nullptr, *dense_w = nullptr, *dense_b = nullptr;
     float *mq_w = nullptr, *mq_b = nullptr, *v_tok = nullptr, *ln_g = nullptr, *ln_b = nullptr;
     PackedLinear prenet0, prenet1, query, val_gst, lstm0, lstm1, proj;
+
+    float *pw0 = nullptr, *pb0 = nullptr, *pw1 = nullptr, *pb1 = nullptr, *pwq = nullptr, *pbq = nullptr;  // plain layouts (fused front)
+    bool fused_front = true;
     float *val_enc_w = nullptr, *val_bias = nullptr, *att_v = nullptr, *att_sb = nullptr;
 
     // workspace
     int32_t *w_tokens = nullptr, *w_mel_len = nullptr;
     float *w_mels_in = nullptr, *w_masks = nullptr, *w_noise = nullptr;
     uint64_t* w_seed = nullptr;
+    unsigned long long* w_dbg = nullptr;   // [3][16] diagnostic stamps: front, lstm1, lstm2 (GSTTACO_STAMPS=1)
+    bool stamps = false;
     float *w_act[2] = {nullptr, nullptr}, *w_enc = nullptr, *w_cenc = nullptr, *w_zero = nullptr;
     float *w_gconv[2] = {nullptr, nullptr}, *w_gst = nullptr, *w_rowbias = nullptr, *w_pm = nullptr;
     float *w_p1 = nullptr, *w_xa = nullptr, *w_q = nullptr, *w_h1[2] = {nullptr, nullptr},
@@ -309,6 +315,27 @@ int same_pad_before(int n_in, int k, int s, int* out_n) {
     return total / 2;      // TF: before = total // 2, after = rest
 }
 
+
+// Records `ev` on `s`.  While `s` is being captured the record is inserted as an explicit event-record
+// NODE that depends on everything captured so far (a plain hipEventRecord in capture only expresses a
+// cross-stream dependency and records nothing at replay).
+int record_event(gsttaco_ctx* c, hipEvent_t ev, hipStream_t s) {
+    if (!c->capturing) {
+        HIPCHECK(c, hipEventRecord(ev, s));
+        return 0;
+    }
+    hipStreamCaptureStatus st;
+    unsigned long long id = 0;
+    hipGraph_t graph = nullptr;
+    const hipGraphNode_t* deps = nullptr;
+    size_t ndeps = 0;
+    HIPCHECK(c, hipStreamGetCaptureInfo_v2(s, &st, &id, &graph, &deps, &ndeps));
+    hipGraphNode_t node;
+    HIPCHECK(c, hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev));
+    HIPCHECK(c, hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ enqueue
 int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
     const gsttaco_config& g = c->cfg;
@@ -328,7 +355,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
     }
     // BiLSTM: one launch per time step, both directions in grid.z; h is written straight into enc_out.
     const int H = g.enc_rnn, C = c->conv_c, EO = c->enc_out;
-    HIPCHECK(c, hipMemsetAsync(c->w_cenc, 0, (size_t)2 * B * H * sizeof(float), s));
+    HIPCHECK(c, gt_launch_zero(c->w_cenc, (size_t)2 * B * H, s));
     for (int t = 0; t < Tv; ++t) {
         SkinnyArgs a[2];
         for (int d = 0; d < 2; ++d) {
@@ -340,11 +367,11 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
             k.seg[0] = SkinnySeg{x + (size_t)tt * C, (int64_t)Tv * C, C / 16, 0};
             if (t == 0) k.seg[1] = SkinnySeg{c->w_zero, 0, H / 16, 0};
             else k.seg[1] = SkinnySeg{c->w_enc + (size_t)tp * EO + d * H, (int64_t)Tv * EO, H / 16, 0};
-            k.nkb = c->bilstm[d].nkb; k.M = B; k.N = H;
+            k.nkb = c->bilstm[d].nkb; k.M = B; k.N = H; k.MT = (B + 15) / 16;
             k.c = c->w_cenc + (size_t)d * B * H;
             k.h = c->w_enc + (size_t)tt * EO + d * H; k.ldh = (int64_t)Tv * EO;
         }
-        HIPCHECK(c, gt_launch_skinny(EPI_LSTM, a[0], &a[1], c->bilstm[0].ntiles, s));
+        HIPCHECK(c, gt_launch_skinny(EPI_LSTM, a[0], &a[1], c->bilstm[0].ntiles, s, TAG_ENC_BILSTM));
     }
     return 0;
 }
@@ -390,7 +417,7 @@ int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
         memset(&k, 0, sizeof(k));
         k.wp = c->val_gst.wp; k.bias = c->val_gst.bias;
         k.seg[0] = SkinnySeg{c->w_gst, g.gst_att, g.gst_att / 16, 0};
-        k.nkb = c->val_gst.nkb; k.M = B; k.N = g.att_size; k.n_split = g.att_size;
+        k.nkb = c->val_gst.nkb; k.M = B; k.N = g.att_size; k.n_split = g.att_size; k.MT = (B + 15) / 16;
         k.out = c->w_rowbias; k.ldo = g.att_size;
         HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->val_gst.ntiles, s));
         rowbias = c->w_rowbias;
@@ -409,25 +436,47 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     const gsttaco_config& g = c->cfg;
     const int mel = g.mel_dim, r = c->r, P0 = c->P0, P1 = c->P1, att = c->att, H1 = c->H1, H2 = c->H2;
     const int XA = P1 + att;
+    const int MT = (B + 15) / 16;
+    const size_t BLK = (size_t)MT * 256;        // floats per k-block of a blocked activation buffer
     const int64_t ld_pre = (int64_t)steps * r * mel;
-    HIPCHECK(c, hipMemsetAsync(c->w_h1[1], 0, (size_t)B * H1 * sizeof(float), s));
-    HIPCHECK(c, hipMemsetAsync(c->w_h2[1], 0, (size_t)B * H2 * sizeof(float), s));
-    HIPCHECK(c, hipMemsetAsync(c->w_c1, 0, (size_t)B * H1 * sizeof(float), s));
-    HIPCHECK(c, hipMemsetAsync(c->w_c2, 0, (size_t)B * H2 * sizeof(float), s));
+    HIPCHECK(c, gt_launch_zero(c->w_h1[1], (size_t)MT * 16 * H1, s));
+    HIPCHECK(c, gt_launch_zero(c->w_h2[1], (size_t)MT * 16 * H2, s));
+    HIPCHECK(c, gt_launch_zero(c->w_c1, (size_t)B * H1, s));
+    HIPCHECK(c, gt_launch_zero(c->w_c2, (size_t)B * H2, s));
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
     int nprof[2] = {0, 0};
     for (int t = 0; t < steps; ++t) {
         const int p = t & 1;
         SkinnyArgs k;
+        const float* frame_ptr = t == 0 ? c->w_zero : c->w_pre + ((size_t)(t - 1) * r + (r - 1)) * mel;
+        const int64_t frame_ld = t == 0 ? 0 : ld_pre;
+        const float* mask0 = has_mask ? c->w_masks + (size_t)t * mask_step : nullptr;
+        const float* mask1 = has_mask ? c->w_masks + (size_t)t * mask_step + (size_t)B * P0 : nullptr;
+        if (c->fused_front && gt_dec_front_supported(mel, P0, P1, att, Tv)) {
+            // 1-4 fused: prenet x2, query projection, score / alignment / context (dec_front.hip)
+            DecFrontArgs f{};
+            f.frame = frame_ptr; f.ldframe = frame_ld;
+            f.w0 = c->pw0; f.b0 = c->pb0; f.w1 = c->pw1; f.b1 = c->pb1; f.wq = c->pwq; f.bq = c->pbq;
+            f.mask0 = mask0; f.mask1 = mask1;
+            f.drop_rate = g.prenet_rate; f.drop_scale = drop_scale; f.seed_ptr = c->w_seed; f.rng_step = (uint32_t)t;
+            f.pm = c->w_pm; f.v = c->att_v; f.score_bias = c->att_sb;
+            f.prev = t == 0 ? nullptr : c->w_align + (size_t)(t - 1) * Tv; f.ldprev = (int64_t)steps * Tv;
+            f.noise = has_noise ? c->w_noise + (size_t)t * B * Tv : nullptr; f.ldnoise = Tv;
+            f.align = c->w_align + (size_t)t * Tv; f.ldalign = (int64_t)steps * Tv;
+            f.xa = c->w_xa; f.MT = MT;
+            f.B = B; f.Tv = Tv; f.mel = mel; f.P0 = P0; f.P1 = P1; f.A = att; f.type = g.att_type;
+            f.sigmoid_noise = g.sigmoid_noise;
+            f.dbg = (c->stamps && t == steps / 2) ? c->w_dbg : nullptr;
+            HIPCHECK(c, gt_launch_dec_front(f, s));
+        } else {
         // 1. prenet layer 0 on the last emitted frame (Taco2.py:186: decodings[:, -1]; zeros at t=0)
         memset(&k, 0, sizeof(k));
         k.wp = c->prenet0.wp; k.bias = c->prenet0.bias;
-        if (t == 0) k.seg[0] = SkinnySeg{c->w_zero, 0, mel / 16, 0};
-        else k.seg[0] = SkinnySeg{c->w_pre + ((size_t)(t - 1) * r + (r - 1)) * mel, ld_pre, mel / 16, 0};
-        k.nkb = c->prenet0.nkb; k.M = B; k.N = P0; k.n_split = P0;
+        k.seg[0] = SkinnySeg{frame_ptr, frame_ld, mel / 16, 0};
+        k.nkb = c->prenet0.nkb; k.M = B; k.N = P0; k.n_split = P0; k.MT = MT;
         k.out = c->w_p1; k.ldo = P0;
-        k.mask = has_mask ? c->w_masks + (size_t)t * mask_step : nullptr; k.ldm = P0;
+        k.mask = mask0; k.ldm = P0;
         k.drop_rate = g.prenet_rate; k.drop_scale = drop_scale;
         k.seed_ptr = c->w_seed; k.rng_step = (uint32_t)t; k.rng_stream = 0x1000u;
         HIPCHECK(c, gt_launch_skinny(EPI_RELU_DROP, k, nullptr, c->prenet0.ntiles, s));
@@ -435,17 +484,17 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         memset(&k, 0, sizeof(k));
         k.wp = c->prenet1.wp; k.bias = c->prenet1.bias;
         k.seg[0] = SkinnySeg{c->w_p1, P0, P0 / 16, 0};
-        k.nkb = c->prenet1.nkb; k.M = B; k.N = P1; k.n_split = P1;
-        k.out = c->w_xa; k.ldo = XA;
-        k.mask = has_mask ? c->w_masks + (size_t)t * mask_step + (size_t)B * P0 : nullptr; k.ldm = P1;
+        k.nkb = c->prenet1.nkb; k.M = B; k.N = P1; k.n_split = P1; k.MT = MT;
+        k.out = c->w_xa; k.out_blocked = 1;
+        k.mask = mask1; k.ldm = P1;
         k.drop_rate = g.prenet_rate; k.drop_scale = drop_scale;
         k.seed_ptr = c->w_seed; k.rng_step = (uint32_t)t; k.rng_stream = 0x1001u;
         HIPCHECK(c, gt_launch_skinny(EPI_RELU_DROP, k, nullptr, c->prenet1.ntiles, s));
         // 3. attention query projection (Steps.py:122)
         memset(&k, 0, sizeof(k));
         k.wp = c->query.wp; k.bias = c->query.bias;
-        k.seg[0] = SkinnySeg{c->w_xa, XA, P1 / 16, 0};
-        k.nkb = c->query.nkb; k.M = B; k.N = att; k.n_split = att;
+        k.seg[0] = SkinnySeg{c->w_xa, 0, P1 / 16, 1};
+        k.nkb = c->query.nkb; k.M = B; k.N = att; k.n_split = att; k.MT = MT;
         k.out = c->w_q; k.ldo = att;
         HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->query.ntiles, s));
         // 4. score / monotonic alignment / context -> xa[:, P1:P1+att]
@@ -454,26 +503,29 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         a.prev = t == 0 ? nullptr : c->w_align + (size_t)(t - 1) * Tv; a.ldprev = (int64_t)steps * Tv;
         a.noise = has_noise ? c->w_noise + (size_t)t * B * Tv : nullptr; a.ldnoise = Tv;
         a.align = c->w_align + (size_t)t * Tv; a.ldalign = (int64_t)steps * Tv;
-        a.ctx = c->w_xa + P1; a.ldctx = XA;
+        a.ctx = c->w_xa + (size_t)(P1 / 16) * BLK; a.ldctx = 0; a.ctx_mt = MT;
         a.B = B; a.Tv = Tv; a.A = att; a.type = g.att_type; a.sigmoid_noise = g.sigmoid_noise;
         a.seed_ptr = c->w_seed; a.rng_step = (uint32_t)t;
         HIPCHECK(c, gt_launch_attn_step(a, s));
+        }
         // 5/6. the two LSTM cells (StackedRNNCells, Taco2.py:111)
         const bool prof = c->prof_every > 0 && (t % c->prof_every) == 0;
         for (int layer = 0; layer < 2; ++layer) {
             memset(&k, 0, sizeof(k));
+            const int H = layer == 0 ? H1 : H2;
+            float** hb = layer == 0 ? c->w_h1 : c->w_h2;
             const PackedLinear& L = layer == 0 ? c->lstm0 : c->lstm1;
-            k.wp = L.wp; k.bias = L.bias;
+            k.wp = L.wp; k.bias = L.bias; k.nkb = L.nkb;
             if (layer == 0) {
-                k.seg[0] = SkinnySeg{c->w_xa, XA, XA / 16, 0};
-                k.seg[1] = SkinnySeg{c->w_h1[p ^ 1], H1, H1 / 16, 0};
-                k.N = H1; k.c = c->w_c1; k.h = c->w_h1[p]; k.ldh = H1;
+                k.seg[0] = SkinnySeg{c->w_xa, 0, XA / 16, 1};
+                k.seg[1] = SkinnySeg{c->w_h1[p ^ 1], 0, H1 / 16, 1};
             } else {
-                k.seg[0] = SkinnySeg{c->w_h1[p], H1, H1 / 16, 0};
-                k.seg[1] = SkinnySeg{c->w_h2[p ^ 1], H2, H2 / 16, 0};
-                k.N = H2; k.c = c->w_c2; k.h = c->w_h2[p]; k.ldh = H2;
+                k.seg[0] = SkinnySeg{c->w_h1[p], 0, H1 / 16, 1};
+                k.seg[1] = SkinnySeg{c->w_h2[p ^ 1], 0, H2 / 16, 1};
             }
-            k.nkb = L.nkb; k.M = B;
+            k.N = H; k.c = layer == 0 ? c->w_c1 : c->w_c2; k.h = hb[p]; k.out_blocked = 1;
+            k.M = B; k.MT = MT;
+            k.dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
             if (prof) {
                 const size_t need = (size_t)2 * (nprof[layer] + 1);
                 while (c->prof_ev[layer].size() < need) {
@@ -481,20 +533,20 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                     HIPCHECK(c, hipEventCreate(&e));
                     c->prof_ev[layer].push_back(e);
                 }
-                HIPCHECK(c, hipEventRecord(c->prof_ev[layer][2 * nprof[layer]], s));
+                { int rce = record_event(c, c->prof_ev[layer][2 * nprof[layer]], s); if (rce) return rce; }
             }
-            HIPCHECK(c, gt_launch_skinny(EPI_LSTM, k, nullptr, L.ntiles, s));
+            HIPCHECK(c, gt_launch_skinny(EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));
             if (prof) {
-                HIPCHECK(c, hipEventRecord(c->prof_ev[layer][2 * nprof[layer] + 1], s));
+                { int rce = record_event(c, c->prof_ev[layer][2 * nprof[layer] + 1], s); if (rce) return rce; }
                 nprof[layer]++;
             }
         }
         // 7. projection [h2, ctx] -> r mel frames + stop logit, written in place (Taco2.py:112-118,194-205)
         memset(&k, 0, sizeof(k));
         k.wp = c->proj.wp; k.bias = c->proj.bias;
-        k.seg[0] = SkinnySeg{c->w_h2[p], H2, H2 / 16, 0};
-        k.seg[1] = SkinnySeg{c->w_xa + P1, XA, att / 16, 0};
-        k.nkb = c->proj.nkb; k.M = B; k.N = c->proj_out; k.n_split = mel * r;
+        k.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
+        k.seg[1] = SkinnySeg{c->w_xa + (size_t)(P1 / 16) * BLK, 0, att / 16, 1};
+        k.nkb = c->proj.nkb; k.M = B; k.N = c->proj_out; k.n_split = mel * r; k.MT = MT;
         k.out = c->w_pre + (size_t)t * r * mel; k.ldo = ld_pre;
         k.out2 = c->w_stop + t; k.ldo2 = steps;
         HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->proj.ntiles, s));
@@ -547,7 +599,9 @@ int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key, F body) 
     if (it == c->graphs.end()) {
         hipGraph_t graph = nullptr;
         HIPCHECK(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed));
+        c->capturing = true;
         int rc = body(c->cap_stream);
+        c->capturing = false;
         hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
         if (rc) {
             if (graph) (void)hipGraphDestroy(graph);
@@ -623,6 +677,10 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->P0 = g.prenet[0]; c->P1 = g.prenet[1]; c->H1 = g.dec_rnn[0]; c->H2 = g.dec_rnn[1]; c->att = g.att_size;
     const char* eg = getenv("GSTTACO_GRAPH");
     c->use_graph = !(eg && eg[0] == '0');
+    const char* ef = getenv("GSTTACO_FUSED_FRONT");
+    c->fused_front = !(ef && ef[0] == '0');
+    const char* es = getenv("GSTTACO_STAMPS");
+    c->stamps = es && es[0] == '1';
     build_manifest(c);
     *out = c;
     return 0;
@@ -634,6 +692,7 @@ void gsttaco_destroy(gsttaco_ctx* c) {
     for (int l = 0; l < 2; ++l)
         for (auto e : c->prof_ev[l]) (void)hipEventDestroy(e);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -741,7 +800,13 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         const HostTensor &k1 = T(c, "decoder.prenet1.kernel"), &b1 = T(c, "decoder.prenet1.bias");
         if ((rc = pack_linear(c, &c->prenet0, {{k0.data.data(), (int)k0.shape[0]}}, c->P0, b0.data.data(), 0))) return rc;
         if ((rc = pack_linear(c, &c->prenet1, {{k1.data.data(), (int)k1.shape[0]}}, c->P1, b1.data.data(), 0))) return rc;
+        if ((rc = upload(c, &c->pw0, k0.data.data(), k0.data.size()))) return rc;
+        if ((rc = upload(c, &c->pb0, b0.data.data(), b0.data.size()))) return rc;
+        if ((rc = upload(c, &c->pw1, k1.data.data(), k1.data.size()))) return rc;
+        if ((rc = upload(c, &c->pb1, b1.data.data(), b1.data.size()))) return rc;
         const HostTensor &qk = T(c, "decoder.attention.query.kernel"), &qb = T(c, "decoder.attention.query.bias");
+        if ((rc = upload(c, &c->pwq, qk.data.data(), qk.data.size()))) return rc;
+        if ((rc = upload(c, &c->pbq, qb.data.data(), qb.data.size()))) return rc;
         if ((rc = pack_linear(c, &c->query, {{qk.data.data(), (int)qk.shape[0]}}, c->att, qb.data.data(), 0))) return rc;
         const HostTensor &vk = T(c, "decoder.attention.value.kernel"), &vb = T(c, "decoder.attention.value.bias");
         const int goff = g.gst_use ? g.gst_att : 0;     // memory channel order [gst | enc] (GST.py:121-124)
@@ -774,6 +839,8 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     if ((rc = dev_alloc(c, (void**)&c->w_tokens, B * Tv * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&c->w_mel_len, B * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&c->w_seed, 16))) return rc;
+    if ((rc = dev_alloc(c, (void**)&c->w_dbg, 3 * 16 * 8))) return rc;
+    HIPCHECK(c, hipMemset(c->w_dbg, 0, 3 * 16 * 8));
     if ((rc = fa(&c->w_masks, S * B * (c->P0 + c->P1)))) return rc;
     if ((rc = fa(&c->w_noise, S * B * Tv))) return rc;
     size_t actc = g.emb;
@@ -782,7 +849,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         if ((rc = fa(&c->w_act[i], B * Tv * actc))) return rc;
     if ((rc = fa(&c->w_enc, B * Tv * c->enc_out))) return rc;
     if ((rc = fa(&c->w_cenc, 2 * B * g.enc_rnn))) return rc;
-    c->zero_floats = B * std::max<size_t>({(size_t)mel, (size_t)g.enc_rnn, (size_t)c->H1, (size_t)c->H2});
+    c->zero_floats = ((B + 15) / 16 * 16) * std::max<size_t>({(size_t)mel, (size_t)g.enc_rnn, (size_t)c->H1, (size_t)c->H2});
     if ((rc = fa(&c->w_zero, c->zero_floats))) return rc;
     HIPCHECK(c, hipMemset(c->w_zero, 0, c->zero_floats * sizeof(float)));
     if (g.gst_use) {
@@ -802,11 +869,13 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     }
     if ((rc = fa(&c->w_pm, B * Tv * c->att))) return rc;
     if ((rc = fa(&c->w_p1, B * c->P0))) return rc;
-    if ((rc = fa(&c->w_xa, B * (c->P1 + c->att)))) return rc;
+    const size_t Bp = (B + 15) / 16 * 16;       // blocked activation buffers hold whole 16-row tiles
+    if ((rc = fa(&c->w_xa, Bp * (c->P1 + c->att)))) return rc;
+    HIPCHECK(c, hipMemset(c->w_xa, 0, Bp * (c->P1 + c->att) * sizeof(float)));
     if ((rc = fa(&c->w_q, B * c->att))) return rc;
     for (int i = 0; i < 2; ++i) {
-        if ((rc = fa(&c->w_h1[i], B * c->H1))) return rc;
-        if ((rc = fa(&c->w_h2[i], B * c->H2))) return rc;
+        if ((rc = fa(&c->w_h1[i], Bp * c->H1))) return rc;
+        if ((rc = fa(&c->w_h2[i], Bp * c->H2))) return rc;
     }
     if ((rc = fa(&c->w_c1, B * c->H1))) return rc;
     if ((rc = fa(&c->w_c2, B * c->H2))) return rc;
@@ -819,6 +888,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         if ((rc = fa(&c->w_post[i], B * Tf * postc))) return rc;
     if ((rc = fa(&c->w_mel, B * Tf * mel))) return rc;
     HIPCHECK(c, gt_attn_init());
+    HIPCHECK(c, gt_dec_front_init());
     HIPCHECK(c, hipDeviceSynchronize());
     // host copies are no longer needed
     for (auto& t : c->tensors) std::vector<float>().swap(t.data);
@@ -960,6 +1030,12 @@ int gsttaco_get_profile(gsttaco_ctx* c, int layer, float* avg_ms, int* count) {
     }
     *count = n;
     *avg_ms = n ? (float)(sum / n) : 0.f;
+    return 0;
+}
+
+int gsttaco_debug_stamps(gsttaco_ctx* c, unsigned long long* host_out48) {
+    if (!c || !host_out48 || !c->w_dbg) return GSTTACO_E_INVALID;
+    HIPCHECK(c, hipMemcpy(host_out48, c->w_dbg, 3 * 16 * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

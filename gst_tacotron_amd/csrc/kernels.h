@@ -6,12 +6,20 @@
 // ---------------------------------------------------------------- skinny_gemm.hip
 enum { EPI_LINEAR = 0, EPI_RELU_DROP = 1, EPI_LSTM = 2 };
 
+// Activation ("A operand") layouts of a [M, K] matrix:
+//   row-major : element (row, k) at ptr[row*ld + k]
+//   blocked   : MFMA-fragment order [k/16][row/16][lane = ((k%16)/4)*16 + row%16][k%4], i.e. one 1-KiB block per
+//               (16 k, 16 rows): a wave reads its A fragment of a k-block with ONE coalesced 16-byte-per-lane load
+//               instead of 16 rows x 64 B at a power-of-two row stride.  All decode-loop activations use it.
 struct SkinnySeg {
-    const float* ptr;   // [M, len] rows, 16-byte aligned
-    int64_t ld;         // row stride in floats (multiple of 4)
+    const float* ptr;   // row-major: [M, len] rows, 16-byte aligned; blocked: first k-block of the segment
+    int64_t ld;         // row-major: row stride in floats (multiple of 4); blocked: unused
     int nkb;            // len / 16
-    int pad_;
+    int blocked;        // 1 = blocked layout
 };
+__host__ __device__ inline size_t gt_blk_off(int row, int k, int MT) {
+    return (((size_t)(k >> 4) * MT + (row >> 4)) << 8) + (size_t)(((((k & 15) >> 2) << 4) + (row & 15)) * 4 + (k & 3));
+}
 
 struct SkinnyArgs {
     const float* wp;    // packed weights [ntiles][nkb][64 lanes][4]
@@ -21,6 +29,8 @@ struct SkinnyArgs {
     int M;              // batch rows
     int N;              // LINEAR: valid output columns; LSTM: hidden units H
     int n_split;        // LINEAR: columns >= n_split go to out2 (projection: mel | stop)
+    int MT;             // M-tiles (ceil(M/16)) of blocked operands / outputs
+    int out_blocked;    // LINEAR: `out` is a blocked activation buffer; LSTM: `h` is
     float* out; int64_t ldo;
     float* out2; int64_t ldo2;
     // EPI_RELU_DROP
@@ -30,9 +40,12 @@ struct SkinnyArgs {
     // EPI_LSTM
     float* c;           // [M, H] cell state, updated in place
     float* h; int64_t ldh;
+    unsigned long long* dbg;   // diagnostic phase stamps (s_memrealtime, 100 MHz) of block 0, or NULL
 };
 
-hipError_t gt_launch_skinny(int epi, const SkinnyArgs& a0, const SkinnyArgs* a1, int ntiles, hipStream_t stream);
+enum { TAG_GENERIC = 0, TAG_DEC_LSTM1 = 1, TAG_DEC_LSTM2 = 2, TAG_ENC_BILSTM = 3 };
+hipError_t gt_launch_skinny(int epi, const SkinnyArgs& a0, const SkinnyArgs* a1, int ntiles, hipStream_t stream,
+                            int tag = TAG_GENERIC);
 
 // ---------------------------------------------------------------- gemm_conv.hip
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
@@ -61,7 +74,8 @@ struct AttnStepArgs {
     const float* prev;  int64_t ldprev; // previous alignment rows [B, Tv] (NULL -> one-hot(0), Steps.py:201-206)
     const float* noise; int64_t ldnoise;// N(0,1) [B, Tv] or NULL -> Philox
     float* align; int64_t ldalign;      // out [B, Tv]
-    float* ctx; int64_t ldctx;          // out [B, A]
+    float* ctx; int64_t ldctx;          // out [B, A] (row-major) or blocked buffer when ctx_mt > 0
+    int ctx_mt;
     int B, Tv, A, type;                 // type: GSTTACO_ATT_*
     float sigmoid_noise;
     const uint64_t* seed_ptr; uint32_t rng_step;
@@ -71,7 +85,32 @@ struct AttnStepArgs {
 hipError_t gt_launch_attn_step(const AttnStepArgs& a, hipStream_t stream);
 hipError_t gt_attn_init();     // opt in to >64 KiB dynamic LDS; call once outside stream capture
 hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream);
+hipError_t gt_launch_zero(float* p, size_t n_floats, hipStream_t stream);   // n rounded up to a multiple of 4 floats
 size_t gt_attn_lds_bytes(int Tv, int A, int* rows_lds);
+
+// ---------------------------------------------------------------- dec_front.hip
+struct DecFrontArgs {
+    const float* frame; int64_t ldframe;    // [B, mel] last emitted frame (zero rows, ld 0, at step 0)
+    const float* w0; const float* b0;       // prenet0 [mel, P0] (TF layout), [P0]
+    const float* w1; const float* b1;       // prenet1 [P0, P1], [P1]
+    const float* wq; const float* bq;       // attention Query [P1, A], [A]
+    const float* mask0; const float* mask1; // keep-masks [B,P0] / [B,P1] or NULL -> Philox
+    float drop_rate, drop_scale;
+    const uint64_t* seed_ptr; uint32_t rng_step;
+    const float* pm;                        // [B, Tv, A] processed memory
+    const float* v; const float* score_bias;
+    const float* prev; int64_t ldprev;      // NULL -> one-hot(0)
+    const float* noise; int64_t ldnoise;    // NULL -> Philox
+    float* align; int64_t ldalign;
+    float* xa;                              // out, BLOCKED [ (P1+A)/16 ][MT][64][4]: prenet output k in [0,P1), context k in [P1,P1+A)
+    int MT;
+    int B, Tv, mel, P0, P1, A, type;
+    float sigmoid_noise;
+    unsigned long long* dbg;   // diagnostic phase stamps of block 0, or NULL
+};
+bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv);
+hipError_t gt_dec_front_init();
+hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- gst.hip
 struct Conv2dArgs {

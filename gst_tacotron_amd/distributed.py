@@ -1,0 +1,67 @@
+"""Utterance-sharded multi-GPU inference: one process per GPU, one gather at the end.
+
+The reference is single-device (no tf.distribute / NCCL anywhere); the path shards
+naturally because utterances are independent (BatchNorm is in inference mode, no cross-utterance
+op).  Each rank decodes a contiguous block of utterances with a full weight replica and the ONLY
+exchange is the final gather of the output tensors to rank 0 -- ``torch.distributed`` backend
+"nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_process_group(backend=None):
+    """Idempotent init from the torchrun environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE)."""
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_bounds(n_items, rank, world):
+    """Contiguous block [lo, hi) of ``n_items`` utterances owned by ``rank`` (sizes differ by <= 1)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_inputs(inputs, rank, world):
+    """Slice every per-utterance array of an inference pattern dict along axis 0."""
+    n = len(inputs["tokens"])
+    lo, hi = shard_bounds(n, rank, world)
+    return {k: (v[lo:hi] if v is not None else None) for k, v in inputs.items()}
+
+
+def gather_to_root(local, n_total=None, dst=0):
+    """Gather per-rank ``[B_local, ...]`` tensors to ``dst``; returns the concatenated tensor on ``dst``
+    and None elsewhere.  Ragged shards (batch not divisible by world size) are padded to the largest
+    shard for the collective and trimmed after it."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if n_total is None:
+        cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        dist.all_reduce(cnt)
+        n_total = int(cnt.item())
+    sizes = [shard_bounds(n_total, r, world) for r in range(world)]
+    bmax = max(hi - lo for lo, hi in sizes)
+    send = local
+    if local.shape[0] < bmax:
+        pad = torch.zeros((bmax - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send = torch.cat([local, pad], dim=0)
+    send = send.contiguous()
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)

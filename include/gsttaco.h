@@ -152,6 +152,9 @@ int gsttaco_set_profiling(gsttaco_ctx* ctx, int every);
 /* After the stream has been synchronised by the caller: average duration (ms) of the bracketed
  * launches of decode-LSTM layer `layer` (0/1) and how many were bracketed. */
 int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
+/* Diagnostic (GSTTACO_STAMPS=1): 3 x 16 phase stamps (100 MHz ticks) of workgroup 0 of the fused front kernel
+ * and the two decode LSTM kernels at the middle decode step of the last replay.  Synchronises the device. */
+int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
 /* Algorithmic bytes one launch of decode-LSTM layer `layer` moves at batch B (weights + activations). */
 int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* ctx, int layer, int B);
 

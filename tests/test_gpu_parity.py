@@ -48,3 +48,136 @@ def test_inference_step_matches_golden(name):
         assert np.isfinite(got).all()
         assert err <= TOL, (name, what, err)
         assert err <= BAR
+
+
+# ------------------------------------------------------------------ per-module parity against the oracle
+def _full_case(B, Tv, Tref, steps, seed, att="SMA", lens=None, rate=0.5):
+    from gst_tacotron_amd import synthetic, weights
+    hp = synthetic.config_hp("cfg2")
+    hp["Tacotron2"]["Decoder"]["Attention"]["Type"] = att
+    hp["Tacotron2"]["Decoder"]["Prenet"]["Dropout_Rate"] = rate
+    w = weights.synthetic_weights(hp, seed=0)
+    rng = np.random.default_rng(seed)
+    tokens, tl = synthetic.make_tokens(rng, B, Tv)
+    mels, ml = synthetic.make_ref_mels(rng, B, Tref, lengths=lens)
+    masks, noise = synthetic.make_randomness(rng, steps, B, Tv, [256, 256], rate=max(rate, 1e-9))
+    return hp, w, tokens, tl, mels, ml, masks, noise
+
+
+def test_encoder_gst_decode_postnet_modules_match_oracle():
+    import torch
+    from oracle import oracle_np
+    B, Tv, Tref, steps = 3, 21, 150, 6
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=21, lens=np.array([150, 64, 65]))
+    m = _model(hp, w, B, Tv, Tref + 1)
+    w64 = oracle_np.cast_weights(w, np.float64)
+    enc = m.encode(tokens)
+    gst = m.Inference_GST_Step(mels, ml)
+    torch.cuda.synchronize()
+    enc_ref = oracle_np.encoder(hp, w64, tokens, np.float64)
+    gst_ref = oracle_np.style_token_layer(hp, w64, mels, ml, np.float64)
+    assert np.abs(enc.cpu().numpy() - enc_ref).max() <= TOL
+    assert np.abs(gst.cpu().numpy() - gst_ref).max() <= TOL
+    # decode from the ORACLE's encoder/gst so each module is checked at its own scale
+    pre, stop, align = m.decode(enc_ref.astype(np.float32), gst_ref.astype(np.float32), masks, noise, steps=steps)
+    torch.cuda.synchronize()
+    mem = oracle_np.gst_concat(enc_ref, gst_ref)
+    pre_ref, stop_ref, align_ref = oracle_np.decoder(hp, w64, mem, np.float64, masks.astype(np.float64),
+                                                     noise.astype(np.float64), steps=steps)
+    assert np.abs(pre.cpu().numpy() - pre_ref).max() <= TOL
+    assert np.abs(stop.cpu().numpy() - stop_ref).max() <= TOL
+    assert np.abs(align.cpu().numpy() - align_ref).max() <= TOL
+    post = m.postnet(pre_ref.astype(np.float32))
+    torch.cuda.synchronize()
+    assert np.abs(post.cpu().numpy() - oracle_np.postnet(hp, w64, pre_ref, np.float64)).max() <= TOL
+
+
+@pytest.mark.parametrize("B,Tv,Tref,att", [(1, 32, 3, "SMA"), (17, 40, 70, "BMA"), (33, 24, 64, "SMA"),
+                                            (2, 200, 40, "BMA"), (2, 300, 40, "SMA")])
+def test_edge_shapes_match_oracle(B, Tv, Tref, att):
+    """Batch 1 / not a multiple of 16 / more than one 32-row chunk; token counts that need 2 and 3 passes of the
+    attention rows (beyond the rows kept in registers); a 3-frame reference mel (one compressed GRU step)."""
+    import torch
+    from oracle import oracle_np
+    steps = 5
+    lens = np.maximum(1, np.minimum(Tref, np.arange(B) * 7 + Tref // 2)).astype(np.int32)
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=B * 1000 + Tv, att=att, lens=lens)
+    m = _model(hp, w, B, Tv, Tref + 1)
+    mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps)
+    torch.cuda.synchronize()
+    ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
+    assert np.abs(mel.cpu().numpy() - ref[0]).max() <= TOL
+    assert np.abs(stop.cpu().numpy() - ref[1]).max() <= TOL
+    assert np.abs(align.cpu().numpy() - ref[3]).max() <= TOL
+
+
+def test_eager_graph_and_unfused_paths_agree(monkeypatch):
+    """The hipGraph replay, eager launches and the unfused (4-kernel) decoder front end are the same arithmetic."""
+    import torch
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(4, 33, 90, 8, seed=5)
+    outs = []
+    for env in ({}, {"GSTTACO_GRAPH": "0"}, {"GSTTACO_FUSED_FRONT": "0"}):
+        for k in ("GSTTACO_GRAPH", "GSTTACO_FUSED_FRONT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = _model(hp, w, 4, 33, 91)
+        mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=8)
+        torch.cuda.synchronize()
+        outs.append((mel.cpu().numpy(), align.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])   # graph == eager, bitwise
+    assert np.abs(outs[0][0] - outs[2][0]).max() <= TOL and np.abs(outs[0][1] - outs[2][1]).max() <= TOL
+
+
+def test_on_device_randomness_is_seeded():
+    """Throughput mode (no injected tensors): Philox dropout / SMA noise are a pure function of the seed."""
+    import torch
+    hp, w, tokens, tl, mels, ml, _, _ = _full_case(4, 20, 64, 10, seed=6)
+    m = _model(hp, w, 4, 20, 65)
+    a = m.Inference_Step(tokens, tl, None, mels, ml, seed=11, steps=10)[0].cpu().numpy()
+    b = m.Inference_Step(tokens, tl, None, mels, ml, seed=11, steps=10)[0].cpu().numpy()
+    c = m.Inference_Step(tokens, tl, None, mels, ml, seed=12, steps=10)[0].cpu().numpy()
+    assert np.isfinite(a).all() and np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_full_size_batch_independence_and_invariants():
+    """BASELINE configs[1] at full size (batch 32 x 128 tokens x 500 steps), too big for the oracle in seconds, through
+    size-independent properties: (1) utterances are independent -- utterance b decoded inside the batch of 32 equals the
+    same utterance decoded alone at batch 1 (different tiling / M-tile count); (2) SMA alignments are non-negative and
+    never gain mass; (3) the decoder always runs Max_Step // r iterations."""
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    hp, inputs = synthetic.config_inputs("cfg2", batch=32)
+    w = weights.synthetic_weights(hp, seed=0)
+    rng = np.random.default_rng(77)
+    masks, noise = synthetic.make_randomness(rng, 500, 32, 128, [256, 256])
+    m = _model(hp, w, 32, 128, 257)
+    mel, stop, _, align = m.Inference_Step(inputs["tokens"], None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"],
+                                           prenet_masks=masks, attn_noise=noise)
+    torch.cuda.synchronize()
+    mel, align = mel.cpu().numpy(), align.cpu().numpy()
+    assert mel.shape == (32, 1000, 80) and stop.shape == (32, 500) and align.shape == (32, 500, 128)
+    assert np.isfinite(mel).all()
+    assert align.min() >= 0.0
+    mass = align.sum(-1)
+    assert np.all(mass[:, 0] <= 1.0 + 1e-5) and np.all(np.diff(mass, axis=1) <= 1e-5)
+    for b in (0, 13, 31):
+        sl = slice(b, b + 1)
+        one = m.Inference_Step(inputs["tokens"][sl], None, None, inputs["mels_for_gst"][sl], inputs["mel_lengths_for_gst"][sl],
+                               prenet_masks=masks[:, :, sl], attn_noise=noise[:, sl])
+        torch.cuda.synchronize()
+        assert np.abs(one[0].cpu().numpy()[0] - mel[b]).max() <= TOL
+        assert np.abs(one[3].cpu().numpy()[0] - align[b]).max() <= TOL
+
+
+def test_error_behaviour_on_gpu():
+    from gst_tacotron_amd import capi
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(2, 16, 32, 2, seed=8)
+    m = _model(hp, w, 2, 16, 33)
+    with pytest.raises(capi.GstTacoError) as e:
+        m.Inference_Step(np.concatenate([tokens, tokens]), None, None, np.concatenate([mels, mels]), np.concatenate([ml, ml]), steps=2)
+    assert e.value.code == -5                                     # capacity given at create
+    with pytest.raises(ValueError, match="GST is enabled"):
+        m.Inference_Step(tokens, steps=2)
+    with pytest.raises(capi.GstTacoError):
+        m.Inference_Step(tokens, None, None, mels, ml, steps=10_000)

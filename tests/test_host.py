@@ -1,0 +1,188 @@
+"""CPU: host logic, the C-ABI surface (load + exported symbols + error behaviour, no compute calls), the Feeder
+conventions, and the world-size-2 utterance sharding / gather over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gst_tacotron_amd import capi, hparams, synthetic, weights
+from gst_tacotron_amd.feeder import Feeder
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gst_tacotron_amd import build
+    build.build()
+    return capi.load_library()
+
+
+def test_header_symbols_are_all_exported(lib):
+    header = open(os.path.join(ROOT, "include", "gsttaco.h")).read()
+    declared = set(re.findall(r"\b(gsttaco_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(capi.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert lib.gsttaco_abi_version() == capi.ABI_VERSION
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gst_tacotron_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "torch_ref" not in src and "oracle_np" not in src, f
+
+
+def test_c_manifest_matches_python_manifest(lib):
+    for hp in (hparams.load_hp(), synthetic.tiny_hp(gst=False), synthetic.config_hp("cfg2")):
+        ctx = capi.Context(hp, max_batch=2, max_tokens=8, max_ref_frames=9)
+        assert list(ctx.manifest().items()) == [(k, tuple(v)) for k, v in weights.manifest(hp).items()]
+        ctx.close()
+
+
+def test_create_rejects_bad_configs(lib):
+    hp = hparams.load_hp()
+    cfg = capi.make_config(hp)
+    h = ctypes.c_void_p()
+    cfg.abi_version = 99
+    assert lib.gsttaco_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg = capi.make_config(hp)
+    cfg.att_type = 7
+    assert lib.gsttaco_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"Unsupported attention type" in lib.gsttaco_last_error(None)       # reference Taco2.py:74-75
+    cfg = capi.make_config(hp)
+    cfg.heads = 3
+    assert lib.gsttaco_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"divisible by num_heads" in lib.gsttaco_last_error(None)           # reference Layers.py:155-156
+    cfg = capi.make_config(hp)
+    cfg.mel_dim = 81
+    assert lib.gsttaco_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    bad = hparams.load_hp()
+    bad["Tacotron2"]["Decoder"]["Attention"]["Type"] = "LSA"
+    with pytest.raises(ValueError, match="Unsupported attention type: LSA"):
+        hparams.Dims(bad)
+
+
+def test_weight_loading_errors_and_no_cpu_fallback(lib):
+    import torch
+    hp = synthetic.tiny_hp()
+    ctx = capi.Context(hp, max_batch=2, max_tokens=8, max_ref_frames=9)
+    w = weights.synthetic_weights(hp, 0)
+    f32p = ctypes.POINTER(ctypes.c_float)
+    a = w["decoder.attention.v"]
+    shape = (ctypes.c_int64 * 1)(a.shape[0])
+    assert lib.gsttaco_load_weight(ctx.handle, b"no.such.tensor", a.ctypes.data_as(f32p), shape, 1) == -4
+    bad = (ctypes.c_int64 * 1)(a.shape[0] + 1)
+    assert lib.gsttaco_load_weight(ctx.handle, b"decoder.attention.v", a.ctypes.data_as(f32p), bad, 1) == -4
+    # compute before finalize -> E_WEIGHTS; finalize with a weight missing -> E_WEIGHTS
+    assert lib.gsttaco_postnet(ctx.handle, None, 1, 1, None, None) == -4
+    assert lib.gsttaco_finalize_weights(ctx.handle) == -4
+    assert b"missing weight" in lib.gsttaco_last_error(ctx.handle)
+    ctx.load_weights(w)
+    if not torch.cuda.is_available():
+        # the product path must fail loudly without a GPU: there is no CPU fallback
+        assert lib.gsttaco_finalize_weights(ctx.handle) == -2
+        assert b"no CPU fallback" in lib.gsttaco_last_error(ctx.handle)
+        from gst_tacotron_amd.model import GST_Tacotron
+        m = GST_Tacotron(hyper_parameters=hp, max_batch=2, max_tokens=8, max_ref_frames=9)
+        with pytest.raises(capi.GstTacoError):
+            m.Restore(weights=w)
+        with pytest.raises(capi.GstTacoError):
+            m.Inference_Step(np.zeros((1, 4), np.int32))
+    ctx.close()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        capi.load_library(str(tmp_path / "libgsttaco.so"))
+
+
+def test_dims_of_the_reference_defaults():
+    d = hparams.Dims(hparams.load_hp())
+    assert (d.vocab, d.emb, d.enc_out, d.mem, d.proj_out, d.steps) == (34, 512, 512, 640, 81, 1000)
+    assert d.sigmoid_noise == 2.0 and d.att_type == "SMA" and d.post_tanh == 3 and d.gru_in == 256
+    d2 = hparams.Dims(synthetic.config_hp("cfg2"))
+    assert d2.proj_out == 161 and d2.steps == 500
+    n = sum(int(np.prod(s)) for s in weights.manifest(synthetic.config_hp("cfg2")).values())
+    assert 24.5e6 < n < 25.5e6            # ~24.9 M parameters
+
+
+def test_feeder_inference_pattern_conventions():
+    hp = hparams.load_hp()
+    f = Feeder(hp)
+    sents = ["Strike while the iron is hot. ", "birds, of a feather?"]
+    mel = np.full((7, 80), 0.5, np.float32)
+    pat = f.Get_Inference_Pattern(sents, [mel])
+    tok = pat["tokens"]
+    assert tok.dtype == np.int32 and tok.shape == (2, len("STRIKE WHILE THE IRON IS HOT.") + 2)
+    assert tok[0, 0] == 0 and tok[0, -1] == 1                       # <S> ... <E>
+    assert tok[0, 1] == f.token_Index_Dict["S"] and tok[0, 2] == f.token_Index_Dict["T"]
+    n1 = len("BIRDS, OF A FEATHER?") + 2
+    assert list(pat["token_lengths"]) == [tok.shape[1], n1]
+    assert np.all(tok[1, n1:] == 1)                                 # padded with <E> = 1 (Feeder.py:177-180)
+    assert pat["initial_mels"].shape == (2, 1, 80) and not pat["initial_mels"].any()
+    g = pat["mels_for_gst"]
+    assert g.shape == (2, 8, 80) and not g[:, 0].any() and np.all(g[:, 1:] == 0.5)   # zero frame prepended
+    assert list(pat["mel_lengths_for_gst"]) == [7, 7]
+    with pytest.raises(KeyError):
+        f.Get_Inference_Pattern(["naïve"], [mel])                   # out-of-vocabulary (Feeder.py:169)
+    assert f.Get_Inference_Pattern(sents, None) is None             # "GST is enabled, but no wav information."
+    assert f.Get_Inference_Pattern(sents, [mel, mel, mel]) is None
+    ragged = f.Get_Inference_GST_Pattern([np.ones((3, 80)), np.ones((5, 80))])
+    assert ragged["mels_for_gst"].shape == (2, 6, 80) and not ragged["mels_for_gst"][0, 4:].any()
+
+
+def test_shard_bounds_cover_everything():
+    from gst_tacotron_amd.distributed import shard_bounds
+    for n in (1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from gst_tacotron_amd import distributed as gd
+rank, local_rank, world = gd.init_process_group(backend="gloo")
+assert world == 2
+n_total = 5                                   # ragged: 3 + 2 utterances
+lo, hi = gd.shard_bounds(n_total, rank, world)
+full = torch.arange(n_total * 4 * 3, dtype=torch.float32).reshape(n_total, 4, 3)
+inputs = gd.shard_inputs({"tokens": full, "none": None}, rank, world)
+assert inputs["none"] is None and inputs["tokens"].shape[0] == hi - lo
+local = inputs["tokens"] * 2.0                # stands in for the per-rank Inference_Step output
+out = gd.gather_to_root(local, n_total=n_total)
+out2 = gd.gather_to_root(local)               # size discovered with an all_reduce
+if rank == 0:
+    assert torch.equal(out, full * 2.0) and torch.equal(out2, full * 2.0)
+    print("GLOO_OK")
+else:
+    assert out is None and out2 is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GLOO_OK" in outs[0]

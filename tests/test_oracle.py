@@ -1,0 +1,141 @@
+"""CPU: the oracle against the committed golden vectors, the two restatements against each other,
+and the known-answer / invariant properties derivable from the reference source."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_CASES, load_golden
+from gst_tacotron_amd import synthetic, weights
+from oracle import oracle_np, torch_ref
+
+F32_STORE = 2e-6     # goldens are stored as float32
+
+
+def _inputs(hp, g):
+    gst = bool(hp["GST"]["Use"])
+    return (g["tokens"], g["mels_for_gst"] if gst else None, g["mel_lengths_for_gst"] if gst else None,
+            g["prenet_masks"], g["attn_noise"])
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_numpy_oracle_reproduces_golden(name):
+    hp, w, g = load_golden(name)
+    tok, mels, ml, masks, noise = _inputs(hp, g)
+    out = oracle_np.inference_step(hp, w, tok, mels, ml, masks, noise, steps=int(g["steps"]), dt=np.float64)
+    np.testing.assert_allclose(out[0], g["mels"], atol=F32_STORE, rtol=0)
+    np.testing.assert_allclose(out[1], g["stops"], atol=F32_STORE, rtol=0)
+    np.testing.assert_allclose(out[3], g["alignments"], atol=F32_STORE, rtol=0)
+    np.testing.assert_allclose(out[4]["pre_mel"], g["pre_mel"], atol=F32_STORE, rtol=0)
+    np.testing.assert_allclose(out[4]["encoder"], g["encoder"], atol=F32_STORE, rtol=0)
+    if hp["GST"]["Use"]:
+        np.testing.assert_allclose(out[4]["gst"], g["gst"], atol=F32_STORE, rtol=0)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_torch_restatement_matches_golden_in_fp32(name):
+    """The independent torch-CPU restatement (the cpu_baseline "port") in float32: fp32 noise only."""
+    hp, w, g = load_golden(name)
+    tok, mels, ml, masks, noise = _inputs(hp, g)
+    out = torch_ref.TorchReference(hp, w, torch.float32).inference_step(tok, mels, ml, masks, noise, steps=int(g["steps"]))
+    assert np.abs(out[0].numpy() - g["mels"]).max() < 5e-5
+    assert np.abs(out[3].numpy() - g["alignments"]).max() < 5e-5
+    assert np.abs(out[1].numpy() - g["stops"]).max() < 5e-5
+
+
+def test_same_padding_is_asymmetric_like_tf():
+    # 80 -> 40 -> 20 -> 10 -> 5 -> 3 -> 2 with pads (0,1)x4 then (1,1)x2 for k3 s2
+    n, pads, outs = 80, [], []
+    for _ in range(6):
+        out, pb, pa = oracle_np.same_pad(n, 3, 2)
+        pads.append((pb, pa)); outs.append(out); n = out
+    assert outs == [40, 20, 10, 5, 3, 2]
+    assert pads == [(0, 1)] * 4 + [(1, 1)] * 2
+    assert oracle_np.same_pad(128, 5, 1) == (128, 2, 2)
+
+
+def test_sma_shift_and_mass_conservation():
+    rng = np.random.default_rng(0)
+    prev = rng.random((3, 9)); prev /= prev.sum(-1, keepdims=True)
+    big = np.full((3, 9), 60.0)
+    # p == 1: alignment is stationary; p == 0: shifts by exactly one (reference Steps.py:226-227)
+    np.testing.assert_allclose(oracle_np.monotonic_alignment("SMA", big, prev), prev, atol=1e-12)
+    shifted = oracle_np.monotonic_alignment("SMA", -big, prev)
+    np.testing.assert_allclose(shifted[:, 1:], prev[:, :-1], atol=1e-12)
+    np.testing.assert_allclose(shifted[:, 0], 0, atol=1e-12)
+    # mass conservation except what falls off the end
+    score = rng.normal(size=(3, 9))
+    p = oracle_np.sigmoid(score)
+    new = oracle_np.monotonic_alignment("SMA", score, prev)
+    np.testing.assert_allclose(new.sum(-1), prev.sum(-1) - prev[:, -1] * (1 - p[:, -1]), atol=1e-12)
+
+
+def test_bma_closed_form_from_one_hot():
+    rng = np.random.default_rng(1)
+    score = rng.normal(size=(2, 7))
+    prev = np.zeros((2, 7)); prev[:, 0] = 1.0
+    p = oracle_np.sigmoid(score)
+    expect = p * np.concatenate([np.ones((2, 1)), np.cumprod(1 - p, -1)[:, :-1]], -1)   # Steps.py:173-178
+    np.testing.assert_allclose(oracle_np.monotonic_alignment("BMA", score, prev), expect, atol=1e-12)
+
+
+def test_decoder_loop_count_initial_state_and_feedback():
+    hp = synthetic.tiny_hp("SMA", r=3, max_step=20)         # 20 // 3 = 6 iterations -> 18 frames (Taco2.py:213)
+    w = oracle_np.cast_weights(weights.synthetic_weights(hp, 1), np.float64)
+    rng = np.random.default_rng(2)
+    mem = rng.normal(size=(2, 5, 16 + 32))
+    masks, noise = synthetic.make_randomness(rng, 6, 2, 5, [32, 32])
+    pre, stops, aligns = oracle_np.decoder(hp, w, mem, np.float64, masks.astype(np.float64), noise.astype(np.float64))
+    assert pre.shape == (2, 18, 16) and stops.shape == (2, 6) and aligns.shape == (2, 6, 5)
+    # first alignment comes from one-hot(0): only positions 0 and 1 can carry mass after one SMA step
+    assert np.all(aligns[:, 0, 2:] == 0)
+
+
+def test_prenet_dropout_is_live_and_scales_by_two():
+    hp = synthetic.tiny_hp()
+    w = oracle_np.cast_weights(weights.synthetic_weights(hp, 3), np.float64)
+    x = np.random.default_rng(3).normal(size=(2, 16))
+    ones = [np.ones((2, 32)), np.ones((2, 32))]
+    zero_second = [np.ones((2, 32)), np.zeros((2, 32))]
+    y = oracle_np.prenet(hp, w, x, ones)
+    h = np.maximum(x @ w["decoder.prenet0.kernel"] + w["decoder.prenet0.bias"], 0) * 2
+    np.testing.assert_allclose(y, np.maximum(h @ w["decoder.prenet1.kernel"] + w["decoder.prenet1.bias"], 0) * 2, atol=1e-12)
+    assert np.all(oracle_np.prenet(hp, w, x, zero_second) == 0)
+
+
+def test_postnet_tanh_only_on_first_three_layers():
+    hp = synthetic.tiny_hp()
+    w = oracle_np.cast_weights(weights.synthetic_weights(hp, 4), np.float64)
+    x = np.random.default_rng(4).normal(size=(1, 11, 16))
+    y = x
+    for i in range(5):
+        y = oracle_np.batch_norm(oracle_np.conv1d_same(y, w[f"postnet.conv{i}.kernel"]), w, f"postnet.conv{i}.bn")
+        if i < 3:
+            y = np.tanh(y)
+    np.testing.assert_allclose(oracle_np.postnet(hp, w, x, np.float64), y + x, atol=1e-12)
+
+
+def test_gst_gather_index_and_padding_invariance():
+    hp = synthetic.tiny_hp()
+    w = weights.synthetic_weights(hp, 5)
+    rng = np.random.default_rng(5)
+    mels, _ = synthetic.make_ref_mels(rng, 2, 130, mel=16)
+    # frames beyond ceil(len/64)*64 can only reach the gathered GRU step through conv bleed of the
+    # last compressed frame; frames >= 192 are outside the receptive field of step index 1 (len 65..128)
+    lens = np.array([100, 100], np.int32)
+    a = oracle_np.style_token_layer(hp, oracle_np.cast_weights(w, np.float64), mels, lens, np.float64)
+    idx = np.ceil(lens / 64).astype(int) - 1
+    assert list(idx) == [1, 1]
+    assert a.shape == (2, 16) and np.isfinite(a).all()
+
+
+def test_fp32_noise_floor_is_far_below_the_bar():
+    """1e-3 is a meaningful bar only if fp32 rounding through the recurrence stays well below it."""
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, 0)
+    rng = np.random.default_rng(9)
+    tok, _ = synthetic.make_tokens(rng, 1, 16)
+    mels, ml = synthetic.make_ref_mels(rng, 1, 64)
+    masks, noise = synthetic.make_randomness(rng, 30, 1, 16, [256, 256])
+    a = oracle_np.inference_step(hp, w, tok, mels, ml, masks, noise, steps=30, dt=np.float64)
+    b = oracle_np.inference_step(hp, w, tok, mels, ml, masks, noise, steps=30, dt=np.float32)
+    assert np.abs(a[0] - b[0]).max() < 2e-5

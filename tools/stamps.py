@@ -1,0 +1,22 @@
+"""Diagnostic: phase stamps of the decode kernels at the middle decode step (GSTTACO_STAMPS=1)."""
+import ctypes, os, sys
+os.environ["GSTTACO_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gst_tacotron_amd import synthetic, weights
+from gst_tacotron_amd.model import GST_Tacotron
+hp, inputs = synthetic.config_inputs("cfg2", batch=32)
+w = weights.synthetic_weights(hp, seed=0)
+m = GST_Tacotron(hyper_parameters=hp, max_batch=32, max_tokens=128, max_ref_frames=257)
+m.Restore(weights=w)
+for i in range(3):
+    m.Inference_Step(inputs["tokens"], None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"], seed=i)
+torch.cuda.synchronize()
+buf = (ctypes.c_uint64 * 48)()
+m.ctx.check(m.ctx.lib.gsttaco_debug_stamps(m.ctx.handle, buf))
+names = {0: "front", 1: "lstm1", 2: "lstm2"}
+for k in range(3):
+    st = [buf[k * 16 + i] for i in range(8)]
+    st = [x for x in st if x]
+    print(names[k], "phase deltas (us):", [round((b - a) / 100.0, 2) for a, b in zip(st[:-1], st[1:])], "total", round((st[-1] - st[0]) / 100.0, 2))
+print("front -> lstm1 start gap (us):", (buf[16] - buf[7]) / 100.0, " lstm1 end -> lstm2 start:", (buf[32] - buf[19]) / 100.0)
