@@ -23,7 +23,6 @@
 
 #define FT 1024            // threads per workgroup
 #define FMAXR 16           // max weight rows (float4 loads) per lane per GEMV phase (two register blocks of 8)
-#define FKEEP 1            // row chunks of the processed memory kept in registers
 
 struct GemvPlan {
     int ncg, kparts, rows, cg, kp;
@@ -69,9 +68,18 @@ __device__ __forceinline__ void gemv_store(const GemvPlan& p, int N, const float
     if (p.kp < p.kparts) *reinterpret_cast<float4*>(partial + (size_t)p.kp * N + p.cg * 4) = acc;
 }
 
+// sum of the k-part partials of one column; 8 independent LDS reads in flight per round (a plain
+// `z += partial[...]` loop serialises ~100-cycle LDS round trips: 32 of them cost >1 us per phase)
 __device__ __forceinline__ float reduce_partial(const float* partial, int kparts, int N, int col) {
     float z = 0.f;
-    for (int p = 0; p < kparts; ++p) z += partial[(size_t)p * N + col];
+    int p = 0;
+    for (; p + 8 <= kparts; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(p + j) * N + col];
+        z += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; p < kparts; ++p) z += partial[(size_t)p * N + col];
     return z;
 }
 
@@ -87,13 +95,15 @@ __device__ __forceinline__ float front_wave_incl_scan(float x, int lane) {
 template <int L, int NP>
 __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     constexpr int A = 4 * L * NP;
-    constexpr int ROWS = FT / L;            // memory rows per pass
+    constexpr int ROWS = FT / L;            // memory rows per pass (one LDS tile)
+    constexpr int LD = A + 4;               // padded tile row: conflict-free 16-byte row writes and 4-byte column reads
+    constexpr int CPARTS = FT / A;          // row groups of the context pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.x;
     const int mel = P.mel, P0 = P.P0, P1 = P.P1, Tv = P.Tv;
 
-    // LDS carve (floats): xs[max(mel,P0,P1)] | y0[P0] | y1[P1] | q[A] | vv[A] | sc[Tv] | pv[Tv] | al[Tv] | red[16*A] | partial[...]
+    // LDS carve (floats): xs | y0 | y1 | q | v | score | prev | align | red[FT] | partial[4 FT] | tile[ROWS][LD]
     int mx = mel > P0 ? mel : P0; if (P1 > mx) mx = P1;
     float* xs = smem;
     float* y0 = xs + ((mx + 3) & ~3);
@@ -101,38 +111,54 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     float* qs = y1 + P1;
     float* vs = qs + A;
     float* sc = vs + A;
-    float* pv = sc + Tv;
-    float* al = pv + Tv;
+    float* pv = sc + ((Tv + 3) & ~3);
+    float* al = pv + ((Tv + 3) & ~3);
     float* red = al + ((Tv + 3) & ~3);
-    float* partial = red + 16 * A;
+    float* partial = red + FT;
+    float* tile = partial + 4 * FT;
 
     // ---- issue every independent global load first
+    const int row = tid / L, li = tid % L;
+    const float* pm = P.pm + (size_t)b * Tv * A;
+    auto load_rows = [&](float4 (&v)[NP], int c) {
+        const int t = c * ROWS + row;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < Tv) v[j] = *reinterpret_cast<const float4*>(pm + (size_t)t * A + 4 * (li + L * j));
+        }
+    };
+    auto store_rows = [&](const float4 (&v)[NP]) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) *reinterpret_cast<float4*>(tile + row * LD + 4 * (li + L * j)) = v[j];
+    };
+    // small operands first: loads return in issue order, so their LDS writes below wait only for themselves
+    float in_x = 0.f, in_v = 0.f, in_p = 0.f;
+    if (tid < mel) in_x = P.frame[(size_t)b * P.ldframe + tid];                    // mel <= FT (checked on the host)
+    if (tid < A) in_v = P.v[tid];
+    if (tid < Tv) in_p = P.prev ? P.prev[(size_t)b * P.ldprev + tid] : (tid == 0 ? 1.f : 0.f);
+    float4 v0[NP];
+    load_rows(v0, 0);                                   // processed-memory rows of chunk 0 (64 KiB at 128x128)
+
     const GemvPlan g0 = make_plan(mel, P0, tid);
     const GemvPlan g1 = make_plan(P0, P1, tid);
     const GemvPlan g2 = make_plan(P1, A, tid);
-    // register budget (128 VGPRs at 16 waves/CU): at most two 8-row weight blocks + the memory rows live at once
+    // register budget (128 VGPRs at 16 waves/CU): three 8-row weight blocks + the memory rows in flight at t=0
     float4 r0a[8], r1a[8];
     gemv_load<8>(P.w0, mel, P0, g0, 0, r0a);
     gemv_load<8>(P.w1, P0, P1, g1, 0, r1a);
 
-    const int row = tid / L, li = tid % L;
-    const float* pm = P.pm + (size_t)b * Tv * A;
-    float4 vreg[FKEEP][NP];
-#pragma unroll
-    for (int c = 0; c < FKEEP; ++c) {
-        const int t = c * ROWS + row;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            vreg[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < Tv) vreg[c][j] = *reinterpret_cast<const float4*>(pm + (size_t)t * A + 4 * (li + L * j));
-        }
-    }
-    for (int i = tid; i < mel; i += FT) xs[i] = P.frame[(size_t)b * P.ldframe + i];
-    for (int a = tid; a < A; a += FT) vs[a] = P.v[a];
-    for (int t = tid; t < Tv; t += FT) pv[t] = P.prev ? P.prev[(size_t)b * P.ldprev + t] : (t == 0 ? 1.f : 0.f);
+    if (tid < mel) xs[tid] = in_x;
+    if (tid < A) vs[tid] = in_v;
+    if (tid < Tv) pv[tid] = in_p;
+    for (int t = tid + FT; t < Tv; t += FT) pv[t] = P.prev ? P.prev[(size_t)b * P.ldprev + t] : 0.f;
     GT_STAMP(P.dbg, 0);
     const float sbias = P.score_bias[0];
     const uint64_t seed = *P.seed_ptr;
+    store_rows(v0);                                     // the rows were requested first, so they are back first
+    asm volatile("" ::: "memory");                        // keep the next request BEHIND the tile write (register budget)
+    float4 r1b[8];
+    gemv_load<8>(P.w1, P0, P1, g1, 8, r1b);             // second half of prenet1 takes the registers the rows freed
     __syncthreads();
     GT_STAMP(P.dbg, 1);
 
@@ -142,8 +168,9 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         gemv_acc<8>(xs, mel, g0, 0, r0a, acc);
         gemv_store(g0, P0, acc, partial);
     }
-    float4 r1b[8];
-    gemv_load<8>(P.w1, P0, P1, g1, 8, r1b);         // second half of prenet1, in flight while prenet0 finishes
+    asm volatile("" ::: "memory");                        // r0a is dead from here: its registers take the query weights
+    float4 r2a[8];
+    gemv_load<8>(P.wq, P1, A, g2, 0, r2a);              // query weights: in flight while prenet0/1 compute
     __syncthreads();
     for (int c = tid; c < P0; c += FT) {
         float v = fmaxf(reduce_partial(partial, g0.kparts, P0, c) + P.b0[c], 0.f);
@@ -161,11 +188,9 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     __syncthreads();
     GT_STAMP(P.dbg, 2);
     // ---- prenet layer 1
-    float4 r2a[8];
     {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         gemv_acc<8>(y0, P0, g1, 0, r1a, acc);
-        gemv_load<8>(P.wq, P1, A, g2, 0, r2a);      // query weights: in flight while prenet1 computes
         gemv_acc<8>(y0, P0, g1, 8, r1b, acc);
         gemv_store(g1, P1, acc, partial);
     }
@@ -197,38 +222,32 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     __syncthreads();
     GT_STAMP(P.dbg, 4);
 
-    // ---- scores: L lanes per memory row, NP float4 pieces per lane
+    // ---- scores: L lanes per memory row read their NP 16-byte pieces of the LDS tile
     const int nchunks = (Tv + ROWS - 1) / ROWS;
-    auto score_rows = [&](const float4 (&v)[NP], int c) {
+    for (int c = 0; c < nchunks; ++c) {
+        if (c > 0) {                                   // Tv > ROWS: stream further chunks through the one tile
+            float4 v[NP];
+            load_rows(v, c);
+            __syncthreads();
+            store_rows(v);
+            __syncthreads();
+        }
         const int t = c * ROWS + row;
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int a0 = 4 * (li + L * j);
-            s += vs[a0 + 0] * gt_tanh(qs[a0 + 0] + v[j].x);
-            s += vs[a0 + 1] * gt_tanh(qs[a0 + 1] + v[j].y);
-            s += vs[a0 + 2] * gt_tanh(qs[a0 + 2] + v[j].z);
-            s += vs[a0 + 3] * gt_tanh(qs[a0 + 3] + v[j].w);
+            const float4 m4 = *reinterpret_cast<const float4*>(tile + row * LD + a0);
+            const float4 q4 = *reinterpret_cast<const float4*>(qs + a0);
+            const float4 w4 = *reinterpret_cast<const float4*>(vs + a0);
+            s += w4.x * gt_tanh(q4.x + m4.x);
+            s += w4.y * gt_tanh(q4.y + m4.y);
+            s += w4.z * gt_tanh(q4.z + m4.z);
+            s += w4.w * gt_tanh(q4.w + m4.w);
         }
 #pragma unroll
         for (int d = 1; d < L; d <<= 1) s += __shfl_xor(s, d, 64);
         if (li == 0 && t < Tv) sc[t] = s + sbias;
-    };
-    auto load_rows = [&](float4 (&v)[NP], int c) {
-        const int t = c * ROWS + row;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < Tv) v[j] = *reinterpret_cast<const float4*>(pm + (size_t)t * A + 4 * (li + L * j));
-        }
-    };
-#pragma unroll
-    for (int c = 0; c < FKEEP; ++c)
-        if (c < nchunks) score_rows(vreg[c], c);
-    for (int c = FKEEP; c < nchunks; ++c) {
-        float4 v[NP];
-        load_rows(v, c);
-        score_rows(v, c);
     }
     __syncthreads();
     GT_STAMP(P.dbg, 5);
@@ -254,7 +273,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
             if (t > 0) v += pv[t - 1] * (1.f - sc[t - 1]);
             al[t] = v;
         }
-    } else if (wave == 0) {
+    } else if (tid < 64) {
         const int per = (Tv + 63) / 64;
         const int t0 = lane * per, t1 = min(Tv, t0 + per);
         float run = 0.f;
@@ -277,43 +296,38 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     GT_STAMP(P.dbg, 6);
     for (int t = tid; t < Tv; t += FT) P.align[(size_t)b * P.ldalign + t] = al[t];
 
-    // ---- context: ctx[a] = sum_t al[t] * pm[t][a]
-    float4 cacc[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) cacc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ctx_rows = [&](const float4 (&v)[NP], int c) {
-        const int t = c * ROWS + row;
-        const float w = t < Tv ? al[t] : 0.f;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            cacc[j].x += w * v[j].x; cacc[j].y += w * v[j].y; cacc[j].z += w * v[j].z; cacc[j].w += w * v[j].w;
+    // ---- context: ctx[a] = sum_t al[t] * pm[t][a]; lane = channel a (conflict-free column reads of the tile),
+    //      CPARTS row groups reduced through LDS
+    const int ca = tid % A, cp = tid / A;
+    float cacc = 0.f;
+    for (int c = nchunks - 1; c >= 0; --c) {           // the tile still holds the LAST chunk of the score pass
+        if (c != nchunks - 1) {
+            float4 v[NP];
+            load_rows(v, c);
+            __syncthreads();
+            store_rows(v);
+            __syncthreads();
         }
-    };
-#pragma unroll
-    for (int c = 0; c < FKEEP; ++c)
-        if (c < nchunks) ctx_rows(vreg[c], c);
-    for (int c = FKEEP; c < nchunks; ++c) {
-        float4 v[NP];
-        load_rows(v, c);
-        ctx_rows(v, c);
-    }
-    // rows of one wave: lanes with equal li differ by multiples of L
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-#pragma unroll
-        for (int d = L; d < 64; d <<= 1) {
-            cacc[j].x += __shfl_xor(cacc[j].x, d, 64);
-            cacc[j].y += __shfl_xor(cacc[j].y, d, 64);
-            cacc[j].z += __shfl_xor(cacc[j].z, d, 64);
-            cacc[j].w += __shfl_xor(cacc[j].w, d, 64);
+        const int nr = min(ROWS, Tv - c * ROWS);
+        const float* alc = al + c * ROWS;
+        float p0 = 0.f, p1 = 0.f;
+        int t = cp;
+        for (; t + CPARTS < nr; t += 2 * CPARTS) {
+            p0 += alc[t] * tile[t * LD + ca];
+            p1 += alc[t + CPARTS] * tile[(t + CPARTS) * LD + ca];
         }
-        if (lane < L) *reinterpret_cast<float4*>(red + wave * A + 4 * (lane + L * j)) = cacc[j];
+        if (t < nr) p0 += alc[t] * tile[t * LD + ca];
+        cacc += p0 + p1;
     }
+    red[cp * A + ca] = cacc;
     __syncthreads();
     for (int a = tid; a < A; a += FT) {
+        float v[CPARTS];
+#pragma unroll
+        for (int w = 0; w < CPARTS; ++w) v[w] = red[w * A + a];
         float z = 0.f;
 #pragma unroll
-        for (int w = 0; w < FT / 64; ++w) z += red[w * A + a];
+        for (int w = 0; w < CPARTS; ++w) z += v[w];
         P.xa[gt_blk_off(b, P1 + a, P.MT)] = z;      // context, k in [P1, P1+A)
     }
     GT_STAMP(P.dbg, 7);
@@ -321,14 +335,15 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
 
 static size_t front_lds_bytes(const DecFrontArgs& a) {
     int mx = a.mel > a.P0 ? a.mel : a.P0; if (a.P1 > mx) mx = a.P1;
-    size_t fl = ((mx + 3) & ~3) + a.P0 + a.P1 + 2 * (size_t)a.A + 2 * (size_t)a.Tv + ((a.Tv + 3) & ~3) + 16 * (size_t)a.A;
-    // partial: kparts*N floats for the largest phase (kparts*N <= FT*4)
-    fl += (size_t)FT * 4;
+    const size_t tv4 = (a.Tv + 3) & ~3;
+    const int L = a.A == 16 ? 4 : 8;
+    size_t fl = ((mx + 3) & ~3) + a.P0 + a.P1 + 2 * (size_t)a.A + 3 * tv4 + FT + 4 * (size_t)FT;
+    fl += (size_t)(FT / L) * (a.A + 4);             // processed-memory tile
     return fl * sizeof(float);
 }
 
 bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv) {
-    if (!(A == 16 || A == 32 || A == 64 || A == 128 || A == 256)) return false;
+    if (!(A == 16 || A == 32 || A == 64 || A == 128 || A == 256) || mel > FT) return false;
     auto ok = [](int K, int N, int maxr) {
         if (N % 4 || N / 4 > FT) return false;
         int kparts = FT / (N / 4);

@@ -19,4 +19,7 @@ for k in range(3):
     st = [buf[k * 16 + i] for i in range(8)]
     st = [x for x in st if x]
     print(names[k], "phase deltas (us):", [round((b - a) / 100.0, 2) for a, b in zip(st[:-1], st[1:])], "total", round((st[-1] - st[0]) / 100.0, 2))
+f = [buf[i] for i in range(16)]
+t0 = f[0]
+print("front raw (us since stamp0):", {i: round((f[i]-t0)/100.0, 2) for i in range(16) if f[i]})
 print("front -> lstm1 start gap (us):", (buf[16] - buf[7]) / 100.0, " lstm1 end -> lstm2 start:", (buf[32] - buf[19]) / 100.0)
