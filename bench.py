@@ -73,6 +73,23 @@ def cpu_baseline(hp, w, inputs, budget_s=15.0):
                                                                       dt, nt, ncpu)}
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 +
+    WRITE_SIZE, separate passes: tools/profile.sh); None when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")))
+    if not files:
+        return None, None
+    try:
+        data = json.load(open(files[-1]))
+        for name, v in data.items():
+            if kernel_substr in name:
+                return v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"], os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +160,7 @@ def main():
         frames = n_total * model.dims.max_step * args.steps
         ms1, cnt1, bytes1 = prof[1]
         achieved = (bytes1 / (ms1 * 1e-3)) / 1e9 if ms1 > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("gt_skinny_kernel<2, 8, 2>")
         line = {
             "metric": "mel-frames/s", "value": frames / elapsed, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -155,7 +173,7 @@ def main():
                        "parallelism": "utterance-sharded x{} + final RCCL gather".format(world)},
             "roofline": {"bound": "hbm", "kernel": "gt_skinny_kernel<EPI_LSTM> decode LSTM layer 2 (33.6 MB fp32 weights/launch)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": bytes1, "avg_launch_us": ms1 * 1e3, "launches_timed": cnt1,
+                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes1, "avg_launch_us": ms1 * 1e3, "launches_timed": cnt1,
                          "layer1_avg_launch_us": prof[0][0] * 1e3, "layer1_bytes_per_launch": prof[0][2]},
         }
         if world == 1 and not args.no_cpu_baseline:
