@@ -17,8 +17,7 @@
 // each holding NP float4 pieces of the row in REGISTERS for both the score and the context pass (the
 // processed memory is read from L2 exactly once per step); row reduction by DPP/shuffle, context
 // reduction by shuffle across the wave's rows and LDS across waves.
-#include "device_utils.h"
-#include "kernels.h"
+#include "skinny_body.h"
 #include "../../include/gsttaco.h"
 
 #define FT 1024            // threads per workgroup
@@ -99,6 +98,21 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     constexpr int LD = A + 4;               // padded tile row: conflict-free 16-byte row writes and 4-byte column reads
     constexpr int CPARTS = FT / A;          // row groups of the context pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x >= P.B) {
+        // ---- worker workgroup: recurrent half of an LSTM gate GEMM (see DecFrontArgs::rec)
+        const int n0 = P.rec_end[0] - P.rec_begin[0];
+        const int total = n0 + (P.rec_end[1] - P.rec_begin[1]);
+        const int mchunks = (P.B + 31) / 32;
+        for (int job = (int)blockIdx.x - P.B; job < total; job += P.n_workers) {
+            const int layer = job < n0 ? 0 : 1;
+            const int tile = layer == 0 ? P.rec_begin[0] + job : P.rec_begin[1] + (job - n0);
+            for (int mc = 0; mc < mchunks; ++mc) {
+                gt_skinny_body<EPI_PARTIAL, FT / 64, true>(P.rec[layer], tile, mc, smem);
+                __syncthreads();
+            }
+        }
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.x;
     const int mel = P.mel, P0 = P.P0, P1 = P.P1, Tv = P.Tv;
@@ -339,6 +353,8 @@ static size_t front_lds_bytes(const DecFrontArgs& a) {
     const int L = a.A == 16 ? 4 : 8;
     size_t fl = ((mx + 3) & ~3) + a.P0 + a.P1 + 2 * (size_t)a.A + 3 * tv4 + FT + 4 * (size_t)FT;
     fl += (size_t)(FT / L) * (a.A + 4);             // processed-memory tile
+    const size_t worker = SkinnyLds<FT / 64>::kFloats;
+    if (fl < worker) fl = worker;
     return fl * sizeof(float);
 }
 
@@ -359,7 +375,7 @@ bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv) {
 
 template <int L, int NP>
 static hipError_t front_launch(const DecFrontArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((gt_dec_front_kernel<L, NP>), dim3(a.B), dim3(FT), front_lds_bytes(a), s, a);
+    hipLaunchKernelGGL((gt_dec_front_kernel<L, NP>), dim3(a.B + a.n_workers), dim3(FT), front_lds_bytes(a), s, a);
     return hipGetLastError();
 }
 

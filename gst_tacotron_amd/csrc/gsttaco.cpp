@@ -84,6 +84,9 @@ struct gsttaco_ctx {
     float *gru_w = nullptr, *gru_u = nullptr, *gru_b = nullptr, *dense_w = nullptr, *dense_b = nullptr;
     float *mq_w = nullptr, *mq_b = nullptr, *v_tok = nullptr, *ln_g = nullptr, *ln_b = nullptr;
     PackedLinear prenet0, prenet1, query, val_gst, lstm0, lstm1, proj;
+    PackedLinear lstm_x[2], lstm_h[2];   // split packs: input half (critical path) / recurrent half + bias (front-kernel workers)
+    float* w_part[2] = {nullptr, nullptr};
+    bool split_rec = true;
 
     float *pw0 = nullptr, *pb0 = nullptr, *pw1 = nullptr, *pb1 = nullptr, *pwq = nullptr, *pbq = nullptr;  // plain layouts (fused front)
     bool fused_front = true;
@@ -446,6 +449,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
     int nprof[2] = {0, 0};
+    // layer-2 recurrent tiles co-scheduled with the (11-workgroup) projection kernel: one tile per otherwise idle CU
+    const int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, 256 - c->proj.ntiles));
     for (int t = 0; t < steps; ++t) {
         const int p = t & 1;
         SkinnyArgs k;
@@ -453,7 +458,9 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         const int64_t frame_ld = t == 0 ? 0 : ld_pre;
         const float* mask0 = has_mask ? c->w_masks + (size_t)t * mask_step : nullptr;
         const float* mask1 = has_mask ? c->w_masks + (size_t)t * mask_step + (size_t)B * P0 : nullptr;
-        if (c->fused_front && gt_dec_front_supported(mel, P0, P1, att, Tv)) {
+        const bool fused = c->fused_front && gt_dec_front_supported(mel, P0, P1, att, Tv);
+        const bool split = fused && c->split_rec;
+        if (fused) {
             // 1-4 fused: prenet x2, query projection, score / alignment / context (dec_front.hip)
             DecFrontArgs f{};
             f.frame = frame_ptr; f.ldframe = frame_ld;
@@ -468,6 +475,21 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             f.B = B; f.Tv = Tv; f.mel = mel; f.P0 = P0; f.P1 = P1; f.A = att; f.type = g.att_type;
             f.sigmoid_noise = g.sigmoid_noise;
             f.dbg = (c->stamps && t == steps / 2) ? c->w_dbg : nullptr;
+            if (split) {
+                for (int layer = 0; layer < 2; ++layer) {
+                    SkinnyArgs& rk = f.rec[layer];
+                    const PackedLinear& L = c->lstm_h[layer];
+                    const int H = layer == 0 ? H1 : H2;
+                    rk.wp = L.wp; rk.bias = L.bias; rk.nkb = L.nkb;
+                    rk.seg[0] = SkinnySeg{layer == 0 ? c->w_h1[p ^ 1] : c->w_h2[p ^ 1], 0, H / 16, 1};
+                    rk.M = B; rk.N = H; rk.MT = MT;
+                    rk.partial_out = c->w_part[layer];
+                    f.rec_begin[layer] = 0; f.rec_end[layer] = L.ntiles;
+                }
+                f.n_workers = B < 192 ? 256 - B : 64;
+                // from step 1 on, the projection kernel of the previous step already did layer-2 tiles [0, co_tiles)
+                if (t > 0 && c->proj.nkb >= 32) f.rec_begin[1] = co_tiles;
+            }
             HIPCHECK(c, gt_launch_dec_front(f, s));
         } else {
         // 1. prenet layer 0 on the last emitted frame (Taco2.py:186: decodings[:, -1]; zeros at t=0)
@@ -514,14 +536,23 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             memset(&k, 0, sizeof(k));
             const int H = layer == 0 ? H1 : H2;
             float** hb = layer == 0 ? c->w_h1 : c->w_h2;
-            const PackedLinear& L = layer == 0 ? c->lstm0 : c->lstm1;
-            k.wp = L.wp; k.bias = L.bias; k.nkb = L.nkb;
-            if (layer == 0) {
-                k.seg[0] = SkinnySeg{c->w_xa, 0, XA / 16, 1};
-                k.seg[1] = SkinnySeg{c->w_h1[p ^ 1], 0, H1 / 16, 1};
+            if (split) {
+                // only the half that depends on this step's inputs; + partial_in (recurrent half + bias)
+                const PackedLinear& L = c->lstm_x[layer];
+                k.wp = L.wp; k.bias = L.bias; k.nkb = L.nkb;
+                if (layer == 0) k.seg[0] = SkinnySeg{c->w_xa, 0, XA / 16, 1};
+                else k.seg[0] = SkinnySeg{c->w_h1[p], 0, H1 / 16, 1};
+                k.partial_in = c->w_part[layer];
             } else {
-                k.seg[0] = SkinnySeg{c->w_h1[p], 0, H1 / 16, 1};
-                k.seg[1] = SkinnySeg{c->w_h2[p ^ 1], 0, H2 / 16, 1};
+                const PackedLinear& L = layer == 0 ? c->lstm0 : c->lstm1;
+                k.wp = L.wp; k.bias = L.bias; k.nkb = L.nkb;
+                if (layer == 0) {
+                    k.seg[0] = SkinnySeg{c->w_xa, 0, XA / 16, 1};
+                    k.seg[1] = SkinnySeg{c->w_h1[p ^ 1], 0, H1 / 16, 1};
+                } else {
+                    k.seg[0] = SkinnySeg{c->w_h1[p], 0, H1 / 16, 1};
+                    k.seg[1] = SkinnySeg{c->w_h2[p ^ 1], 0, H2 / 16, 1};
+                }
             }
             k.N = H; k.c = layer == 0 ? c->w_c1 : c->w_c2; k.h = hb[p]; k.out_blocked = 1;
             k.M = B; k.MT = MT;
@@ -549,7 +580,19 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         k.nkb = c->proj.nkb; k.M = B; k.N = c->proj_out; k.n_split = mel * r; k.MT = MT;
         k.out = c->w_pre + (size_t)t * r * mel; k.ldo = ld_pre;
         k.out2 = c->w_stop + t; k.ldo2 = steps;
-        HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->proj.ntiles, s));
+        if (split && t + 1 < steps && c->proj.nkb >= 32) {
+            // co-scheduled workers: recurrent half of layer 2 for the NEXT step, h2_t . W_h + b (tiles [0, co_tiles))
+            SkinnyArgs rk;
+            memset(&rk, 0, sizeof(rk));
+            const PackedLinear& L = c->lstm_h[1];
+            rk.wp = L.wp; rk.bias = L.bias; rk.nkb = L.nkb;
+            rk.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
+            rk.M = B; rk.N = H2; rk.MT = MT;
+            rk.partial_out = c->w_part[1];
+            HIPCHECK(c, gt_launch_skinny_co(k, c->proj.ntiles, rk, 0, co_tiles, s));
+        } else {
+            HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->proj.ntiles, s));
+        }
     }
     c->prof_count[0] = nprof[0];
     c->prof_count[1] = nprof[1];
@@ -679,6 +722,8 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->use_graph = !(eg && eg[0] == '0');
     const char* ef = getenv("GSTTACO_FUSED_FRONT");
     c->fused_front = !(ef && ef[0] == '0');
+    const char* er = getenv("GSTTACO_SPLIT_REC");
+    c->split_rec = !(er && er[0] == '0');
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);
@@ -824,6 +869,9 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
             if ((rc = pack_linear(c, l == 0 ? &c->lstm0 : &c->lstm1,
                                   {{k.data.data(), (int)k.shape[0]}, {u.data.data(), (int)u.shape[0]}},
                                   4 * g.dec_rnn[l], b.data.data(), g.dec_rnn[l]))) return rc;
+            // split form: z = x.W_x + (h_prev.W_h + b); the second term is computed by the front kernel's workers
+            if ((rc = pack_linear(c, &c->lstm_x[l], {{k.data.data(), (int)k.shape[0]}}, 4 * g.dec_rnn[l], nullptr, g.dec_rnn[l]))) return rc;
+            if ((rc = pack_linear(c, &c->lstm_h[l], {{u.data.data(), (int)u.shape[0]}}, 4 * g.dec_rnn[l], b.data.data(), g.dec_rnn[l]))) return rc;
         }
         const HostTensor &pk = T(c, "decoder.projection.kernel"), &pb = T(c, "decoder.projection.bias");
         if ((rc = pack_linear(c, &c->proj, {{pk.data.data(), (int)pk.shape[0]}}, c->proj_out, pb.data.data(), 0))) return rc;
@@ -877,6 +925,8 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         if ((rc = fa(&c->w_h1[i], Bp * c->H1))) return rc;
         if ((rc = fa(&c->w_h2[i], Bp * c->H2))) return rc;
     }
+    if ((rc = fa(&c->w_part[0], Bp * 4 * c->H1))) return rc;
+    if ((rc = fa(&c->w_part[1], Bp * 4 * c->H2))) return rc;
     if ((rc = fa(&c->w_c1, B * c->H1))) return rc;
     if ((rc = fa(&c->w_c2, B * c->H2))) return rc;
     if ((rc = fa(&c->w_pre, B * Tf * mel))) return rc;

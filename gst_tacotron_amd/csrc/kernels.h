@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 // ---------------------------------------------------------------- skinny_gemm.hip
-enum { EPI_LINEAR = 0, EPI_RELU_DROP = 1, EPI_LSTM = 2 };
+enum { EPI_LINEAR = 0, EPI_RELU_DROP = 1, EPI_LSTM = 2, EPI_PARTIAL = 3 };
 
 // Activation ("A operand") layouts of a [M, K] matrix:
 //   row-major : element (row, k) at ptr[row*ld + k]
@@ -40,12 +40,19 @@ struct SkinnyArgs {
     // EPI_LSTM
     float* c;           // [M, H] cell state, updated in place
     float* h; int64_t ldh;
+    // EPI_PARTIAL writes / EPI_LSTM adds pre-activation partial sums, tile order [tile][MT*16 rows][16 cols]
+    float* partial_out;
+    const float* partial_in;
     unsigned long long* dbg;   // diagnostic phase stamps (s_memrealtime, 100 MHz) of block 0, or NULL
 };
 
 enum { TAG_GENERIC = 0, TAG_DEC_LSTM1 = 1, TAG_DEC_LSTM2 = 2, TAG_ENC_BILSTM = 3 };
 hipError_t gt_launch_skinny(int epi, const SkinnyArgs& a0, const SkinnyArgs* a1, int ntiles, hipStream_t stream,
                             int tag = TAG_GENERIC);
+// EPI_LINEAR main GEMM (tiles [0, ntiles)) plus co-scheduled worker workgroups in the same launch that compute tiles
+// [co_begin, co_end) of an independent EPI_PARTIAL GEMM `co` on CUs the small main grid leaves idle.
+hipError_t gt_launch_skinny_co(const SkinnyArgs& main_args, int ntiles, const SkinnyArgs& co, int co_begin, int co_end,
+                               hipStream_t stream);
 
 // ---------------------------------------------------------------- gemm_conv.hip
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
@@ -107,6 +114,12 @@ struct DecFrontArgs {
     int B, Tv, mel, P0, P1, A, type;
     float sigmoid_noise;
     unsigned long long* dbg;   // diagnostic phase stamps of block 0, or NULL
+    // Worker workgroups (blockIdx.x >= B) of the same launch: recurrent halves h_{t-1}.W_h + b of the two decode LSTM
+    // layers, written as pre-activation partial sums.  They only need the PREVIOUS step's state, so they run on the
+    // ~224 CUs the per-utterance front end leaves idle.  n_workers == 0 disables them.
+    SkinnyArgs rec[2];
+    int rec_begin[2], rec_end[2];   // tile ranges [begin, end) of each layer handled by this launch's workers
+    int n_workers;
 };
 bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv);
 hipError_t gt_dec_front_init();

@@ -1,0 +1,187 @@
+// Body of the skinny (batch-rows) fp32 MFMA GEMM, shared by gt_skinny_kernel (skinny_gemm.hip) and by the worker
+// workgroups of the fused decoder front kernel (dec_front.hip).  See skinny_gemm.hip for the design notes.
+#pragma once
+#include "device_utils.h"
+#include "kernels.h"
+
+// LDS needed by one workgroup running the body with NW waves (floats)
+template <int NW>
+struct SkinnyLds {
+    static constexpr int kPart = NW * 32 * 17;
+    static constexpr int kZs = 32 * 17;
+    static constexpr int kFloats = kPart + kZs;
+};
+
+// One workgroup (NW waves, all NW*64 threads must call) computes output tile `tile` (16 columns) for batch rows
+// [mchunk*32, mchunk*32+32).  `lds` points at SkinnyLds<NW>::kFloats floats of LDS.
+template <int EPI, int NW, bool NT_WEIGHTS>
+__device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int tile, const int mchunk, float* lds) {
+    // k-blocks a wave keeps in flight at once: 3 x 16-byte loads each -> 12 VGPRs per k-block
+    constexpr int MAXI = NW == 8 ? 16 : (NW == 16 ? 4 : 8);
+    float (*part)[32][17] = reinterpret_cast<float (*)[32][17]>(lds);
+    float (*zs)[17] = reinterpret_cast<float (*)[17]>(lds + SkinnyLds<NW>::kPart);
+
+    const int m0 = mchunk * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int M = A.M;
+    const int row0 = min(m0 + r, M - 1);
+    const int row1 = min(m0 + 16 + r, M - 1);
+
+    // epilogue operands are requested first so they are never on the dependent tail
+    const int e_row = threadIdx.x >> 4, e_col = threadIdx.x & 15;       // (only the first 512 threads' worth is used)
+    constexpr int NE = (512 / (NW * 64)) > 0 ? (512 / (NW * 64)) : 1;     // outputs per thread of the 32x16 tile
+    const bool e_act = NW * 64 <= 512 || threadIdx.x < 512;
+    float bias_v[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        bias_v[i] = A.bias[tile * 16 + e_col];
+        if (EPI == EPI_LSTM && A.partial_in && e_act && m0 + e_row + i * (NW * 4) < A.MT * 16)
+            bias_v[i] += A.partial_in[((size_t)tile * A.MT * 16 + m0 + e_row + i * (NW * 4)) * 16 + e_col];   // recurrent half + bias
+    }
+    float c_prev = 0.f;
+    if (EPI == EPI_LSTM && threadIdx.x < 128) {
+        const int grow = m0 + (threadIdx.x >> 2), unit = tile * 4 + (threadIdx.x & 3);
+        if (grow < M && unit < A.N) c_prev = A.c[(size_t)grow * A.N + unit];
+    }
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+    GT_STAMP(A.dbg, 0);
+
+    const float4* wp = reinterpret_cast<const float4*>(A.wp) + (size_t)tile * A.nkb * 64 + lane;
+    const int nkb = A.nkb;
+    const int e0 = A.seg[0].nkb, e1 = e0 + A.seg[1].nkb;
+    // per-segment lane base pointers for the two M-tiles (rows m0..m0+15, m0+16..m0+31) and the k-block stride
+    const int MT = A.MT;
+    const int mt0 = mchunk * 2, mt1 = min(mt0 + 1, MT - 1);
+    const float *sp0[3], *sp1[3];
+    int sstep[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const SkinnySeg& S = A.seg[s].nkb ? A.seg[s] : A.seg[0];
+        if (S.blocked) {
+            sp0[s] = S.ptr + (size_t)mt0 * 256 + lane * 4;
+            sp1[s] = S.ptr + (size_t)mt1 * 256 + lane * 4;
+            sstep[s] = MT * 256;
+        } else {
+            sp0[s] = S.ptr + (size_t)row0 * S.ld + 4 * q;
+            sp1[s] = S.ptr + (size_t)row1 * S.ld + 4 * q;
+            sstep[s] = 16;
+        }
+    }
+
+    for (int base = wave; base < nkb; base += NW * MAXI) {
+        float4 b[MAXI], x0[MAXI], x1[MAXI];
+        // issue every load of this chunk before the first MFMA: the wave's whole K range is in flight at once
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int kb = base + i * NW;               // wave-uniform
+            if (kb < nkb) {
+                const float *p0, *p1;
+                int lk, st;
+                if (kb < e0) { p0 = sp0[0]; p1 = sp1[0]; lk = kb; st = sstep[0]; }
+                else if (kb < e1) { p0 = sp0[1]; p1 = sp1[1]; lk = kb - e0; st = sstep[1]; }
+                else { p0 = sp0[2]; p1 = sp1[2]; lk = kb - e1; st = sstep[2]; }
+                if (NT_WEIGHTS) {
+                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)kb * 64));
+                    b[i] = make_float4(t[0], t[1], t[2], t[3]);
+                } else {
+                    b[i] = wp[(size_t)kb * 64];
+                }
+                x0[i] = *reinterpret_cast<const float4*>(p0 + (size_t)lk * st);
+                x1[i] = *reinterpret_cast<const float4*>(p1 + (size_t)lk * st);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int kb = base + i * NW;
+            if (kb < nkb) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, b[i].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, b[i].x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, b[i].y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, b[i].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, b[i].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, b[i].z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, b[i].w, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, b[i].w, acc1, 0, 0, 0);
+            }
+        }
+    }
+
+    GT_STAMP(A.dbg, 1);
+    // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        part[wave][q * 4 + j][r] = acc0[j];
+        part[wave][16 + q * 4 + j][r] = acc1[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        if (!e_act) break;
+        const int row = e_row + i * (NW * 4);
+        float z = bias_v[i];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) z += part[w][row][e_col];
+        zs[row][e_col] = z;
+    }
+    __syncthreads();
+    GT_STAMP(A.dbg, 2);
+
+    if (EPI == EPI_PARTIAL) {
+        // pre-activation partial sums in tile order [tile][MT*16 rows][16 cols]
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int row = e_row + i * (NW * 4);
+            if (e_act && m0 + row < A.MT * 16) A.partial_out[((size_t)tile * A.MT * 16 + m0 + row) * 16 + e_col] = zs[row][e_col];
+        }
+    } else if (EPI == EPI_LSTM) {
+        // tile-local column g*4+u  <->  gate g (i,f,c~,o) of hidden unit tile*4+u
+        const int e = threadIdx.x;
+        if (e < 128) {
+            const int row = e >> 2, u = e & 3;
+            const int grow = m0 + row;
+            const int unit = tile * 4 + u;
+            if (grow < M && unit < A.N) {
+                const float gi = gt_sigmoid(zs[row][u]);
+                const float gf = gt_sigmoid(zs[row][4 + u]);
+                const float gg = gt_tanh(zs[row][8 + u]);
+                const float go = gt_sigmoid(zs[row][12 + u]);
+                const float c2 = gf * c_prev + gi * gg;
+                A.c[(size_t)grow * A.N + unit] = c2;
+                const float hv = go * gt_tanh(c2);
+                if (A.out_blocked) A.h[gt_blk_off(grow, unit, MT)] = hv;
+                else A.h[(size_t)grow * A.ldh + unit] = hv;
+            }
+        }
+    } else {
+        for (int e = threadIdx.x; e < 512; e += NW * 64) {
+            const int row = e >> 4, col = e & 15;
+            const int grow = m0 + row, gcol = tile * 16 + col;
+            if (grow < M && gcol < A.N) {
+                float v = zs[row][col];
+                if (EPI == EPI_RELU_DROP) {
+                    v = fmaxf(v, 0.f);
+                    if (A.drop_rate > 0.f) {
+                        float keep;
+                        if (A.mask) {
+                            keep = A.mask[(size_t)grow * A.ldm + gcol];
+                        } else {
+                            Philox4 p = gt_philox(*A.seed_ptr, (uint32_t)(grow * A.N + gcol), A.rng_step, 0u, A.rng_stream);
+                            keep = (gt_u01(p.x) > A.drop_rate) ? 1.f : 0.f;
+                        }
+                        v = v * A.drop_scale * keep;      // tf.nn.dropout: x * scale * mask
+                    }
+                }
+                if (gcol < A.n_split) {
+                    if (A.out_blocked) A.out[gt_blk_off(grow, gcol, MT)] = v;
+                    else A.out[(size_t)grow * A.ldo + gcol] = v;
+                }
+                else A.out2[(size_t)grow * A.ldo2 + (gcol - A.n_split)] = v;
+            }
+        }
+    }
+    GT_STAMP(A.dbg, 3);
+}

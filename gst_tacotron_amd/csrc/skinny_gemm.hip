@@ -18,172 +18,43 @@
 // loads are the B operands of 4 consecutive v_mfma_f32_16x16x4_f32; the matching A operands (activations)
 // are 4 consecutive k of one batch row = one 16-byte load.  fp32 in / fp32 accumulate (exact fp32 FMA
 // chain), since the parity bar is 1e-3 through a 1000-frame recurrence.
-#include "device_utils.h"
-#include "kernels.h"
+#include "skinny_body.h"
 
 // TAG only separates kernel symbols per call site (decode LSTM layer 1 / 2, encoder BiLSTM) so that
 // rocprofv3 --stats reports them on separate lines.
 template <int EPI, int NW, int TAG>
 __global__ __launch_bounds__(NW * 64) void gt_skinny_kernel(SkinnyArgs a0, SkinnyArgs a1) {
     const SkinnyArgs& A = (blockIdx.z == 0) ? a0 : a1;
-    // k-blocks a wave keeps in flight at once: 3 x 16-byte loads each -> 12 VGPRs per k-block
-    constexpr int MAXI = NW == 8 ? 16 : 8;
-    // weights of the big LSTM GEMMs are read by exactly one CU once per step: stream them non-temporally so
-    // they do not evict the activations / prenet weights / processed memory that every step re-reads from L2
-    constexpr bool NT_WEIGHTS = (TAG == TAG_DEC_LSTM1 || TAG == TAG_DEC_LSTM2);
-    __shared__ float part[NW][32][17];
-    __shared__ float zs[32][17];
+    __shared__ __attribute__((aligned(16))) float lds[SkinnyLds<NW>::kFloats];
+    // weights of the big decode LSTM GEMMs are read by exactly one CU once per step: stream them non-temporally
+    constexpr bool NT = (TAG == TAG_DEC_LSTM1 || TAG == TAG_DEC_LSTM2);
+    gt_skinny_body<EPI, NW, NT>(A, blockIdx.x, blockIdx.y, lds);
+}
 
-    const int tile = blockIdx.x;
-    const int m0 = blockIdx.y * 32;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 15, q = lane >> 4;
-    const int M = A.M;
-    const int row0 = min(m0 + r, M - 1);
-    const int row1 = min(m0 + 16 + r, M - 1);
-
-    // epilogue operands are requested first so they are never on the dependent tail
-    const int e_row = threadIdx.x >> 4, e_col = threadIdx.x & 15;       // (only the first 512 threads' worth is used)
-    float bias_v[512 / (NW * 64) > 0 ? 512 / (NW * 64) : 1];
-#pragma unroll
-    for (int i = 0; i < 512 / (NW * 64); ++i) bias_v[i] = A.bias[tile * 16 + e_col];
-    float c_prev = 0.f;
-    if (EPI == EPI_LSTM && threadIdx.x < 128) {
-        const int grow = m0 + (threadIdx.x >> 2), unit = tile * 4 + (threadIdx.x & 3);
-        if (grow < M && unit < A.N) c_prev = A.c[(size_t)grow * A.N + unit];
-    }
-
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
-    GT_STAMP(A.dbg, 0);
-
-    const float4* wp = reinterpret_cast<const float4*>(A.wp) + (size_t)tile * A.nkb * 64 + lane;
-    const int nkb = A.nkb;
-    const int e0 = A.seg[0].nkb, e1 = e0 + A.seg[1].nkb;
-    // per-segment lane base pointers for the two M-tiles (rows m0..m0+15, m0+16..m0+31) and the k-block stride
-    const int MT = A.MT;
-    const int mt0 = blockIdx.y * 2, mt1 = min(mt0 + 1, MT - 1);
-    const float *sp0[3], *sp1[3];
-    int sstep[3];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const SkinnySeg& S = A.seg[s].nkb ? A.seg[s] : A.seg[0];
-        if (S.blocked) {
-            sp0[s] = S.ptr + (size_t)mt0 * 256 + lane * 4;
-            sp1[s] = S.ptr + (size_t)mt1 * 256 + lane * 4;
-            sstep[s] = MT * 256;
-        } else {
-            sp0[s] = S.ptr + (size_t)row0 * S.ld + 4 * q;
-            sp1[s] = S.ptr + (size_t)row1 * S.ld + 4 * q;
-            sstep[s] = 16;
-        }
-    }
-
-    for (int base = wave; base < nkb; base += NW * MAXI) {
-        float4 b[MAXI], x0[MAXI], x1[MAXI];
-        // issue every load of this chunk before the first MFMA: the wave's whole K range is in flight at once
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int kb = base + i * NW;               // wave-uniform
-            if (kb < nkb) {
-                const float *p0, *p1;
-                int lk, st;
-                if (kb < e0) { p0 = sp0[0]; p1 = sp1[0]; lk = kb; st = sstep[0]; }
-                else if (kb < e1) { p0 = sp0[1]; p1 = sp1[1]; lk = kb - e0; st = sstep[1]; }
-                else { p0 = sp0[2]; p1 = sp1[2]; lk = kb - e1; st = sstep[2]; }
-                if (NT_WEIGHTS) {
-                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)kb * 64));
-                    b[i] = make_float4(t[0], t[1], t[2], t[3]);
-                } else {
-                    b[i] = wp[(size_t)kb * 64];
-                }
-                x0[i] = *reinterpret_cast<const float4*>(p0 + (size_t)lk * st);
-                x1[i] = *reinterpret_cast<const float4*>(p1 + (size_t)lk * st);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int kb = base + i * NW;
-            if (kb < nkb) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, b[i].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, b[i].x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, b[i].y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, b[i].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, b[i].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, b[i].z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, b[i].w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, b[i].w, acc1, 0, 0, 0);
-            }
-        }
-    }
-
-    GT_STAMP(A.dbg, 1);
-    // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + reg
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        part[wave][q * 4 + j][r] = acc0[j];
-        part[wave][16 + q * 4 + j][r] = acc1[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 512 / (NW * 64); ++i) {
-        const int row = e_row + i * (NW * 4);
-        float z = bias_v[i];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) z += part[w][row][e_col];
-        zs[row][e_col] = z;
-    }
-    __syncthreads();
-    GT_STAMP(A.dbg, 2);
-
-    if (EPI == EPI_LSTM) {
-        // tile-local column g*4+u  <->  gate g (i,f,c~,o) of hidden unit tile*4+u
-        const int e = threadIdx.x;
-        if (e < 128) {
-            const int row = e >> 2, u = e & 3;
-            const int grow = m0 + row;
-            const int unit = tile * 4 + u;
-            if (grow < M && unit < A.N) {
-                const float gi = gt_sigmoid(zs[row][u]);
-                const float gf = gt_sigmoid(zs[row][4 + u]);
-                const float gg = gt_tanh(zs[row][8 + u]);
-                const float go = gt_sigmoid(zs[row][12 + u]);
-                const float c2 = gf * c_prev + gi * gg;
-                A.c[(size_t)grow * A.N + unit] = c2;
-                const float hv = go * gt_tanh(c2);
-                if (A.out_blocked) A.h[gt_blk_off(grow, unit, MT)] = hv;
-                else A.h[(size_t)grow * A.ldh + unit] = hv;
-            }
+// Projection (EPI_LINEAR, 11 workgroups at 161 columns) co-scheduled with recurrent-half partial GEMM tiles.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gt_skinny_co_kernel(SkinnyArgs main_args, SkinnyArgs co, int n_main, int co_begin) {
+    __shared__ __attribute__((aligned(16))) float lds[SkinnyLds<NW>::kFloats];
+    const int mchunks = (main_args.M + 31) / 32;
+    if ((int)blockIdx.x < n_main) {
+        for (int mc = 0; mc < mchunks; ++mc) {
+            gt_skinny_body<EPI_LINEAR, NW, false>(main_args, blockIdx.x, mc, lds);
+            __syncthreads();
         }
     } else {
-        for (int e = threadIdx.x; e < 512; e += NW * 64) {
-            const int row = e >> 4, col = e & 15;
-            const int grow = m0 + row, gcol = tile * 16 + col;
-            if (grow < M && gcol < A.N) {
-                float v = zs[row][col];
-                if (EPI == EPI_RELU_DROP) {
-                    v = fmaxf(v, 0.f);
-                    if (A.drop_rate > 0.f) {
-                        float keep;
-                        if (A.mask) {
-                            keep = A.mask[(size_t)grow * A.ldm + gcol];
-                        } else {
-                            Philox4 p = gt_philox(*A.seed_ptr, (uint32_t)(grow * A.N + gcol), A.rng_step, 0u, A.rng_stream);
-                            keep = (gt_u01(p.x) > A.drop_rate) ? 1.f : 0.f;
-                        }
-                        v = v * A.drop_scale * keep;      // tf.nn.dropout: x * scale * mask
-                    }
-                }
-                if (gcol < A.n_split) {
-                    if (A.out_blocked) A.out[gt_blk_off(grow, gcol, MT)] = v;
-                    else A.out[(size_t)grow * A.ldo + gcol] = v;
-                }
-                else A.out2[(size_t)grow * A.ldo2 + (gcol - A.n_split)] = v;
-            }
+        const int tile = co_begin + (int)blockIdx.x - n_main;
+        for (int mc = 0; mc < mchunks; ++mc) {
+            gt_skinny_body<EPI_PARTIAL, NW, true>(co, tile, mc, lds);
+            __syncthreads();
         }
     }
-    GT_STAMP(A.dbg, 3);
+}
+
+hipError_t gt_launch_skinny_co(const SkinnyArgs& main_args, int ntiles, const SkinnyArgs& co, int co_begin, int co_end,
+                               hipStream_t stream) {
+    const int nco = co_end > co_begin ? co_end - co_begin : 0;
+    hipLaunchKernelGGL((gt_skinny_co_kernel<8>), dim3(ntiles + nco), dim3(512), 0, stream, main_args, co, ntiles, co_begin);
+    return hipGetLastError();
 }
 
 template <int EPI, int TAG>
