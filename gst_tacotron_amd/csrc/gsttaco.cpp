@@ -111,8 +111,10 @@ struct gsttaco_ctx {
 
     // profiling
     int prof_every = 0;
-    int prof_count[2] = {0, 0};
-    std::vector<hipEvent_t> prof_ev[2];     // pairs (start, stop) per bracketed launch, per LSTM layer
+    // bracketed decode kernels: 0 = LSTM layer 1, 1 = LSTM layer 2, 2 = front (+ workers), 3 = projection (+ workers)
+    // 4 = empty bracket (two event nodes back to back): the cost the bracketing itself adds, for calibration
+    int prof_count[5] = {0, 0, 0, 0, 0};
+    std::vector<hipEvent_t> prof_ev[5];     // pairs (start, stop) per bracketed launch
 };
 
 namespace {
@@ -448,7 +450,21 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     HIPCHECK(c, gt_launch_zero(c->w_c2, (size_t)B * H2, s));
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
-    int nprof[2] = {0, 0};
+    int nprof[5] = {0, 0, 0, 0, 0};
+    auto prof_begin = [&](int which) -> int {
+        const size_t need = (size_t)2 * (nprof[which] + 1);
+        while (c->prof_ev[which].size() < need) {
+            hipEvent_t e;
+            HIPCHECK(c, hipEventCreate(&e));
+            c->prof_ev[which].push_back(e);
+        }
+        return record_event(c, c->prof_ev[which][2 * nprof[which]], s);
+    };
+    auto prof_end = [&](int which) -> int {
+        int rce = record_event(c, c->prof_ev[which][2 * nprof[which] + 1], s);
+        nprof[which]++;
+        return rce;
+    };
     // layer-2 recurrent tiles co-scheduled with the (11-workgroup) projection kernel: one tile per otherwise idle CU
     const int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, 256 - c->proj.ntiles));
     for (int t = 0; t < steps; ++t) {
@@ -458,6 +474,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         const int64_t frame_ld = t == 0 ? 0 : ld_pre;
         const float* mask0 = has_mask ? c->w_masks + (size_t)t * mask_step : nullptr;
         const float* mask1 = has_mask ? c->w_masks + (size_t)t * mask_step + (size_t)B * P0 : nullptr;
+        const bool prof = c->prof_every > 0 && (t % c->prof_every) == 0;
         const bool fused = c->fused_front && gt_dec_front_supported(mel, P0, P1, att, Tv);
         const bool split = fused && c->split_rec;
         if (fused) {
@@ -490,7 +507,9 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 // from step 1 on, the projection kernel of the previous step already did layer-2 tiles [0, co_tiles)
                 if (t > 0 && c->proj.nkb >= 32) f.rec_begin[1] = co_tiles;
             }
+            if (prof) { int rce = prof_begin(2); if (rce) return rce; }
             HIPCHECK(c, gt_launch_dec_front(f, s));
+            if (prof) { int rce = prof_end(2); if (rce) return rce; }
         } else {
         // 1. prenet layer 0 on the last emitted frame (Taco2.py:186: decodings[:, -1]; zeros at t=0)
         memset(&k, 0, sizeof(k));
@@ -531,7 +550,6 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         HIPCHECK(c, gt_launch_attn_step(a, s));
         }
         // 5/6. the two LSTM cells (StackedRNNCells, Taco2.py:111)
-        const bool prof = c->prof_every > 0 && (t % c->prof_every) == 0;
         for (int layer = 0; layer < 2; ++layer) {
             memset(&k, 0, sizeof(k));
             const int H = layer == 0 ? H1 : H2;
@@ -557,20 +575,9 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             k.N = H; k.c = layer == 0 ? c->w_c1 : c->w_c2; k.h = hb[p]; k.out_blocked = 1;
             k.M = B; k.MT = MT;
             k.dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
-            if (prof) {
-                const size_t need = (size_t)2 * (nprof[layer] + 1);
-                while (c->prof_ev[layer].size() < need) {
-                    hipEvent_t e;
-                    HIPCHECK(c, hipEventCreate(&e));
-                    c->prof_ev[layer].push_back(e);
-                }
-                { int rce = record_event(c, c->prof_ev[layer][2 * nprof[layer]], s); if (rce) return rce; }
-            }
+            if (prof) { int rce = prof_begin(layer); if (rce) return rce; }
             HIPCHECK(c, gt_launch_skinny(EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));
-            if (prof) {
-                { int rce = record_event(c, c->prof_ev[layer][2 * nprof[layer] + 1], s); if (rce) return rce; }
-                nprof[layer]++;
-            }
+            if (prof) { int rce = prof_end(layer); if (rce) return rce; }
         }
         // 7. projection [h2, ctx] -> r mel frames + stop logit, written in place (Taco2.py:112-118,194-205)
         memset(&k, 0, sizeof(k));
@@ -580,6 +587,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         k.nkb = c->proj.nkb; k.M = B; k.N = c->proj_out; k.n_split = mel * r; k.MT = MT;
         k.out = c->w_pre + (size_t)t * r * mel; k.ldo = ld_pre;
         k.out2 = c->w_stop + t; k.ldo2 = steps;
+        if (prof) { int rce = prof_begin(3); if (rce) return rce; }
         if (split && t + 1 < steps && c->proj.nkb >= 32) {
             // co-scheduled workers: recurrent half of layer 2 for the NEXT step, h2_t . W_h + b (tiles [0, co_tiles))
             SkinnyArgs rk;
@@ -593,9 +601,13 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         } else {
             HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->proj.ntiles, s));
         }
+        if (prof) { int rce = prof_end(3); if (rce) return rce; }
+        if (prof) {     // empty bracket
+            int rce = prof_begin(4); if (rce) return rce;
+            rce = prof_end(4); if (rce) return rce;
+        }
     }
-    c->prof_count[0] = nprof[0];
-    c->prof_count[1] = nprof[1];
+    for (int i = 0; i < 5; ++i) c->prof_count[i] = nprof[i];
     return 0;
 }
 
@@ -734,7 +746,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
 void gsttaco_destroy(gsttaco_ctx* c) {
     if (!c) return;
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < 5; ++l)
         for (auto e : c->prof_ev[l]) (void)hipEventDestroy(e);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
 
@@ -1070,7 +1082,7 @@ int gsttaco_set_profiling(gsttaco_ctx* c, int every) {
 }
 
 int gsttaco_get_profile(gsttaco_ctx* c, int layer, float* avg_ms, int* count) {
-    if (!c || layer < 0 || layer > 1 || !avg_ms || !count) return GSTTACO_E_INVALID;
+    if (!c || layer < 0 || layer > 4 || !avg_ms || !count) return GSTTACO_E_INVALID;
     const int n = c->prof_count[layer];
     double sum = 0;
     for (int i = 0; i < n; ++i) {
@@ -1089,12 +1101,31 @@ int gsttaco_debug_stamps(gsttaco_ctx* c, unsigned long long* host_out48) {
     return 0;
 }
 
-int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int layer, int B) {
-    if (!c || layer < 0 || layer > 1) return GSTTACO_E_INVALID;
-    // weights (kernel + recurrent kernel + bias) read once + activations in (x, h_prev, c) and out (h, c)
-    const int64_t H = layer == 0 ? c->H1 : c->H2;
-    const int64_t K = layer == 0 ? (c->P1 + c->att + c->H1) : (c->H1 + c->H2);
-    return 4 * (K * 4 * H + 4 * H) + 4 * (int64_t)B * (K + 3 * H);
+int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int which, int B) {
+    if (!c || which < 0 || which > 3) return GSTTACO_E_INVALID;
+    // Algorithmic bytes of one launch at batch B and T_v = max_tokens: every weight once, every activation row once
+    // in and once out (the re-reads of the shared activations by every workgroup are NOT algorithmic).
+    const int64_t P0 = c->P0, P1 = c->P1, A = c->att, H1 = c->H1, H2 = c->H2, mel = c->cfg.mel_dim, Tv = c->cfg.max_tokens;
+    const bool fused = c->fused_front && c->split_rec;
+    auto gemm = [&](int64_t K, int64_t N, int64_t extra_row_floats) { return 4 * (K * N + N) + 4 * (int64_t)B * (K + extra_row_floats); };
+    const int64_t ntile2 = (H2 + 3) / 4;
+    const int64_t co_tiles = std::max<int64_t>(0, std::min<int64_t>(ntile2, 256 - c->proj.ntiles));
+    switch (which) {
+        case 0:     // LSTM layer 1: x-half only when the recurrent half runs in the front launch
+            return fused ? gemm(P1 + A, 4 * H1, 4 * H1 + 3 * H1) : gemm(P1 + A + H1, 4 * H1, 3 * H1);
+        case 1:
+            return fused ? gemm(H1, 4 * H2, 4 * H2 + 3 * H2) : gemm(H1 + H2, 4 * H2, 3 * H2);
+        case 2: {   // front: prenet x2 + query weights, processed memory, alignments; + workers' recurrent halves
+            int64_t b = 4 * (mel * P0 + P0 + P0 * P1 + P1 + P1 * A + A) + 4 * (int64_t)B * (Tv * A + mel + 2 * Tv + P1 + A);
+            if (fused) b += gemm(H1, 4 * H1, 4 * H1) + (ntile2 - co_tiles) * (4 * (H2 * 16 + 16) + 4 * (int64_t)B * 16) + 4 * (int64_t)B * H2;
+            return b;
+        }
+        default: {  // projection (+ co-scheduled layer-2 recurrent tiles)
+            int64_t b = gemm(H2 + A, c->proj_out, c->proj_out);
+            if (fused) b += co_tiles * (4 * (H2 * 16 + 16) + 4 * (int64_t)B * 16);
+            return b;
+        }
+    }
 }
 
 }  // extern "C"

@@ -146,8 +146,7 @@ int gsttaco_inference_step(gsttaco_ctx* ctx, const int32_t* tokens,
                            float* mel, float* stop, float* align, float* pre_mel, void* stream);
 
 /* Measurement support (bench.py): per-kernel timing of the last gsttaco_inference_step replay.
- * When enabled, HIP event-record nodes bracket every `every`-th launch of the dominant decode
- * kernel (the LSTM gate GEMM) inside the graph. */
+ * When enabled, HIP event-record nodes bracket the four kernels of every `every`-th decode step inside the graph. */
 int gsttaco_set_profiling(gsttaco_ctx* ctx, int every);
 /* After the stream has been synchronised by the caller: average duration (ms) of the bracketed
  * launches of decode-LSTM layer `layer` (0/1) and how many were bracketed. */
