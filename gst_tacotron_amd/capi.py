@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsttaco.so")
 
 MAX_LAYERS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 ATT_CODES = {"BMA": 0, "SMA": 1}
 
 # every symbol include/gsttaco.h declares
@@ -82,11 +82,11 @@ def load_library(path=None):
                                         ctypes.POINTER(ctypes.c_int64 * 4), ctypes.POINTER(ctypes.c_int)]
     lib.gsttaco_load_weight.argtypes = [vp, ctypes.c_char_p, f32p, ctypes.POINTER(ctypes.c_int64), i32]
     lib.gsttaco_finalize_weights.argtypes = [vp]
-    lib.gsttaco_encode.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.gsttaco_encode.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.gsttaco_gst.argtypes = [vp, vp, vp, i32, i32, vp, vp]
-    lib.gsttaco_decode.argtypes = [vp, vp, vp, vp, vp, u64, i32, i32, i32, vp, vp, vp, vp]
+    lib.gsttaco_decode.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, vp, vp, vp, vp]
     lib.gsttaco_postnet.argtypes = [vp, vp, i32, i32, vp, vp]
-    lib.gsttaco_inference_step.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.gsttaco_inference_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     lib.gsttaco_set_profiling.argtypes = [vp, i32]
     lib.gsttaco_get_profile.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     lib.gsttaco_lstm_launch_bytes.argtypes = [vp, i32, i32]

@@ -39,19 +39,21 @@ __device__ __forceinline__ float wave_incl_scan(float x, int lane) {
 
 __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int Tv = P.Tv, A = P.A, LD = A + 1;
+    const int TvFull = P.Tv, A = P.A, LD = A + 1;
+    // masked mode: only the first tok_len[b] memory positions exist for this utterance
+    const int Tv = P.tok_len ? max(1, min(TvFull, P.tok_len[blockIdx.x])) : TvFull;
     const int rows_lds = P.rows_lds;
     float* tile = smem;                              // [rows_lds][LD]
     float* qs = tile + (size_t)rows_lds * LD;        // [A]
     float* vs = qs + A;                              // [A]
     float* sc = vs + A;                              // [Tv] score -> p
-    float* pv = sc + Tv;                             // [Tv] previous alignment
-    float* al = pv + Tv;                             // [Tv] new alignment
-    float* partial = al + Tv;                        // [4*256]
+    float* pv = sc + TvFull;                         // [Tv] previous alignment
+    float* al = pv + TvFull;                         // [Tv] new alignment
+    float* partial = al + TvFull;                    // [4*256]
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    const float* pm = P.pm + (size_t)b * Tv * A;
+    const float* pm = P.pm + (size_t)b * TvFull * A;
 
     for (int a = tid; a < A; a += ATT_THREADS) {
         qs[a] = P.q[(size_t)b * P.ldq + a];
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
             float nz;
             if (P.noise) nz = P.noise[(size_t)b * P.ldnoise + t];
             else {
-                Philox4 r = gt_philox(*P.seed_ptr, (uint32_t)(b * Tv + t), P.rng_step, 0u, GT_RNG_NOISE);
+                Philox4 r = gt_philox(*P.seed_ptr, (uint32_t)(b * TvFull + t), P.rng_step, 0u, GT_RNG_NOISE);
                 nz = gt_normal(r.x, r.y);
             }
             s += P.sigmoid_noise * nz;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
         }
     }
     __syncthreads();
-    for (int t = tid; t < Tv; t += ATT_THREADS) P.align[(size_t)b * P.ldalign + t] = al[t];
+    for (int t = tid; t < TvFull; t += ATT_THREADS) P.align[(size_t)b * P.ldalign + t] = t < Tv ? al[t] : 0.f;
 
     // ---- pass 2: context  ctx[a] = sum_t al[t] * pm[t][a]; thread -> (a = tid % AP, part = tid / AP)
     const int AP = A <= 64 ? 64 : (A <= 128 ? 128 : 256);

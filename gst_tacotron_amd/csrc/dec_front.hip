@@ -115,7 +115,9 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.x;
-    const int mel = P.mel, P0 = P.P0, P1 = P.P1, Tv = P.Tv;
+    const int mel = P.mel, P0 = P.P0, P1 = P.P1, TvFull = P.Tv;
+    // masked mode (A12): only the first tok_len[b] memory positions exist for this utterance
+    const int Tv = P.tok_len ? max(1, min(TvFull, P.tok_len[b])) : TvFull;
 
     // LDS carve (floats): xs | y0 | y1 | q | v | score | prev | align | red[FT] | partial[4 FT] | tile[ROWS][LD]
     int mx = mel > P0 ? mel : P0; if (P1 > mx) mx = P1;
@@ -125,15 +127,15 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     float* qs = y1 + P1;
     float* vs = qs + A;
     float* sc = vs + A;
-    float* pv = sc + ((Tv + 3) & ~3);
-    float* al = pv + ((Tv + 3) & ~3);
-    float* red = al + ((Tv + 3) & ~3);
+    float* pv = sc + ((TvFull + 3) & ~3);
+    float* al = pv + ((TvFull + 3) & ~3);
+    float* red = al + ((TvFull + 3) & ~3);
     float* partial = red + FT;
     float* tile = partial + 4 * FT;
 
     // ---- issue every independent global load first
     const int row = tid / L, li = tid % L;
-    const float* pm = P.pm + (size_t)b * Tv * A;
+    const float* pm = P.pm + (size_t)b * TvFull * A;
     auto load_rows = [&](float4 (&v)[NP], int c) {
         const int t = c * ROWS + row;
 #pragma unroll
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
             float nz;
             if (P.noise) nz = P.noise[(size_t)b * P.ldnoise + t];
             else {
-                Philox4 r = gt_philox(seed, (uint32_t)(b * Tv + t), P.rng_step, 0u, GT_RNG_NOISE);
+                Philox4 r = gt_philox(seed, (uint32_t)(b * TvFull + t), P.rng_step, 0u, GT_RNG_NOISE);
                 nz = gt_normal(r.x, r.y);
             }
             s += P.sigmoid_noise * nz;
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     }
     __syncthreads();
     GT_STAMP(P.dbg, 6);
-    for (int t = tid; t < Tv; t += FT) P.align[(size_t)b * P.ldalign + t] = al[t];
+    for (int t = tid; t < TvFull; t += FT) P.align[(size_t)b * P.ldalign + t] = t < Tv ? al[t] : 0.f;
 
     // ---- context: ctx[a] = sum_t al[t] * pm[t][a]; lane = channel a (conflict-free column reads of the tile),
     //      CPARTS row groups reduced through LDS

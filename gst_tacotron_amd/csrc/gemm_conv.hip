@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
     const int K = A.taps * A.Cin;
 
     // per-thread A rows (constant over the K loop)
-    int a_b[A_F4], a_t[A_F4];
+    int a_b[A_F4], a_t[A_F4], a_len[A_F4];
     bool a_ok[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
         const int mm = a_ok[i] ? m : 0;
         a_b[i] = mm / A.T;
         a_t[i] = mm - a_b[i] * A.T;
+        a_len[i] = A.row_len ? min(A.T, A.row_len[a_b[i]]) : A.T;      // masked mode: rows >= length read as zero
     }
 
     f32x16 acc[RM][RN];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
                 const int tap = kk / A.Cin;
                 const int c = kk - tap * A.Cin;
                 const int ts = a_t[i] + tap - A.pad_before;
-                if (ts >= 0 && ts < A.T) {
+                if (ts >= 0 && ts < a_len[i]) {
                     const int64_t rowi = (int64_t)a_b[i] * A.T + ts;
                     const float* rp = A.tokens ? A.x + (int64_t)A.tokens[rowi] * A.Cin : A.x + rowi * A.Cin;
                     v = *reinterpret_cast<const float4*>(rp + c);

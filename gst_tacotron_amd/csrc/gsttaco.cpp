@@ -49,7 +49,7 @@ struct ConvLayer {
 };
 
 struct GraphKey {
-    int kind, B, Tv, Tref1, steps, has_mask, has_noise, prof;
+    int kind, B, Tv, Tref1, steps, has_mask, has_noise, prof, masked;
     bool operator<(const GraphKey& o) const {
         return memcmp(this, &o, sizeof(GraphKey)) < 0;
     }
@@ -93,7 +93,7 @@ struct gsttaco_ctx {
     float *val_enc_w = nullptr, *val_bias = nullptr, *att_v = nullptr, *att_sb = nullptr;
 
     // workspace
-    int32_t *w_tokens = nullptr, *w_mel_len = nullptr;
+    int32_t *w_tokens = nullptr, *w_mel_len = nullptr, *w_tok_len = nullptr;
     float *w_mels_in = nullptr, *w_masks = nullptr, *w_noise = nullptr;
     uint64_t* w_seed = nullptr;
     unsigned long long* w_dbg = nullptr;   // [3][16] diagnostic stamps: front, lstm1, lstm2 (GSTTACO_STAMPS=1)
@@ -342,7 +342,8 @@ int record_event(gsttaco_ctx* c, hipEvent_t ev, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ enqueue
-int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
+int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked) {
+    const int32_t* tlen = masked ? c->w_tok_len : nullptr;      // masked-mode extension
     const gsttaco_config& g = c->cfg;
     const float* x = c->d_emb;
     const int32_t* tok = c->w_tokens;
@@ -355,6 +356,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
         a.B = B; a.T = Tv; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;
         a.pad_before = same_pad_before(Tv, L.taps, 1, nullptr);
         a.act = ACT_RELU;
+        a.row_len = tlen;
         HIPCHECK(c, gt_launch_conv_gemm(a, s));
         x = c->w_act[cur]; tok = nullptr; cur ^= 1;
     }
@@ -375,6 +377,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
             k.nkb = c->bilstm[d].nkb; k.M = B; k.N = H; k.MT = (B + 15) / 16;
             k.c = c->w_cenc + (size_t)d * B * H;
             k.h = c->w_enc + (size_t)tt * EO + d * H; k.ldh = (int64_t)Tv * EO;
+            k.row_len = tlen; k.t_index = tt;
         }
         HIPCHECK(c, gt_launch_skinny(EPI_LSTM, a[0], &a[1], c->bilstm[0].ntiles, s, TAG_ENC_BILSTM));
     }
@@ -437,7 +440,8 @@ int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
     return 0;
 }
 
-int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool has_mask, bool has_noise) {
+int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool has_mask, bool has_noise, bool masked) {
+    const int32_t* tlen = masked ? c->w_tok_len : nullptr;
     const gsttaco_config& g = c->cfg;
     const int mel = g.mel_dim, r = c->r, P0 = c->P0, P1 = c->P1, att = c->att, H1 = c->H1, H2 = c->H2;
     const int XA = P1 + att;
@@ -491,6 +495,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             f.xa = c->w_xa; f.MT = MT;
             f.B = B; f.Tv = Tv; f.mel = mel; f.P0 = P0; f.P1 = P1; f.A = att; f.type = g.att_type;
             f.sigmoid_noise = g.sigmoid_noise;
+            f.tok_len = tlen;
             f.dbg = (c->stamps && t == steps / 2) ? c->w_dbg : nullptr;
             if (split) {
                 for (int layer = 0; layer < 2; ++layer) {
@@ -546,7 +551,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         a.align = c->w_align + (size_t)t * Tv; a.ldalign = (int64_t)steps * Tv;
         a.ctx = c->w_xa + (size_t)(P1 / 16) * BLK; a.ldctx = 0; a.ctx_mt = MT;
         a.B = B; a.Tv = Tv; a.A = att; a.type = g.att_type; a.sigmoid_noise = g.sigmoid_noise;
-        a.seed_ptr = c->w_seed; a.rng_step = (uint32_t)t;
+        a.seed_ptr = c->w_seed; a.rng_step = (uint32_t)t; a.tok_len = tlen;
         HIPCHECK(c, gt_launch_attn_step(a, s));
         }
         // 5/6. the two LSTM cells (StackedRNNCells, Taco2.py:111)
@@ -898,6 +903,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     auto fa = [&](float** p, size_t n) { return dev_alloc(c, (void**)p, n * sizeof(float)); };
     if ((rc = dev_alloc(c, (void**)&c->w_tokens, B * Tv * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&c->w_mel_len, B * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&c->w_tok_len, B * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&c->w_seed, 16))) return rc;
     if ((rc = dev_alloc(c, (void**)&c->w_dbg, 3 * 16 * 8))) return rc;
     HIPCHECK(c, hipMemset(c->w_dbg, 0, 3 * 16 * 8));
@@ -958,15 +964,17 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     return 0;
 }
 
-int gsttaco_encode(gsttaco_ctx* c, const int32_t* tokens, int B, int Tv, float* enc, void* stream) {
+int gsttaco_encode(gsttaco_ctx* c, const int32_t* tokens, const int32_t* token_lengths, int B, int Tv, float* enc, void* stream) {
     int rc = check_ready(c);
     if (rc) return rc;
     if (!tokens || !enc) return fail(c, GSTTACO_E_INVALID, "null argument");
     if ((rc = check_shape(c, B, Tv, 0, 0))) return rc;
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(c, hipMemcpyAsync(c->w_tokens, tokens, (size_t)B * Tv * 4, hipMemcpyDeviceToDevice, s));
-    GraphKey key{1, B, Tv, 0, 0, 0, 0, 0};
-    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv); }))) return rc;
+    const bool masked = token_lengths != nullptr;
+    if (masked) HIPCHECK(c, hipMemcpyAsync(c->w_tok_len, token_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    GraphKey key{1, B, Tv, 0, 0, 0, 0, 0, masked};
+    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv, masked); }))) return rc;
     HIPCHECK(c, hipMemcpyAsync(enc, c->w_enc, (size_t)B * Tv * c->enc_out * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
@@ -981,7 +989,7 @@ int gsttaco_gst(gsttaco_ctx* c, const float* mels, const int32_t* lens, int B, i
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(c, hipMemcpyAsync(c->w_mels_in, mels, (size_t)B * Tref1 * c->cfg.mel_dim * 4, hipMemcpyDeviceToDevice, s));
     HIPCHECK(c, hipMemcpyAsync(c->w_mel_len, lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-    GraphKey key{2, B, 0, Tref1, 0, 0, 0, 0};
+    GraphKey key{2, B, 0, Tref1, 0, 0, 0, 0, 0};
     if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_gst(c, st, B, Tref1); }))) return rc;
     HIPCHECK(c, hipMemcpyAsync(gst, c->w_gst, (size_t)B * c->cfg.gst_att * 4, hipMemcpyDeviceToDevice, s));
     return 0;
@@ -997,8 +1005,9 @@ static int stage_randomness(gsttaco_ctx* c, hipStream_t s, const float* mask, co
     return 0;
 }
 
-int gsttaco_decode(gsttaco_ctx* c, const float* enc, const float* gst, const float* mask, const float* noise,
-                   uint64_t seed, int B, int Tv, int steps, float* pre_mel, float* stop, float* align, void* stream) {
+int gsttaco_decode(gsttaco_ctx* c, const float* enc, const float* gst, const int32_t* token_lengths, const float* mask,
+                   const float* noise, uint64_t seed, int B, int Tv, int steps, float* pre_mel, float* stop, float* align,
+                   void* stream) {
     int rc = check_ready(c);
     if (rc) return rc;
     if (!enc || !pre_mel || !stop || !align || (c->cfg.gst_use && !gst)) return fail(c, GSTTACO_E_INVALID, "null argument");
@@ -1009,10 +1018,12 @@ int gsttaco_decode(gsttaco_ctx* c, const float* enc, const float* gst, const flo
     if (c->cfg.gst_use)
         HIPCHECK(c, hipMemcpyAsync(c->w_gst, gst, (size_t)B * c->cfg.gst_att * 4, hipMemcpyDeviceToDevice, s));
     if ((rc = stage_randomness(c, s, mask, noise, seed, B, Tv, steps))) return rc;
-    GraphKey key{3, B, Tv, 0, steps, mask != nullptr, noise != nullptr, c->prof_every};
+    const bool masked = token_lengths != nullptr;
+    if (masked) HIPCHECK(c, hipMemcpyAsync(c->w_tok_len, token_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    GraphKey key{3, B, Tv, 0, steps, mask != nullptr, noise != nullptr, c->prof_every, masked};
     rc = run_cached(c, s, key, [&](hipStream_t st) {
         int r2 = enqueue_value_proj(c, st, B, Tv);
-        return r2 ? r2 : enqueue_decode(c, st, B, Tv, steps, mask != nullptr, noise != nullptr);
+        return r2 ? r2 : enqueue_decode(c, st, B, Tv, steps, mask != nullptr, noise != nullptr, masked);
     });
     if (rc) return rc;
     const size_t mel = c->cfg.mel_dim;
@@ -1031,13 +1042,13 @@ int gsttaco_postnet(gsttaco_ctx* c, const float* pre_mel, int B, int Tf, float* 
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)B * Tf * c->cfg.mel_dim;
     HIPCHECK(c, hipMemcpyAsync(c->w_pre, pre_mel, n * 4, hipMemcpyDeviceToDevice, s));
-    GraphKey key{4, B, 0, 0, Tf, 0, 0, 0};
+    GraphKey key{4, B, 0, 0, Tf, 0, 0, 0, 0};
     if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_postnet(c, st, B, Tf, c->w_pre, c->w_mel); }))) return rc;
     HIPCHECK(c, hipMemcpyAsync(mel, c->w_mel, n * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
-int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const float* mels_for_gst, const int32_t* mel_lengths,
+int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t* token_lengths, const float* mels_for_gst, const int32_t* mel_lengths,
                            const float* mask, const float* noise, uint64_t seed, int B, int Tv, int Tref1, int steps,
                            float* mel, float* stop, float* align, float* pre_mel, void* stream) {
     int rc = check_ready(c);
@@ -1057,12 +1068,14 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const float* m
         HIPCHECK(c, hipMemcpyAsync(c->w_mel_len, mel_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     }
     if ((rc = stage_randomness(c, s, mask, noise, seed, B, Tv, steps))) return rc;
-    GraphKey key{0, B, Tv, Tref1, steps, mask != nullptr, noise != nullptr, c->prof_every};
+    const bool masked = token_lengths != nullptr;
+    if (masked) HIPCHECK(c, hipMemcpyAsync(c->w_tok_len, token_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    GraphKey key{0, B, Tv, Tref1, steps, mask != nullptr, noise != nullptr, c->prof_every, masked};
     rc = run_cached(c, s, key, [&](hipStream_t st) {
-        int r2 = enqueue_encoder(c, st, B, Tv);
+        int r2 = enqueue_encoder(c, st, B, Tv, masked);
         if (!r2 && gst) r2 = enqueue_gst(c, st, B, Tref1);
         if (!r2) r2 = enqueue_value_proj(c, st, B, Tv);
-        if (!r2) r2 = enqueue_decode(c, st, B, Tv, steps, mask != nullptr, noise != nullptr);
+        if (!r2) r2 = enqueue_decode(c, st, B, Tv, steps, mask != nullptr, noise != nullptr, masked);
         if (!r2) r2 = enqueue_postnet(c, st, B, steps * c->r, c->w_pre, c->w_mel);
         return r2;
     });

@@ -43,6 +43,9 @@ struct SkinnyArgs {
     // EPI_PARTIAL writes / EPI_LSTM adds pre-activation partial sums, tile order [tile][MT*16 rows][16 cols]
     float* partial_out;
     const float* partial_in;
+    // masked-mode extension: EPI_LSTM rows whose time index t_index >= row_len[row] do not exist --
+    // h is written as 0 and the cell state is left untouched (NULL = the reference's unmasked behaviour)
+    const int32_t* row_len; int t_index;
     unsigned long long* dbg;   // diagnostic phase stamps (s_memrealtime, 100 MHz) of block 0, or NULL
 };
 
@@ -65,6 +68,7 @@ struct ConvGemmArgs {
     const float* shift;     // [N] or NULL (=0)
     const float* rowbias;   // [B, N] or NULL
     const float* res;       // [B*T, ldo] residual or NULL
+    const int32_t* row_len; // masked-mode extension (A12): input rows t >= row_len[b] read as zero, or NULL
     float* out;             // [B*T, ldo]
     int64_t ldo;
     int B, T, Cin, N, taps, pad_before, act;
@@ -86,6 +90,7 @@ struct AttnStepArgs {
     int B, Tv, A, type;                 // type: GSTTACO_ATT_*
     float sigmoid_noise;
     const uint64_t* seed_ptr; uint32_t rng_step;
+    const int32_t* tok_len;             // masked-mode extension (A12): positions >= tok_len[b] do not exist, or NULL
     int rows_lds;                       // rows of pm staged in LDS per chunk
 };
 
@@ -113,6 +118,7 @@ struct DecFrontArgs {
     int MT;
     int B, Tv, mel, P0, P1, A, type;
     float sigmoid_noise;
+    const int32_t* tok_len;    // masked-mode extension (A12): memory positions >= tok_len[b] do not exist, or NULL
     unsigned long long* dbg;   // diagnostic phase stamps of block 0, or NULL
     // Worker workgroups (blockIdx.x >= B) of the same launch: recurrent halves h_{t-1}.W_h + b of the two decode LSTM
     // layers, written as pre-activation partial sums.  They only need the PREVIOUS step's state, so they run on the

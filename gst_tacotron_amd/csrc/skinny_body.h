@@ -144,7 +144,11 @@ __device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int ti
             const int row = e >> 2, u = e & 3;
             const int grow = m0 + row;
             const int unit = tile * 4 + u;
-            if (grow < M && unit < A.N) {
+            if (grow < M && unit < A.N && A.row_len && A.t_index >= A.row_len[grow]) {
+                // masked mode: this time step does not exist for this utterance
+                if (A.out_blocked) A.h[gt_blk_off(grow, unit, MT)] = 0.f;
+                else A.h[(size_t)grow * A.ldh + unit] = 0.f;
+            } else if (grow < M && unit < A.N) {
                 const float gi = gt_sigmoid(zs[row][u]);
                 const float gf = gt_sigmoid(zs[row][4 + u]);
                 const float gg = gt_tanh(zs[row][8 + u]);

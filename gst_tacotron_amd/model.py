@@ -91,15 +91,24 @@ class GST_Tacotron:
     # ------------------------------------------------------------------ hot path
     def Inference_Step(self, tokens, token_lengths=None, initial_mels=None, mels_for_gst=None,
                        mel_lengths_for_gst=None, prenet_masks=None, attn_noise=None, seed=None,
-                       steps=None, return_pre_mel=False):
+                       steps=None, return_pre_mel=False, masked=False):
         """reference Model.py:249-255.  Returns (mel_Logits [B,S*r,mel], stop_Logits [B,S],
-        spectrogram_Logits (None), alignments [B,S,T_v]) as CUDA tensors on the current stream."""
+        spectrogram_Logits (None), alignments [B,S,T_v]) as CUDA tensors on the current stream.
+        ``masked=True`` (extension): honour ``token_lengths`` so each utterance of a ragged batch equals
+        that utterance run alone; the default ignores them like the reference does."""
         self._require_ready()
         d = self.dims
         tok = self._dev(tokens, torch.int32)
         if tok.dim() != 2:
             raise ValueError("tokens must be [batch, time]")
         B, Tv = tok.shape
+        tlen = None
+        if masked:
+            if token_lengths is None:
+                raise ValueError("masked=True needs token_lengths")
+            tlen = self._dev(token_lengths, torch.int32)
+            if tuple(tlen.shape) != (B,):
+                raise ValueError("token_lengths must be [batch]")
         mels = lens = None
         Tref1 = 0
         if d.gst:
@@ -126,7 +135,7 @@ class GST_Tacotron:
             seed = self.seed
         with torch.cuda.device(self.device):
             self.ctx.check(self.ctx.lib.gsttaco_inference_step(
-                self.ctx.handle, _ptr(tok), _ptr(mels), _ptr(lens), _ptr(masks), _ptr(noise),
+                self.ctx.handle, _ptr(tok), _ptr(tlen), _ptr(mels), _ptr(lens), _ptr(masks), _ptr(noise),
                 ctypes.c_uint64(int(seed)), B, Tv, Tref1, S, _ptr(mel), _ptr(stop), _ptr(align), _ptr(pre),
                 self._stream()))
         if return_pre_mel:
@@ -156,20 +165,22 @@ class GST_Tacotron:
         return self.Inference_Step(**pattern_Dict, **kwargs)
 
     # ------------------------------------------------------------------ per-phase entry points (tests / profiling)
-    def encode(self, tokens):
+    def encode(self, tokens, token_lengths=None):
         self._require_ready()
         tok = self._dev(tokens, torch.int32)
+        tlen = self._dev(token_lengths, torch.int32)
         B, Tv = tok.shape
         enc = torch.empty((B, Tv, self.dims.enc_out), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            self.ctx.check(self.ctx.lib.gsttaco_encode(self.ctx.handle, _ptr(tok), B, Tv, _ptr(enc), self._stream()))
+            self.ctx.check(self.ctx.lib.gsttaco_encode(self.ctx.handle, _ptr(tok), _ptr(tlen), B, Tv, _ptr(enc), self._stream()))
         return enc
 
-    def decode(self, enc, gst=None, prenet_masks=None, attn_noise=None, seed=0, steps=None):
+    def decode(self, enc, gst=None, prenet_masks=None, attn_noise=None, seed=0, steps=None, token_lengths=None):
         self._require_ready()
         d = self.dims
         enc = self._dev(enc, torch.float32)
         gst = self._dev(gst, torch.float32)
+        tlen = self._dev(token_lengths, torch.int32)
         B, Tv = enc.shape[0], enc.shape[1]
         S = d.steps if steps is None else int(steps)
         masks = self._dev(prenet_masks, torch.float32)
@@ -179,7 +190,7 @@ class GST_Tacotron:
         align = torch.empty((B, S, Tv), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             self.ctx.check(self.ctx.lib.gsttaco_decode(
-                self.ctx.handle, _ptr(enc), _ptr(gst), _ptr(masks), _ptr(noise), ctypes.c_uint64(int(seed)),
+                self.ctx.handle, _ptr(enc), _ptr(gst), _ptr(tlen), _ptr(masks), _ptr(noise), ctypes.c_uint64(int(seed)),
                 B, Tv, S, _ptr(pre), _ptr(stop), _ptr(align), self._stream()))
         return pre, stop, align
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 1
+#define GSTTACO_ABI_VERSION 2
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -116,8 +116,15 @@ int gsttaco_load_weight(gsttaco_ctx* ctx, const char* name, const float* host_da
 /* BN folding, MFMA-fragment repack, upload to HBM, workspace allocation. */
 int gsttaco_finalize_weights(gsttaco_ctx* ctx);
 
+/* Masked mode (EXTENSION): the reference has no padding masks -- `token_lengths` is accepted by
+ * Inference_Step and ignored (Model.py:249-253).  token_lengths == NULL reproduces that.  With a [B] int32
+ * device array the padded positions t >= token_lengths[b] are treated as non-existent (encoder convs see zeros there,
+ * the BiLSTM and the attention cover [0, length) only), so every utterance of a ragged batch equals that utterance
+ * run alone; encoder rows / alignment columns beyond the length are written as 0. */
+
 /* tokens [B,Tv] int32  ->  enc [B,Tv,2*enc_rnn] */
-int gsttaco_encode(gsttaco_ctx* ctx, const int32_t* tokens, int B, int Tv, float* enc, void* stream);
+int gsttaco_encode(gsttaco_ctx* ctx, const int32_t* tokens, const int32_t* token_lengths, int B, int Tv, float* enc,
+                   void* stream);
 
 /* mels_for_gst [B,Tref1,mel] (frame 0 = the prepended zero frame, dropped inside as GST.py:98 does),
  * mel_lengths [B] int32 (excluding that frame)  ->  gst [B,gst_att] */
@@ -129,7 +136,7 @@ int gsttaco_gst(gsttaco_ctx* ctx, const float* mels_for_gst, const int32_t* mel_
  * attn_noise : NULL (on-device Philox, `seed`) or N(0,1) samples [steps,B,Tv]
  * steps      : 0 = Max_Step // Step_Reduction, else 1..that
  * outputs    : pre_mel [B,steps*r,mel], stop [B,steps], align [B,steps,Tv] */
-int gsttaco_decode(gsttaco_ctx* ctx, const float* enc, const float* gst,
+int gsttaco_decode(gsttaco_ctx* ctx, const float* enc, const float* gst, const int32_t* token_lengths,
                    const float* prenet_mask, const float* attn_noise, uint64_t seed,
                    int B, int Tv, int steps, float* pre_mel, float* stop, float* align, void* stream);
 
@@ -139,7 +146,7 @@ int gsttaco_postnet(gsttaco_ctx* ctx, const float* pre_mel, int B, int T, float*
 /* The whole Inference_Step (Model.py:249-255) minus the CBHG vocoder: encoder, GST, decode loop,
  * postnet, replayed from one cached hipGraph per (B,Tv,Tref1,steps) shape.
  * mels_for_gst / mel_lengths are ignored (may be NULL) when GST is off; pre_mel may be NULL. */
-int gsttaco_inference_step(gsttaco_ctx* ctx, const int32_t* tokens,
+int gsttaco_inference_step(gsttaco_ctx* ctx, const int32_t* tokens, const int32_t* token_lengths,
                            const float* mels_for_gst, const int32_t* mel_lengths,
                            const float* prenet_mask, const float* attn_noise, uint64_t seed,
                            int B, int Tv, int Tref1, int steps,

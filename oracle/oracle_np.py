@@ -80,7 +80,10 @@ def lstm_cell(x, h, c, kernel, rec, bias):
     return o * np.tanh(c2), c2
 
 
-def lstm_sequence(x, kernel, rec, bias, reverse=False):
+def lstm_sequence(x, kernel, rec, bias, reverse=False, lengths=None):
+    """``lengths`` (masked-mode EXTENSION; the reference has no masks, F5): steps t >= lengths[b] do
+    not exist for utterance b -- state stays zero / frozen and the output row is zero, so the backward direction
+    starts at lengths[b]-1 with a zero state exactly as if the utterance were run alone."""
     B, T, _ = x.shape
     u = rec.shape[0]
     h = np.zeros((B, u), x.dtype)
@@ -88,7 +91,12 @@ def lstm_sequence(x, kernel, rec, bias, reverse=False):
     out = np.zeros((B, T, u), x.dtype)
     order = range(T - 1, -1, -1) if reverse else range(T)
     for t in order:
-        h, c = lstm_cell(x[:, t], h, c, kernel, rec, bias)
+        h2, c2 = lstm_cell(x[:, t], h, c, kernel, rec, bias)
+        if lengths is not None:
+            act = (t < np.asarray(lengths))[:, None]
+            h2 = np.where(act, h2, 0.0).astype(x.dtype)
+            c2 = np.where(act, c2, c).astype(x.dtype)
+        h, c = h2, c2
         out[:, t] = h       # backward outputs are stored back in forward time order (A.7)
     return out
 
@@ -116,17 +124,25 @@ def cast_weights(weights, dt):
 
 
 # ----------------------------------------------------------------------------- modules
-def encoder(hp, w, tokens, dt):
+def encoder(hp, w, tokens, dt, token_lengths=None):
     """Reference Modules/Taco2.py:12-51: Embedding -> 3x(Conv1D, BN, ReLU,
-    Dropout=identity at inference) -> Bidirectional LSTM, concat [fwd, bwd]."""
+    Dropout=identity at inference) -> Bidirectional LSTM, concat [fwd, bwd].
+    ``token_lengths`` switches on the masked-mode extension (A12): every conv sees zeros at t >= length (what
+    'same' padding would supply if the utterance were alone) and the BiLSTM covers [0, length) only."""
     x = w["encoder.embedding"][np.asarray(tokens)]
+    m = None
+    if token_lengths is not None:
+        m = (np.arange(x.shape[1])[None, :] < np.asarray(token_lengths)[:, None])[..., None].astype(x.dtype)
     n_conv = len(hp["Tacotron2"]["Encoder"]["Conv"]["Filters"])
     for i in range(n_conv):
+        if m is not None:
+            x = x * m
         x = conv1d_same(x, w[f"encoder.conv{i}.kernel"])
         x = np.maximum(batch_norm(x, w, f"encoder.conv{i}.bn"), 0)
     p = "encoder.bilstm."
-    fwd = lstm_sequence(x, w[p + "fwd.kernel"], w[p + "fwd.recurrent_kernel"], w[p + "fwd.bias"])
-    bwd = lstm_sequence(x, w[p + "bwd.kernel"], w[p + "bwd.recurrent_kernel"], w[p + "bwd.bias"], reverse=True)
+    fwd = lstm_sequence(x, w[p + "fwd.kernel"], w[p + "fwd.recurrent_kernel"], w[p + "fwd.bias"], lengths=token_lengths)
+    bwd = lstm_sequence(x, w[p + "bwd.kernel"], w[p + "bwd.recurrent_kernel"], w[p + "bwd.bias"], reverse=True,
+                        lengths=token_lengths)
     return np.concatenate([fwd, bwd], axis=-1).astype(dt)
 
 
@@ -192,8 +208,14 @@ def prenet(hp, w, x, masks):
     return x
 
 
-def monotonic_alignment(att_type, score, prev):
-    """SMA: reference Steps.py:222-229; BMA: Steps.py:171-180,183-199."""
+def monotonic_alignment(att_type, score, prev, lengths=None):
+    """SMA: reference Steps.py:222-229; BMA: Steps.py:171-180,183-199.
+    ``lengths`` (masked-mode extension A12): positions >= lengths[b] do not exist for utterance b."""
+    if lengths is not None:
+        out = np.zeros_like(prev)
+        for b, n in enumerate(np.asarray(lengths)):
+            out[b:b + 1, :n] = monotonic_alignment(att_type, score[b:b + 1, :n], prev[b:b + 1, :n])
+        return out
     p = sigmoid(score)
     if att_type == "SMA":
         shifted = np.zeros_like(prev)
@@ -206,7 +228,7 @@ def monotonic_alignment(att_type, score, prev):
     return p * cp * np.cumsum(prev / np.clip(cp, 1e-10, 1.0), axis=-1)
 
 
-def attention_step(hp, w, query_in, processed_memory, prev_align, noise):
+def attention_step(hp, w, query_in, processed_memory, prev_align, noise, lengths=None):
     """Reference Steps.py:107-166.  ``processed_memory`` is Dense_Value(memory)
     (loop-invariant, F7); the context is a weighted sum of the PROJECTED memory."""
     att = hp["Tacotron2"]["Decoder"]["Attention"]
@@ -216,7 +238,7 @@ def attention_step(hp, w, query_in, processed_memory, prev_align, noise):
     sn = att.get("Sigmoid_Noise", 2.0 if att["Type"] == "SMA" else 0.0)
     if sn > 0.0:
         score = score + score.dtype.type(sn) * noise                                            # :169-170 / :220-221
-    align = monotonic_alignment(att["Type"], score, prev_align)
+    align = monotonic_alignment(att["Type"], score, prev_align, lengths)
     ctx = np.einsum("bt,bta->ba", align, processed_memory)                                      # :164
     return ctx, align
 
@@ -225,7 +247,7 @@ def process_memory(w, memory):
     return memory @ w["decoder.attention.value.kernel"] + w["decoder.attention.value.bias"]     # Steps.py:123
 
 
-def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, return_states=False):
+def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, return_states=False, token_lengths=None):
     """Reference Taco2.py:153-228 (training=False branch).
     prenet_masks [steps, n_prenet, B, size] keep-masks; attn_noise [steps, B, T_v] ~ N(0,1)."""
     mel, r = int(hp["Sound"]["Mel_Dim"]), int(hp["Step_Reduction"])
@@ -246,7 +268,7 @@ def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, r
         masks = None if prenet_masks is None else prenet_masks[t]
         p = prenet(hp, w, frame, masks)                                      # Taco2.py:106
         noise = None if attn_noise is None else attn_noise[t]
-        ctx, align = attention_step(hp, w, p, pm, align, noise)              # Taco2.py:107-109
+        ctx, align = attention_step(hp, w, p, pm, align, noise, token_lengths)   # Taco2.py:107-109
         x = np.concatenate([p, ctx], -1)                                     # :110
         for i in range(len(sizes)):                                          # :111 StackedRNNCells
             hs[i], cs[i] = lstm_cell(x, hs[i], cs[i], w[f"decoder.lstm{i}.kernel"],
@@ -274,12 +296,12 @@ def postnet(hp, w, pre, dt):
 
 
 def inference_step(hp, weights, tokens, mels_for_gst=None, mel_lengths_for_gst=None,
-                   prenet_masks=None, attn_noise=None, steps=None, dt=np.float64):
+                   prenet_masks=None, attn_noise=None, steps=None, dt=np.float64, token_lengths=None):
     """Reference Model.py:249-255 with the wiring of Model.py:108-129,145-156.
     Returns (mels [B,S*r,mel] post-net, stops [B,S], None (vocoder out of scope), alignments [B,S,T_v])
     plus a dict of intermediates for per-module parity tests."""
     w = cast_weights(weights, dt)
-    enc = encoder(hp, w, tokens, dt)
+    enc = encoder(hp, w, tokens, dt, token_lengths)        # token_lengths=None: the reference's unmasked behaviour
     inter = {"encoder": enc}
     memory = enc
     if hp["GST"]["Use"]:
@@ -290,7 +312,7 @@ def inference_step(hp, weights, tokens, mels_for_gst=None, mel_lengths_for_gst=N
         prenet_masks = np.asarray(prenet_masks, dt)
     if attn_noise is not None:
         attn_noise = np.asarray(attn_noise, dt)
-    pre, stops, aligns = decoder(hp, w, memory, dt, prenet_masks, attn_noise, steps)
+    pre, stops, aligns = decoder(hp, w, memory, dt, prenet_masks, attn_noise, steps, token_lengths=token_lengths)
     inter["pre_mel"] = pre
     mels = postnet(hp, w, pre, dt)
     return mels, stops, None, aligns, inter

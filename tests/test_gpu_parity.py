@@ -181,3 +181,38 @@ def test_error_behaviour_on_gpu():
         m.Inference_Step(tokens, steps=2)
     with pytest.raises(capi.GstTacoError):
         m.Inference_Step(tokens, None, None, mels, ml, steps=10_000)
+
+
+@pytest.mark.parametrize("att", ["SMA", "BMA"])
+def test_masked_mode_ragged_batch(att):
+    """Masked-mode extension (BASELINE configs[2]): a ragged padded batch with token_lengths honoured matches
+    the masked oracle, and every utterance equals the same utterance decoded alone (unmasked, at its own length)."""
+    import torch
+    from oracle import oracle_np
+    B, Tv, Tref, steps = 5, 150, 80, 6
+    lens = np.array([150, 33, 128, 64, 97], np.int32)
+    hp, w, _, _, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=31, att=att, lens=np.array([80, 20, 64, 65, 33]))
+    from gst_tacotron_amd import synthetic
+    tokens, _ = synthetic.make_tokens(np.random.default_rng(32), B, Tv, lengths=lens)
+    m = _model(hp, w, B, Tv, Tref + 1)
+    mel, stop, _, align = m.Inference_Step(tokens, lens, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps,
+                                           masked=True)
+    torch.cuda.synchronize()
+    mel, align = mel.cpu().numpy(), align.cpu().numpy()
+    ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64, token_lengths=lens)
+    assert np.abs(mel - ref[0]).max() <= TOL and np.abs(align - ref[3]).max() <= TOL
+    enc = m.encode(tokens, lens).cpu().numpy()
+    assert np.abs(enc - ref[4]["encoder"]).max() <= TOL
+    for b in (1, 3):
+        n = int(lens[b])
+        assert not align[b][:, n:].any() and not enc[b, n:].any()
+        one = m.Inference_Step(tokens[b:b + 1, :n], None, None, mels[b:b + 1], ml[b:b + 1], prenet_masks=masks[:, :, b:b + 1],
+                               attn_noise=np.ascontiguousarray(noise[:, b:b + 1, :n]), steps=steps)
+        torch.cuda.synchronize()
+        assert np.abs(one[0].cpu().numpy()[0] - mel[b]).max() <= TOL
+        assert np.abs(one[3].cpu().numpy()[0] - align[b][:, :n]).max() <= TOL
+    # the default (reference behaviour) still ignores token_lengths
+    un = m.Inference_Step(tokens, lens, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps)
+    torch.cuda.synchronize()
+    ref_un = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
+    assert np.abs(un[0].cpu().numpy() - ref_un[0]).max() <= TOL

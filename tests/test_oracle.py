@@ -139,3 +139,26 @@ def test_fp32_noise_floor_is_far_below_the_bar():
     a = oracle_np.inference_step(hp, w, tok, mels, ml, masks, noise, steps=30, dt=np.float64)
     b = oracle_np.inference_step(hp, w, tok, mels, ml, masks, noise, steps=30, dt=np.float32)
     assert np.abs(a[0] - b[0]).max() < 2e-5
+
+
+@pytest.mark.parametrize("att", ["SMA", "BMA"])
+def test_masked_mode_extension_equals_running_each_utterance_alone(att):
+    """SURVEY A12 (an extension: the reference has no masks, F5): with token_lengths honoured, utterance b of a ragged
+    padded batch equals the same utterance run alone at its own length, and no alignment mass sits on the padding."""
+    hp = synthetic.tiny_hp(att_type=att, r=2, max_step=16)
+    w = weights.synthetic_weights(hp, 2)
+    rng = np.random.default_rng(3)
+    lens = np.array([11, 5, 8], np.int32)
+    tokens, _ = synthetic.make_tokens(rng, 3, 11, lengths=lens)
+    mels, ml = synthetic.make_ref_mels(rng, 3, 70, mel=16, lengths=np.array([70, 40, 64]))
+    masks, noise = synthetic.make_randomness(rng, 8, 3, 11, [32, 32])
+    full = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, dt=np.float64, token_lengths=lens)
+    unmasked = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, dt=np.float64)
+    assert np.abs(full[0][1] - unmasked[0][1]).max() > 1e-3          # padding does change the unmasked (reference) result
+    for b in range(3):
+        n = int(lens[b])
+        one = oracle_np.inference_step(hp, w, tokens[b:b + 1, :n], mels[b:b + 1], ml[b:b + 1], masks[:, :, b:b + 1],
+                                       noise[:, b:b + 1, :n], dt=np.float64)
+        np.testing.assert_allclose(one[0][0], full[0][b], atol=1e-12)
+        np.testing.assert_allclose(one[3][0], full[3][b][:, :n], atol=1e-12)
+        assert not full[3][b][:, n:].any() and not full[4]["encoder"][b, n:].any()
