@@ -18,8 +18,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsttaco.so")
 
 MAX_LAYERS = 8
-ABI_VERSION = 2
-ATT_CODES = {"BMA": 0, "SMA": 1}
+ABI_VERSION = 3
+ATT_CODES = {"BMA": 0, "SMA": 1, "LSA": 2}
 
 # every symbol include/gsttaco.h declares
 EXPORTED_SYMBOLS = (
@@ -41,6 +41,8 @@ class Config(ctypes.Structure):
         ("n_prenet", ctypes.c_int32), ("prenet", _I32A), ("prenet_rate", ctypes.c_float),
         ("n_dec_rnn", ctypes.c_int32), ("dec_rnn", _I32A),
         ("att_type", ctypes.c_int32), ("att_size", ctypes.c_int32), ("sigmoid_noise", ctypes.c_float),
+        ("loc_filters", ctypes.c_int32), ("loc_kernel", ctypes.c_int32), ("lsa_cumulate", ctypes.c_int32),
+        ("lsa_smoothing", ctypes.c_int32),
         ("n_post", ctypes.c_int32), ("post_filters", _I32A), ("post_kernels", _I32A), ("post_tanh", ctypes.c_int32),
         ("gst_use", ctypes.c_int32), ("n_ref_conv", ctypes.c_int32),
         ("ref_filters", _I32A), ("ref_kernels", _I32A), ("ref_strides", _I32A),
@@ -121,6 +123,8 @@ def make_config(hp, vocab=None, device=0, max_batch=32, max_tokens=256, max_ref_
     for i, s in enumerate(d.dec_rnn):
         c.dec_rnn[i] = s
     c.att_type, c.att_size, c.sigmoid_noise = ATT_CODES[d.att_type], d.att, d.sigmoid_noise
+    c.loc_filters, c.loc_kernel = d.loc_filters, d.loc_kernel
+    c.lsa_cumulate, c.lsa_smoothing = int(d.lsa_cumulate), int(d.lsa_smoothing)
     c.n_post = len(d.post_filters)
     for i, (f, k) in enumerate(zip(d.post_filters, d.post_kernels)):
         c.post_filters[i], c.post_kernels[i] = f, k

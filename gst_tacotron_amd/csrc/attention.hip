@@ -19,13 +19,15 @@
 
 #define ATT_THREADS 256
 
-size_t gt_attn_lds_bytes(int Tv, int A, int* rows_lds) {
+size_t gt_attn_lds_bytes(int Tv, int A, int loc_f, int loc_k, int* rows_lds) {
     int rows = Tv < 256 ? Tv : 256;
-    // keep the tile <= 128 KiB
-    while ((size_t)rows * (A + 1) * 4 > 128 * 1024 && rows > 16) rows /= 2;
+    // keep the tile (+ the LSA location features of its rows) <= 96 KiB
+    while ((size_t)rows * (A + 1 + loc_f) * 4 > 96 * 1024 && rows > 16) rows /= 2;
     if (rows_lds) *rows_lds = rows;
-    // tile + q + v + score/p + prev + align + partials
-    return ((size_t)rows * (A + 1) + 2 * (size_t)A + 3 * (size_t)Tv + 4 * 256 + 64) * sizeof(float);
+    // tile + q + v + score/p + prev + align + partials (+ LSA: location features, dense and conv weights, biases)
+    size_t fl = (size_t)rows * (A + 1) + 2 * (size_t)A + 3 * (size_t)Tv + 4 * 256 + 64;
+    if (loc_f > 0) fl += (size_t)rows * loc_f + (size_t)loc_f * A + (size_t)loc_k * loc_f + loc_f + 2 * (size_t)A;
+    return fl * sizeof(float);
 }
 
 __device__ __forceinline__ float wave_incl_scan(float x, int lane) {
@@ -50,6 +52,14 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
     float* pv = sc + TvFull;                         // [Tv] previous alignment
     float* al = pv + TvFull;                         // [Tv] new alignment
     float* partial = al + TvFull;                    // [4*256]
+    // LSA extension scratch
+    const bool lsa = P.type == GSTTACO_ATT_LSA;
+    const int LF = lsa ? P.loc_f : 0, LK = lsa ? P.loc_k : 0;
+    float* lfeat = partial + 4 * 256;                // [rows_lds][LF]  conv(state)+bias
+    float* ldw = lfeat + (size_t)rows_lds * LF;      // [LF][A]
+    float* lcw = ldw + (size_t)LF * A;               // [LK][LF]
+    float* lcb = lcw + (size_t)LK * LF;              // [LF]
+    float* labias = lcb + LF;                        // [A]  location-dense bias + additive bias
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -57,12 +67,21 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
 
     for (int a = tid; a < A; a += ATT_THREADS) {
         qs[a] = P.q[(size_t)b * P.ldq + a];
-        vs[a] = P.v[a];
+        vs[a] = P.type == GSTTACO_ATT_LSA ? 0.f : P.v[a];      // LSA has no attention_v (Layers.py:407)
     }
-    for (int t = tid; t < Tv; t += ATT_THREADS)
-        pv[t] = P.prev ? P.prev[(size_t)b * P.ldprev + t] : (t == 0 ? 1.f : 0.f);
+    for (int t = tid; t < Tv; t += ATT_THREADS) {
+        if (lsa) pv[t] = P.lsa_state[(size_t)b * TvFull + t];       // cumulative (or last) alignment, zeros at step 0
+        else pv[t] = P.prev ? P.prev[(size_t)b * P.ldprev + t] : (t == 0 ? 1.f : 0.f);
+    }
+    if (lsa) {
+        for (int i = tid; i < LF * A; i += ATT_THREADS) ldw[i] = P.loc_dw[i];
+        for (int i = tid; i < LK * LF; i += ATT_THREADS) lcw[i] = P.loc_cw[i];
+        for (int i = tid; i < LF; i += ATT_THREADS) lcb[i] = P.loc_cb[i];
+        for (int i = tid; i < A; i += ATT_THREADS) labias[i] = P.loc_db[i] + P.att_bias[i];
+    }
 
-    const float bias = P.score_bias[0];
+    const float bias = lsa ? 0.f : P.score_bias[0];
+    const int lpad = (LK - 1) / 2;                   // TF 'same', stride 1: before = (k-1)//2
     const int nchunks = (Tv + rows_lds - 1) / rows_lds;
     const int a4 = A >> 2;
 
@@ -88,12 +107,36 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
         __syncthreads();
         const int nr = stage(c);
         __syncthreads();
+        if (lsa) {
+            // location features of this chunk's rows: Conv1D(state) + bias  (Layers.py:362-363)
+            for (int i = tid; i < nr * LF; i += ATT_THREADS) {
+                const int rr = i / LF, f = i - rr * LF;
+                const int t = c * rows_lds + rr;
+                float acc = lcb[f];
+                for (int j = 0; j < LK; ++j) {
+                    const int ts = t + j - lpad;
+                    if (ts >= 0 && ts < Tv) acc += pv[ts] * lcw[j * LF + f];
+                }
+                lfeat[i] = acc;
+            }
+            __syncthreads();
+        }
         const int row = tid % RP, part = tid / RP;
         float s = 0.f;
         if (row < nr) {
             const float* tr = tile + row * LD;
             const int abeg = part * arange, aend = min(A, abeg + arange);
-            for (int a = abeg; a < aend; ++a) s += vs[a] * gt_tanh(qs[a] + tr[a]);
+            if (lsa) {
+                // score = sum_a tanh(q + key + Dense(loc) + bias)   (Layers.py:364, 407; no v vector, scale 1)
+                const float* lf = lfeat + (size_t)row * LF;
+                for (int a = abeg; a < aend; ++a) {
+                    float loc = labias[a];
+                    for (int f = 0; f < LF; ++f) loc += lf[f] * ldw[f * A + a];
+                    s += gt_tanh(qs[a] + tr[a] + loc);
+                }
+            } else {
+                for (int a = abeg; a < aend; ++a) s += vs[a] * gt_tanh(qs[a] + tr[a]);
+            }
         }
         partial[part * 256 + row] = s;
         __syncthreads();
@@ -105,6 +148,28 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
     }
     __syncthreads();
 
+    if (lsa) {
+        // softmax (or smoothing normalisation, Layers.py:426-444) over the Tv positions: one wave, serial chunk per lane
+        if (tid < 64) {
+            const int per = (Tv + 63) / 64;
+            const int t0 = tid * per, t1 = min(Tv, t0 + per);
+            float mx = -INFINITY;
+            for (int t = t0; t < t1; ++t) mx = fmaxf(mx, sc[t]);
+            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            float sum = 0.f;
+            for (int t = t0; t < t1; ++t) {
+                const float e = P.lsa_smoothing ? 1.f / (1.f + expf(-sc[t])) : expf(sc[t] - mx);
+                al[t] = e;
+                sum += e;
+            }
+            for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            const float inv = 1.f / sum;
+            for (int t = t0; t < t1; ++t) {
+                al[t] *= inv;
+                P.lsa_state[(size_t)b * TvFull + t] = P.lsa_cumulate ? pv[t] + al[t] : al[t];
+            }
+        }
+    } else {
     // ---- noise + sigmoid
     for (int t = tid; t < Tv; t += ATT_THREADS) {
         float s = sc[t];
@@ -153,6 +218,7 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
             }
         }
     }
+    }   // !lsa
     __syncthreads();
     for (int t = tid; t < TvFull; t += ATT_THREADS) P.align[(size_t)b * P.ldalign + t] = t < Tv ? al[t] : 0.f;
 
@@ -218,7 +284,7 @@ hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream) 
 hipError_t gt_launch_attn_step(const AttnStepArgs& a, hipStream_t stream) {
     if (a.A > 256 || (a.A & 3)) return hipErrorInvalidValue;
     int rows;
-    size_t lds = gt_attn_lds_bytes(a.Tv, a.A, &rows);
+    size_t lds = gt_attn_lds_bytes(a.Tv, a.A, a.type == GSTTACO_ATT_LSA ? a.loc_f : 0, a.type == GSTTACO_ATT_LSA ? a.loc_k : 0, &rows);
     AttnStepArgs p = a;
     p.rows_lds = rows;
     hipLaunchKernelGGL(gt_attn_step_kernel, dim3(a.B), dim3(ATT_THREADS), lds, stream, p);

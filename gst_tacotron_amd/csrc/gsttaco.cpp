@@ -91,6 +91,8 @@ struct gsttaco_ctx {
     float *pw0 = nullptr, *pb0 = nullptr, *pw1 = nullptr, *pb1 = nullptr, *pwq = nullptr, *pbq = nullptr;  // plain layouts (fused front)
     bool fused_front = true;
     float *val_enc_w = nullptr, *val_bias = nullptr, *att_v = nullptr, *att_sb = nullptr;
+    float *loc_cw = nullptr, *loc_cb = nullptr, *loc_dw = nullptr, *loc_db = nullptr, *att_bias = nullptr;   // LSA extension
+    float* w_lsa_state = nullptr;
 
     // workspace
     int32_t *w_tokens = nullptr, *w_mel_len = nullptr, *w_tok_len = nullptr;
@@ -196,8 +198,16 @@ void build_manifest(gsttaco_ctx* c) {
     add_tensor(c, "decoder.attention.query.bias", {g.att_size});
     add_tensor(c, "decoder.attention.value.kernel", {c->mem_dim, g.att_size});
     add_tensor(c, "decoder.attention.value.bias", {g.att_size});
-    add_tensor(c, "decoder.attention.v", {g.att_size});
-    add_tensor(c, "decoder.attention.score_bias", {});
+    if (g.att_type == GSTTACO_ATT_LSA) {      // extension A13 (reference Layers.py:310-321, 335-341)
+        add_tensor(c, "decoder.attention.location_conv.kernel", {g.loc_kernel, 1, g.loc_filters});
+        add_tensor(c, "decoder.attention.location_conv.bias", {g.loc_filters});
+        add_tensor(c, "decoder.attention.location_dense.kernel", {g.loc_filters, g.att_size});
+        add_tensor(c, "decoder.attention.location_dense.bias", {g.att_size});
+        add_tensor(c, "decoder.attention.bias", {g.att_size});
+    } else {
+        add_tensor(c, "decoder.attention.v", {g.att_size});
+        add_tensor(c, "decoder.attention.score_bias", {});
+    }
     cin = cin + g.att_size;
     for (int i = 0; i < g.n_dec_rnn; ++i) {
         std::string p = "decoder.lstm" + std::to_string(i);
@@ -452,6 +462,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     HIPCHECK(c, gt_launch_zero(c->w_h2[1], (size_t)MT * 16 * H2, s));
     HIPCHECK(c, gt_launch_zero(c->w_c1, (size_t)B * H1, s));
     HIPCHECK(c, gt_launch_zero(c->w_c2, (size_t)B * H2, s));
+    if (g.att_type == GSTTACO_ATT_LSA) HIPCHECK(c, gt_launch_zero(c->w_lsa_state, (size_t)B * Tv, s));   // Layers.py:356
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
     int nprof[5] = {0, 0, 0, 0, 0};
@@ -479,7 +490,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         const float* mask0 = has_mask ? c->w_masks + (size_t)t * mask_step : nullptr;
         const float* mask1 = has_mask ? c->w_masks + (size_t)t * mask_step + (size_t)B * P0 : nullptr;
         const bool prof = c->prof_every > 0 && (t % c->prof_every) == 0;
-        const bool fused = c->fused_front && gt_dec_front_supported(mel, P0, P1, att, Tv);
+        // the fused front end implements BMA/SMA; the LSA extension runs on the four-kernel path
+        const bool fused = c->fused_front && g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv);
         const bool split = fused && c->split_rec;
         if (fused) {
             // 1-4 fused: prenet x2, query projection, score / alignment / context (dec_front.hip)
@@ -552,6 +564,9 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         a.ctx = c->w_xa + (size_t)(P1 / 16) * BLK; a.ldctx = 0; a.ctx_mt = MT;
         a.B = B; a.Tv = Tv; a.A = att; a.type = g.att_type; a.sigmoid_noise = g.sigmoid_noise;
         a.seed_ptr = c->w_seed; a.rng_step = (uint32_t)t; a.tok_len = tlen;
+        a.loc_cw = c->loc_cw; a.loc_cb = c->loc_cb; a.loc_dw = c->loc_dw; a.loc_db = c->loc_db; a.att_bias = c->att_bias;
+        a.lsa_state = c->w_lsa_state; a.loc_k = g.loc_kernel; a.loc_f = g.loc_filters;
+        a.lsa_cumulate = g.lsa_cumulate; a.lsa_smoothing = g.lsa_smoothing;
         HIPCHECK(c, gt_launch_attn_step(a, s));
         }
         // 5/6. the two LSTM cells (StackedRNNCells, Taco2.py:111)
@@ -708,8 +723,10 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     if (g.n_dec_rnn != 2) return bad("Decoder.RNN.Size must have exactly 2 layers");
     if (g.dec_rnn[0] % 16 || g.dec_rnn[1] % 16 || g.dec_rnn[0] < 16 || g.dec_rnn[1] < 16)
         return bad("Decoder.RNN sizes must be multiples of 16");
-    if (g.att_type != GSTTACO_ATT_BMA && g.att_type != GSTTACO_ATT_SMA)
+    if (g.att_type != GSTTACO_ATT_BMA && g.att_type != GSTTACO_ATT_SMA && g.att_type != GSTTACO_ATT_LSA)
         return bad("Unsupported attention type");            // reference Taco2.py:74-75
+    if (g.att_type == GSTTACO_ATT_LSA && (g.loc_filters < 1 || g.loc_filters > 128 || g.loc_kernel < 1 || g.loc_kernel > 255))
+        return bad("LSA: Attention.Conv.Filters must be 1..128 and Kernel_Size 1..255");
     if (g.att_size < 16 || g.att_size % 16 || g.att_size > 256) return bad("Attention.Size must be a multiple of 16, <= 256");
     if (g.n_post < 1 || g.n_post > GSTTACO_MAX_LAYERS) return bad("bad postnet layer count");
     for (int i = 0; i < g.n_post; ++i)
@@ -876,10 +893,22 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
             if ((rc = pack_linear(c, &c->val_gst, {{vk.data.data(), g.gst_att}}, c->att, vb.data.data(), 0))) return rc;
         if ((rc = upload(c, &c->val_enc_w, vk.data.data() + (size_t)goff * c->att, (size_t)c->enc_out * c->att))) return rc;
         if ((rc = upload(c, &c->val_bias, vb.data.data(), vb.data.size()))) return rc;
-        const HostTensor& av = T(c, "decoder.attention.v");
-        if ((rc = upload(c, &c->att_v, av.data.data(), av.data.size()))) return rc;
-        const HostTensor& sb = T(c, "decoder.attention.score_bias");
-        if ((rc = upload(c, &c->att_sb, sb.data.data(), 1))) return rc;
+        if (g.att_type == GSTTACO_ATT_LSA) {
+            auto up = [&](float** dst, const char* name) {
+                const HostTensor& t = T(c, name);
+                return upload(c, dst, t.data.data(), t.data.size());
+            };
+            if ((rc = up(&c->loc_cw, "decoder.attention.location_conv.kernel"))) return rc;
+            if ((rc = up(&c->loc_cb, "decoder.attention.location_conv.bias"))) return rc;
+            if ((rc = up(&c->loc_dw, "decoder.attention.location_dense.kernel"))) return rc;
+            if ((rc = up(&c->loc_db, "decoder.attention.location_dense.bias"))) return rc;
+            if ((rc = up(&c->att_bias, "decoder.attention.bias"))) return rc;
+        } else {
+            const HostTensor& av = T(c, "decoder.attention.v");
+            if ((rc = upload(c, &c->att_v, av.data.data(), av.data.size()))) return rc;
+            const HostTensor& sb = T(c, "decoder.attention.score_bias");
+            if ((rc = upload(c, &c->att_sb, sb.data.data(), 1))) return rc;
+        }
         for (int l = 0; l < 2; ++l) {
             std::string p = "decoder.lstm" + std::to_string(l);
             const HostTensor &k = T(c, p + ".kernel"), &u = T(c, p + ".recurrent_kernel"), &b = T(c, p + ".bias");
@@ -934,6 +963,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         if ((rc = fa(&c->w_rowbias, B * c->att))) return rc;
     }
     if ((rc = fa(&c->w_pm, B * Tv * c->att))) return rc;
+    if ((rc = fa(&c->w_lsa_state, B * Tv))) return rc;
     if ((rc = fa(&c->w_p1, B * c->P0))) return rc;
     const size_t Bp = (B + 15) / 16 * 16;       // blocked activation buffers hold whole 16-row tiles
     if ((rc = fa(&c->w_xa, Bp * (c->P1 + c->att)))) return rc;

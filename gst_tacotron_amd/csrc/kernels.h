@@ -91,6 +91,11 @@ struct AttnStepArgs {
     float sigmoid_noise;
     const uint64_t* seed_ptr; uint32_t rng_step;
     const int32_t* tok_len;             // masked-mode extension (A12): positions >= tok_len[b] do not exist, or NULL
+    // LSA extension (type == GSTTACO_ATT_LSA): location conv [k,1,F] + bias [F], location dense [F,A] + bias [A],
+    // additive bias [A]; state [B,Tv] = cumulative (or last) alignment, read and updated in place
+    const float *loc_cw, *loc_cb, *loc_dw, *loc_db, *att_bias;
+    float* lsa_state;
+    int loc_k, loc_f, lsa_cumulate, lsa_smoothing;
     int rows_lds;                       // rows of pm staged in LDS per chunk
 };
 
@@ -98,7 +103,7 @@ hipError_t gt_launch_attn_step(const AttnStepArgs& a, hipStream_t stream);
 hipError_t gt_attn_init();     // opt in to >64 KiB dynamic LDS; call once outside stream capture
 hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream);
 hipError_t gt_launch_zero(float* p, size_t n_floats, hipStream_t stream);   // n rounded up to a multiple of 4 floats
-size_t gt_attn_lds_bytes(int Tv, int A, int* rows_lds);
+size_t gt_attn_lds_bytes(int Tv, int A, int loc_f, int loc_k, int* rows_lds);
 
 // ---------------------------------------------------------------- dec_front.hip
 struct DecFrontArgs {

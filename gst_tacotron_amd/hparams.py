@@ -17,7 +17,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_HP_PATH = os.path.join(_HERE, "Hyper_Parameters.json")
 DEFAULT_TOKEN_PATH = os.path.join(_HERE, "Token_Index_Dict.ENG.json")
 
-ATTENTION_TYPES = ("BMA", "SMA")  # reference Taco2.py:66-75 accepts exactly these
+# reference Taco2.py:66-75 accepts exactly "BMA"/"SMA".  "LSA" is an EXTENSION: north_star names a
+# location-sensitive attention, which the reference only has as a whole-sequence Keras layer
+# (Modules/Attention/Layers.py:289-444) that its decoder cannot select; it is restated step-wise here.
+ATTENTION_TYPES = ("BMA", "SMA", "LSA")
 
 
 def load_hp(source=None):
@@ -45,6 +48,8 @@ def load_token_dict(hp=None, base_dir=None):
 
 def attention_sigmoid_noise(hp):
     att = hp["Tacotron2"]["Decoder"]["Attention"]
+    if att["Type"] == "LSA":
+        return 0.0
     if "Sigmoid_Noise" in att:
         return float(att["Sigmoid_Noise"])
     return 2.0 if att["Type"] == "SMA" else 0.0
@@ -77,6 +82,12 @@ class Dims:
             raise ValueError("Unsupported attention type: {}".format(self.att_type))
         self.att = int(dec["Attention"]["Size"])
         self.sigmoid_noise = attention_sigmoid_noise(hp)
+        # LSA extension hyper-parameters (new, additive keys: Attention.Conv.{Filters,Kernel_Size}, Cumulate_Weights, Smoothing)
+        conv = dec["Attention"].get("Conv", {})
+        self.loc_filters = int(conv.get("Filters", 32))
+        self.loc_kernel = int(conv.get("Kernel_Size", 31))
+        self.lsa_cumulate = bool(dec["Attention"].get("Cumulate_Weights", True))   # Layers.py:302
+        self.lsa_smoothing = bool(dec["Attention"].get("Smoothing", False))        # Layers.py:300
         self.post_filters = [int(x) for x in dec["Conv"]["Filters"]] + [self.mel]  # Taco2.py:133
         self.post_kernels = [int(x) for x in dec["Conv"]["Kernel_Size"]] + [5]     # Taco2.py:134
         self.post_tanh = len(dec["Conv"]["Filters"]) - 1                           # Taco2.py:145 (F9)

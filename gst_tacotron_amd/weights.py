@@ -60,8 +60,15 @@ def manifest(hp, vocab=None):
     m["decoder.attention.query.bias"] = (d.att,)
     m["decoder.attention.value.kernel"] = (d.mem, d.att)
     m["decoder.attention.value.bias"] = (d.att,)
-    m["decoder.attention.v"] = (d.att,)
-    m["decoder.attention.score_bias"] = ()
+    if d.att_type == "LSA":     # extension A13: Layers.py:310-321, 335-341
+        m["decoder.attention.location_conv.kernel"] = (d.loc_kernel, 1, d.loc_filters)
+        m["decoder.attention.location_conv.bias"] = (d.loc_filters,)
+        m["decoder.attention.location_dense.kernel"] = (d.loc_filters, d.att)
+        m["decoder.attention.location_dense.bias"] = (d.att,)
+        m["decoder.attention.bias"] = (d.att,)
+    else:
+        m["decoder.attention.v"] = (d.att,)
+        m["decoder.attention.score_bias"] = ()
     cin = d.prenet[-1] + d.att
     for i, s in enumerate(d.dec_rnn):
         m[f"decoder.lstm{i}.kernel"] = (cin, 4 * s)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 2
+#define GSTTACO_ABI_VERSION 3
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -49,7 +49,9 @@ enum {
     GSTTACO_E_CAPACITY = -5     /* batch / tokens / frames exceed the capacity given at create */
 };
 
-enum { GSTTACO_ATT_BMA = 0, GSTTACO_ATT_SMA = 1 };   /* reference Taco2.py:66-75 */
+/* BMA / SMA: reference Taco2.py:66-75.  LSA: EXTENSION -- step-wise restatement of LocationSensitiveAttention
+ * (reference Modules/Attention/Layers.py:289-444), which the reference decoder cannot select. */
+enum { GSTTACO_ATT_BMA = 0, GSTTACO_ATT_SMA = 1, GSTTACO_ATT_LSA = 2 };
 
 /* Mirrors the hot-path keys of Hyper_Parameters.json (reference file of that name). */
 typedef struct gsttaco_config {
@@ -75,6 +77,10 @@ typedef struct gsttaco_config {
     int32_t att_type;           /* GSTTACO_ATT_* */
     int32_t att_size;           /* Attention.Size */
     float   sigmoid_noise;      /* SMA 2.0 (Steps.py:212), BMA 0.0 (Steps.py:58) */
+    int32_t loc_filters;        /* LSA only: Attention.Conv.Filters      (Layers.py:314-319) */
+    int32_t loc_kernel;         /* LSA only: Attention.Conv.Kernel_Size */
+    int32_t lsa_cumulate;       /* LSA only: cumulate_weights (Layers.py:302, default 1) */
+    int32_t lsa_smoothing;      /* LSA only: smoothing normalisation instead of softmax (Layers.py:300, 426-444) */
     int32_t n_post;             /* len(Decoder.Conv.Filters)+1 */
     int32_t post_filters[GSTTACO_MAX_LAYERS];
     int32_t post_kernels[GSTTACO_MAX_LAYERS];

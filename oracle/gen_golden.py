@@ -72,6 +72,10 @@ def main():
     make_case("tiny_sma_r1_nogst", synthetic.tiny_hp("SMA", r=1, gst=False, max_step=16), 5, 7, B=5, Tv=9, Tref=0)
     make_case("tiny_bma_r3_nodrop", synthetic.tiny_hp("BMA", r=3, gst=True, max_step=18, prenet_rate=0.0), 6, 8,
               B=2, Tv=17, Tref=64)
+    # extension A13: step-wise location-sensitive attention (softmax and smoothing variants)
+    lsa = synthetic.tiny_hp("SMA", r=2, gst=True, max_step=16)
+    lsa["Tacotron2"]["Decoder"]["Attention"] = {"Type": "LSA", "Size": 16, "Conv": {"Filters": 8, "Kernel_Size": 7}}
+    make_case("tiny_lsa_r2_gst", lsa, 9, 4, B=3, Tv=13, Tref=70)
     # (iii) full-dims short trajectory (LJSpeech hparams): B=2, T_v=16, 20 steps, r=2
     hp = synthetic.config_hp("cfg2")
     make_case("full_sma_r2_short", hp, 0, 11, B=2, Tv=16, Tref=96, ref_lengths=np.array([96, 50]), steps=20)

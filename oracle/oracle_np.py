@@ -228,6 +228,29 @@ def monotonic_alignment(att_type, score, prev, lengths=None):
     return p * cp * np.cumsum(prev / np.clip(cp, 1e-10, 1.0), axis=-1)
 
 
+def lsa_step(hp, w, query_in, processed_memory, state, lengths=None):
+    """EXTENSION: one step of LocationSensitiveAttention restated from the whole-sequence layer
+    reference Modules/Attention/Layers.py:345-424 (the reference decoder cannot select it, Taco2.py:66-75).
+    ``state`` is what Layers.py:361 feeds the location conv: the SUM of all previous alignments when
+    cumulate_weights (default True, zeros before the first step, :356) or the last alignment otherwise."""
+    att = hp["Tacotron2"]["Decoder"]["Attention"]
+    q = query_in @ w["decoder.attention.query.kernel"] + w["decoder.attention.query.bias"]       # :351
+    loc = conv1d_same(state[:, :, None], w["decoder.attention.location_conv.kernel"]) \
+        + w["decoder.attention.location_conv.bias"]                                               # :362-363 (Conv1D has a bias)
+    loc = loc @ w["decoder.attention.location_dense.kernel"] + w["decoder.attention.location_dense.bias"]   # :364
+    score = np.tanh(q[:, None, :] + processed_memory + loc + w["decoder.attention.bias"]).sum(-1)  # :407 (scale = 1)
+    if lengths is not None:
+        score = np.where(np.arange(score.shape[1])[None, :] < np.asarray(lengths)[:, None], score, -np.inf)
+    if att.get("Smoothing", False):
+        sg = sigmoid(score)                                                                       # :426-444
+        align = sg / sg.sum(-1, keepdims=True)
+    else:
+        align = softmax(score)                                                                    # :419-420
+    ctx = np.einsum("bt,bta->ba", align, processed_memory)                                        # :421
+    new_state = state + align if att.get("Cumulate_Weights", True) else align
+    return ctx, align, new_state
+
+
 def attention_step(hp, w, query_in, processed_memory, prev_align, noise, lengths=None):
     """Reference Steps.py:107-166.  ``processed_memory`` is Dense_Value(memory)
     (loop-invariant, F7); the context is a weighted sum of the PROJECTED memory."""
@@ -259,8 +282,11 @@ def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, r
     hs = [np.zeros((B, s), dt) for s in sizes]
     cs = [np.zeros((B, s), dt) for s in sizes]
     frame = np.zeros((B, mel), dt)                                           # Taco2.py:162-165
+    is_lsa = hp["Tacotron2"]["Decoder"]["Attention"]["Type"] == "LSA"
     align = np.zeros((B, Tv), dt)
-    align[:, 0] = 1.0                                                        # Steps.py:201-206
+    if not is_lsa:
+        align[:, 0] = 1.0                                                    # Steps.py:201-206
+    lsa_state = np.zeros((B, Tv), dt)                                        # Layers.py:356
     pre = np.zeros((B, steps * r, mel), dt)
     stops = np.zeros((B, steps), dt)
     aligns = np.zeros((B, steps, Tv), dt)
@@ -268,7 +294,14 @@ def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, r
         masks = None if prenet_masks is None else prenet_masks[t]
         p = prenet(hp, w, frame, masks)                                      # Taco2.py:106
         noise = None if attn_noise is None else attn_noise[t]
-        ctx, align = attention_step(hp, w, p, pm, align, noise, token_lengths)   # Taco2.py:107-109
+        if is_lsa:
+            if token_lengths is not None:       # processed memory beyond the length is irrelevant (align = 0 there)
+                lsa_in = lsa_state * (np.arange(Tv)[None, :] < np.asarray(token_lengths)[:, None])
+            else:
+                lsa_in = lsa_state
+            ctx, align, lsa_state = lsa_step(hp, w, p, pm, lsa_in, token_lengths)
+        else:
+            ctx, align = attention_step(hp, w, p, pm, align, noise, token_lengths)   # Taco2.py:107-109
         x = np.concatenate([p, ctx], -1)                                     # :110
         for i in range(len(sizes)):                                          # :111 StackedRNNCells
             hs[i], cs[i] = lstm_cell(x, hs[i], cs[i], w[f"decoder.lstm{i}.kernel"],

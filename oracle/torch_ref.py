@@ -155,6 +155,29 @@ class TorchReference:
         att = hp["Tacotron2"]["Decoder"]["Attention"]
         q = x @ w["decoder.attention.query.kernel"] + w["decoder.attention.query.bias"]
         value = memory @ w["decoder.attention.value.kernel"] + w["decoder.attention.value.bias"]   # every step (F7)
+        if att["Type"] == "LSA":        # extension A13, restated from Layers.py:345-424 with torch's own conv1d
+            state = prev_align          # cumulative (or last) alignment
+            k = w["decoder.attention.location_conv.kernel"]
+            pb, pa = _same_pad(state.shape[1], k.shape[0], 1)
+            loc = F.conv1d(F.pad(state.unsqueeze(1), (pb, pa)), k.permute(2, 1, 0).contiguous(),
+                           w["decoder.attention.location_conv.bias"]).transpose(1, 2)
+            loc = loc @ w["decoder.attention.location_dense.kernel"] + w["decoder.attention.location_dense.bias"]
+            score = torch.tanh(q.unsqueeze(1) + value + loc + w["decoder.attention.bias"]).sum(-1)
+            if att.get("Smoothing", False):
+                sg = torch.sigmoid(score)
+                align = sg / sg.sum(-1, keepdim=True)
+            else:
+                align = torch.softmax(score, dim=-1)
+            ctx = (align.unsqueeze(1) @ value).squeeze(1)
+            new_state = state + align if att.get("Cumulate_Weights", True) else align
+            y = torch.cat([x, ctx], dim=-1)
+            new_states = []
+            for i in range(len(hp["Tacotron2"]["Decoder"]["RNN"]["Size"])):
+                h, c = self._lstm_cell(y, states[i][0], states[i][1], f"decoder.lstm{i}")
+                new_states.append((h, c))
+                y = h
+            y = torch.cat([y, ctx], dim=-1) @ w["decoder.projection.kernel"] + w["decoder.projection.bias"]
+            return y[:, :-1], y[:, -1:], (align, new_state), new_states
         score = torch.sum(w["decoder.attention.v"] * torch.tanh(q.unsqueeze(1) + value), dim=-1) \
             + w["decoder.attention.score_bias"]
         sn = att.get("Sigmoid_Noise", 2.0 if att["Type"] == "SMA" else 0.0)
@@ -188,13 +211,18 @@ class TorchReference:
         B, Tv, _ = memory.shape
         decodings = torch.zeros(B, 1, mel, dtype=self.dt)
         stops = torch.zeros(B, 0, dtype=self.dt)
+        is_lsa = hp["Tacotron2"]["Decoder"]["Attention"]["Type"] == "LSA"
         alignments = F.one_hot(torch.zeros(B, dtype=torch.long), Tv).to(self.dt).unsqueeze(1)
+        lsa_state = torch.zeros(B, Tv, dtype=self.dt)
         states = [(torch.zeros(B, s, dtype=self.dt), torch.zeros(B, s, dtype=self.dt))
                   for s in hp["Tacotron2"]["Decoder"]["RNN"]["Size"]]
         for t in range(steps):
             masks = None if prenet_masks is None else prenet_masks[t]
             noise = None if attn_noise is None else attn_noise[t]
-            dec, stop, align, states = self.decoder_step(memory, decodings[:, -1], alignments[:, -1], states, masks, noise)
+            if is_lsa:
+                dec, stop, (align, lsa_state), states = self.decoder_step(memory, decodings[:, -1], lsa_state, states, masks, noise)
+            else:
+                dec, stop, align, states = self.decoder_step(memory, decodings[:, -1], alignments[:, -1], states, masks, noise)
             decodings = torch.cat([decodings, dec.reshape(B, r, mel)], dim=1)
             stops = torch.cat([stops, stop], dim=-1)
             alignments = torch.cat([alignments, align.unsqueeze(1)], dim=1)

@@ -10,7 +10,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-GOLDEN_CASES = ["tiny_sma_r2_gst", "tiny_bma_r1_gst", "tiny_sma_r1_nogst", "tiny_bma_r3_nodrop",
+GOLDEN_CASES = ["tiny_sma_r2_gst", "tiny_bma_r1_gst", "tiny_sma_r1_nogst", "tiny_bma_r3_nodrop", "tiny_lsa_r2_gst",
                 "full_sma_r2_short", "full_cfg1_short"]
 
 

@@ -41,7 +41,9 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_c_manifest_matches_python_manifest(lib):
-    for hp in (hparams.load_hp(), synthetic.tiny_hp(gst=False), synthetic.config_hp("cfg2")):
+    lsa = synthetic.tiny_hp()
+    lsa["Tacotron2"]["Decoder"]["Attention"] = {"Type": "LSA", "Size": 16, "Conv": {"Filters": 8, "Kernel_Size": 7}}
+    for hp in (hparams.load_hp(), synthetic.tiny_hp(gst=False), synthetic.config_hp("cfg2"), lsa):
         ctx = capi.Context(hp, max_batch=2, max_tokens=8, max_ref_frames=9)
         assert list(ctx.manifest().items()) == [(k, tuple(v)) for k, v in weights.manifest(hp).items()]
         ctx.close()
@@ -65,8 +67,8 @@ def test_create_rejects_bad_configs(lib):
     cfg.mel_dim = 81
     assert lib.gsttaco_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     bad = hparams.load_hp()
-    bad["Tacotron2"]["Decoder"]["Attention"]["Type"] = "LSA"
-    with pytest.raises(ValueError, match="Unsupported attention type: LSA"):
+    bad["Tacotron2"]["Decoder"]["Attention"]["Type"] = "DCA"
+    with pytest.raises(ValueError, match="Unsupported attention type: DCA"):
         hparams.Dims(bad)
 
 
