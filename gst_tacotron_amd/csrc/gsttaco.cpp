@@ -481,7 +481,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         return rce;
     };
     // layer-2 recurrent tiles co-scheduled with the (11-workgroup) projection kernel: one tile per otherwise idle CU
-    const int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, 256 - c->proj.ntiles));
+    int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, 192));      // measured: 192 <= 245 <= 128 (flat optimum)
+    if (const char* ec = getenv("GSTTACO_CO_TILES")) co_tiles = std::max(0, std::min(co_tiles, atoi(ec)));
     for (int t = 0; t < steps; ++t) {
         const int p = t & 1;
         SkinnyArgs k;
@@ -772,6 +773,7 @@ void gsttaco_destroy(gsttaco_ctx* c) {
         for (auto e : c->prof_ev[l]) (void)hipEventDestroy(e);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
 
+
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -817,6 +819,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     if (!strstr(prop.gcnArchName, "gfx950"))
         return fail(c, GSTTACO_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     HIPCHECK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+
 
     int rc = 0;
     // ---- encoder
