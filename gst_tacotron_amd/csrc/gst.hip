@@ -12,19 +12,20 @@
 #include "device_utils.h"
 #include "kernels.h"
 
-// one thread per (b, ho, wo-pair?, co): co fastest so weight reads and output writes coalesce and the
-// input pixel is a wave-wide broadcast.
+// One thread per (b, ho, wo, 4 consecutive output channels): the input pixel is a wave-wide broadcast load, the
+// weights one coalesced 16-byte load per (tap, ci) shared by 4 FMAs.  Cout % 4 == 0 (checked on the host side).
 __global__ __launch_bounds__(256) void gt_conv2d_bn_relu_kernel(Conv2dArgs P) {
-    const int64_t total = (int64_t)P.B * P.Ho * P.Wo * P.Cout;
+    const int C4 = P.Cout >> 2;
+    const int64_t total = (int64_t)P.B * P.Ho * P.Wo * C4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int co = idx % P.Cout;
-        int64_t rest = idx / P.Cout;
+        const int c4 = idx % C4;
+        int64_t rest = idx / C4;
         const int wo = rest % P.Wo; rest /= P.Wo;
         const int ho = rest % P.Ho;
         const int b = rest / P.Ho;
         const float* xb = P.x + (int64_t)b * P.xb;
-        float acc = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = 0; i < P.k; ++i) {
             const int hi = ho * P.stride + i - P.pad_h;
             if (hi < 0 || hi >= P.H) continue;
@@ -32,16 +33,27 @@ __global__ __launch_bounds__(256) void gt_conv2d_bn_relu_kernel(Conv2dArgs P) {
                 const int wi = wo * P.stride + j - P.pad_w;
                 if (wi < 0 || wi >= P.W) continue;
                 const float* xp = xb + ((int64_t)hi * P.W + wi) * P.Cin;
-                const float* wp = P.w + ((int64_t)(i * P.k + j) * P.Cin) * P.Cout + co;
-                for (int ci = 0; ci < P.Cin; ++ci) acc += xp[ci] * wp[(int64_t)ci * P.Cout];
+                const float4* wp = reinterpret_cast<const float4*>(P.w + ((int64_t)(i * P.k + j) * P.Cin) * P.Cout) + c4;
+#pragma unroll 4
+                for (int ci = 0; ci < P.Cin; ++ci) {
+                    const float xv = xp[ci];
+                    const float4 wv = wp[(int64_t)ci * C4];
+                    acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
+                }
             }
         }
-        P.out[idx] = fmaxf(acc * P.scale[co] + P.shift[co], 0.f);
+        const float4 sc = reinterpret_cast<const float4*>(P.scale)[c4];
+        const float4 sh = reinterpret_cast<const float4*>(P.shift)[c4];
+        float4 o;
+        o.x = fmaxf(acc.x * sc.x + sh.x, 0.f); o.y = fmaxf(acc.y * sc.y + sh.y, 0.f);
+        o.z = fmaxf(acc.z * sc.z + sh.z, 0.f); o.w = fmaxf(acc.w * sc.w + sh.w, 0.f);
+        reinterpret_cast<float4*>(P.out)[idx] = o;
     }
 }
 
 hipError_t gt_launch_conv2d_bn_relu(const Conv2dArgs& a, hipStream_t stream) {
-    const int64_t total = (int64_t)a.B * a.Ho * a.Wo * a.Cout;
+    if (a.Cout & 3) return hipErrorInvalidValue;
+    const int64_t total = (int64_t)a.B * a.Ho * a.Wo * (a.Cout >> 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
@@ -78,12 +90,26 @@ __global__ __launch_bounds__(TAIL_THREADS) void gt_gst_tail_kernel(GstTailArgs P
         for (int i = tid; i < P.gru_in; i += TAIL_THREADS) xs[i] = xt[i];
         __syncthreads();
         for (int j = tid; j < G; j += TAIL_THREADS) {
-            float a = P.gru_b[j];
-            for (int k = 0; k < P.gru_in; ++k) a += xs[k] * P.gru_w[(int64_t)k * G + j];
-            mx[j] = a;
-            float r = P.gru_b[G + j];
-            for (int k = 0; k < u; ++k) r += hs[k] * P.gru_u[(int64_t)k * G + j];
-            mh[j] = r;
+            // 4 independent accumulators: the weight loads of 4 consecutive k are in flight together
+            float a0 = P.gru_b[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int k = 0;
+            for (; k + 4 <= P.gru_in; k += 4) {
+                a0 += xs[k] * P.gru_w[(int64_t)k * G + j];
+                a1 += xs[k + 1] * P.gru_w[(int64_t)(k + 1) * G + j];
+                a2 += xs[k + 2] * P.gru_w[(int64_t)(k + 2) * G + j];
+                a3 += xs[k + 3] * P.gru_w[(int64_t)(k + 3) * G + j];
+            }
+            for (; k < P.gru_in; ++k) a0 += xs[k] * P.gru_w[(int64_t)k * G + j];
+            mx[j] = (a0 + a1) + (a2 + a3);
+            float r0 = P.gru_b[G + j], r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            for (k = 0; k + 4 <= u; k += 4) {
+                r0 += hs[k] * P.gru_u[(int64_t)k * G + j];
+                r1 += hs[k + 1] * P.gru_u[(int64_t)(k + 1) * G + j];
+                r2 += hs[k + 2] * P.gru_u[(int64_t)(k + 2) * G + j];
+                r3 += hs[k + 3] * P.gru_u[(int64_t)(k + 3) * G + j];
+            }
+            for (; k < u; ++k) r0 += hs[k] * P.gru_u[(int64_t)k * G + j];
+            mh[j] = (r0 + r1) + (r2 + r3);
         }
         __syncthreads();
         for (int i = tid; i < u; i += TAIL_THREADS) {

@@ -736,7 +736,8 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     if (g.gst_use) {
         if (g.n_ref_conv < 1 || g.n_ref_conv > GSTTACO_MAX_LAYERS) return bad("bad reference-encoder conv count");
         for (int i = 0; i < g.n_ref_conv; ++i)
-            if (g.ref_filters[i] < 1 || g.ref_kernels[i] < 1 || g.ref_strides[i] < 1) return bad("bad reference-encoder conv");
+            if (g.ref_filters[i] < 4 || g.ref_filters[i] % 4 || g.ref_kernels[i] < 1 || g.ref_strides[i] < 1)
+                return bad("reference-encoder Conv.Filters must be multiples of 4");
         if (g.ref_rnn < 1 || g.ref_dense < 1 || g.n_tokens < 1 || g.token_emb < 1) return bad("bad GST sizes");
         if (g.heads < 1 || g.gst_att % g.heads)
             return bad("size must be divisible by num_heads.");   // reference Layers.py:155-156
