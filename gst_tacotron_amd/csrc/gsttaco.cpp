@@ -1156,7 +1156,8 @@ int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int which, int B) {
     const bool fused = c->fused_front && c->split_rec;
     auto gemm = [&](int64_t K, int64_t N, int64_t extra_row_floats) { return 4 * (K * N + N) + 4 * (int64_t)B * (K + extra_row_floats); };
     const int64_t ntile2 = (H2 + 3) / 4;
-    const int64_t co_tiles = std::max<int64_t>(0, std::min<int64_t>(ntile2, 256 - c->proj.ntiles));
+    int64_t co_tiles = std::max<int64_t>(0, std::min<int64_t>(ntile2, 192));       // same rule as enqueue_decode
+    if (c->proj.nkb < 32) co_tiles = 0;
     switch (which) {
         case 0:     // LSTM layer 1: x-half only when the recurrent half runs in the front launch
             return fused ? gemm(P1 + A, 4 * H1, 4 * H1 + 3 * H1) : gemm(P1 + A + H1, 4 * H1, 3 * H1);
