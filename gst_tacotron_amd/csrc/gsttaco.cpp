@@ -87,6 +87,7 @@ struct gsttaco_ctx {
     PackedLinear lstm_x[2], lstm_h[2];   // split packs: input half (critical path) / recurrent half + bias (front-kernel workers)
     float* w_part[2] = {nullptr, nullptr};
     bool split_rec = true;
+    int keep_x_weights = 1;
 
     float *pw0 = nullptr, *pb0 = nullptr, *pw1 = nullptr, *pb1 = nullptr, *pwq = nullptr, *pbq = nullptr;  // plain layouts (fused front)
     bool fused_front = true;
@@ -582,6 +583,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 if (layer == 0) k.seg[0] = SkinnySeg{c->w_xa, 0, XA / 16, 1};
                 else k.seg[0] = SkinnySeg{c->w_h1[p], 0, H1 / 16, 1};
                 k.partial_in = c->w_part[layer];
+                k.keep_weights = c->keep_x_weights;
             } else {
                 const PackedLinear& L = layer == 0 ? c->lstm0 : c->lstm1;
                 k.wp = L.wp; k.bias = L.bias; k.nkb = L.nkb;
@@ -760,6 +762,8 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->fused_front = !(ef && ef[0] == '0');
     const char* er = getenv("GSTTACO_SPLIT_REC");
     c->split_rec = !(er && er[0] == '0');
+    const char* ek = getenv("GSTTACO_KEEP_X");
+    if (ek) c->keep_x_weights = atoi(ek);
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);

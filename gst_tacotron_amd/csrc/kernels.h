@@ -46,6 +46,8 @@ struct SkinnyArgs {
     // masked-mode extension: EPI_LSTM rows whose time index t_index >= row_len[row] do not exist --
     // h is written as 0 and the cell state is left untouched (NULL = the reference's unmasked behaviour)
     const int32_t* row_len; int t_index;
+    int keep_weights;   // 1: load the weights with the default cache policy (they are re-read every step and small enough
+                        // to stay L2-resident) instead of non-temporally
     unsigned long long* dbg;   // diagnostic phase stamps (s_memrealtime, 100 MHz) of block 0, or NULL
 };
 

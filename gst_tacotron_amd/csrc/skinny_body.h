@@ -84,7 +84,7 @@ __device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int ti
                 if (kb < e0) { p0 = sp0[0]; p1 = sp1[0]; lk = kb; st = sstep[0]; }
                 else if (kb < e1) { p0 = sp0[1]; p1 = sp1[1]; lk = kb - e0; st = sstep[1]; }
                 else { p0 = sp0[2]; p1 = sp1[2]; lk = kb - e1; st = sstep[2]; }
-                if (NT_WEIGHTS) {
+                if (NT_WEIGHTS && !A.keep_weights) {
                     const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)kb * 64));
                     b[i] = make_float4(t[0], t[1], t[2], t[3]);
                 } else {
