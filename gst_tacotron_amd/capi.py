@@ -18,14 +18,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsttaco.so")
 
 MAX_LAYERS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 ATT_CODES = {"BMA": 0, "SMA": 1, "LSA": 2}
 
 # every symbol include/gsttaco.h declares
 EXPORTED_SYMBOLS = (
     "gsttaco_abi_version", "gsttaco_create", "gsttaco_destroy", "gsttaco_last_error",
     "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight", "gsttaco_finalize_weights",
-    "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_inference_step",
+    "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder", "gsttaco_inference_step",
     "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_lstm_launch_bytes", "gsttaco_debug_stamps",
 )
 
@@ -48,6 +48,10 @@ class Config(ctypes.Structure):
         ("ref_filters", _I32A), ("ref_kernels", _I32A), ("ref_strides", _I32A),
         ("ref_rnn", ctypes.c_int32), ("ref_dense", ctypes.c_int32), ("n_tokens", ctypes.c_int32),
         ("token_emb", ctypes.c_int32), ("heads", ctypes.c_int32), ("gst_att", ctypes.c_int32),
+        ("voc_use", ctypes.c_int32), ("spec_dim", ctypes.c_int32), ("bank_count", ctypes.c_int32),
+        ("bank_filters", ctypes.c_int32), ("n_voc_proj", ctypes.c_int32), ("voc_proj_filters", _I32A),
+        ("voc_proj_kernels", _I32A), ("highway_count", ctypes.c_int32), ("highway_size", ctypes.c_int32),
+        ("voc_rnn", ctypes.c_int32),
         ("max_batch", ctypes.c_int32), ("max_tokens", ctypes.c_int32), ("max_ref_frames", ctypes.c_int32),
     ]
 
@@ -88,7 +92,8 @@ def load_library(path=None):
     lib.gsttaco_gst.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.gsttaco_decode.argtypes = [vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, vp, vp, vp, vp]
     lib.gsttaco_postnet.argtypes = [vp, vp, i32, i32, vp, vp]
-    lib.gsttaco_inference_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    lib.gsttaco_vocoder.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.gsttaco_inference_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.gsttaco_set_profiling.argtypes = [vp, i32]
     lib.gsttaco_get_profile.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     lib.gsttaco_lstm_launch_bytes.argtypes = [vp, i32, i32]
@@ -96,7 +101,7 @@ def load_library(path=None):
     lib.gsttaco_debug_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.gsttaco_debug_stamps.restype = ctypes.c_int
     for fn in ("gsttaco_create", "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight",
-               "gsttaco_finalize_weights", "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet",
+               "gsttaco_finalize_weights", "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder",
                "gsttaco_inference_step", "gsttaco_set_profiling", "gsttaco_get_profile"):
         getattr(lib, fn).restype = ctypes.c_int
     if path is None:
@@ -138,6 +143,15 @@ def make_config(hp, vocab=None, device=0, max_batch=32, max_tokens=256, max_ref_
             c.ref_filters[i], c.ref_kernels[i], c.ref_strides[i] = f, k, s
         c.ref_rnn, c.ref_dense, c.n_tokens = d.ref_rnn, d.ref_dense, d.n_tokens
         c.token_emb, c.heads, c.gst_att = d.token_emb, d.heads, d.gst_att
+    c.voc_use = int(d.vocoder)
+    if d.vocoder:
+        if len(d.voc_proj_filters) > MAX_LAYERS:
+            raise ValueError("too many vocoder projection layers")
+        c.spec_dim, c.bank_count, c.bank_filters = d.spec, d.bank_count, d.bank_filters
+        c.n_voc_proj = len(d.voc_proj_filters)
+        for i, (f, k) in enumerate(zip(d.voc_proj_filters, d.voc_proj_kernels)):
+            c.voc_proj_filters[i], c.voc_proj_kernels[i] = f, k
+        c.highway_count, c.highway_size, c.voc_rnn = d.highway_count, d.highway_size, d.voc_rnn
     c.max_batch, c.max_tokens, c.max_ref_frames = max_batch, max_tokens, max_ref_frames
     return c
 

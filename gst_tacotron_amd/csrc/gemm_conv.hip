@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int Mtot = A.B * A.T;
     const int K = A.taps * A.Cin;
+    const int ldw = A.ldw ? A.ldw : A.N;
 
     // per-thread A rows (constant over the K loop)
     int a_b[A_F4], a_t[A_F4], a_len[A_F4];
@@ -75,6 +76,10 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
                     const int64_t rowi = (int64_t)a_b[i] * A.T + ts;
                     const float* rp = A.tokens ? A.x + (int64_t)A.tokens[rowi] * A.Cin : A.x + rowi * A.Cin;
                     v = *reinterpret_cast<const float4*>(rp + c);
+                    if (A.pool2 && ts + 1 < a_len[i]) {         // MaxPool1D(2,1,'same'): padding never wins the max
+                        const float4 v2 = *reinterpret_cast<const float4*>(rp + A.Cin + c);
+                        v.x = fmaxf(v.x, v2.x); v.y = fmaxf(v.y, v2.y); v.z = fmaxf(v.z, v2.z); v.w = fmaxf(v.w, v2.w);
+                    }
                 }
             }
             ra[i] = v;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
             const int nq = f - kr * (BN / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int kk = k0 + kr, n = n0 + nq * 4;
-            if (kr < BK && kk < K && n < A.N) v = *reinterpret_cast<const float4*>(A.w + (int64_t)kk * A.N + n);
+            if (kr < BK && kk < K && n < A.N) v = *reinterpret_cast<const float4*>(A.w + (int64_t)kk * ldw + n);
             rb[i] = v;
         }
     };
@@ -178,5 +183,32 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         dim3 grid((M + 127) / 128, 1);
         hipLaunchKernelGGL((gt_conv_gemm_kernel<4, 1, 1, 1>), grid, dim3(256), 0, stream, a);
     }
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void gt_highway_kernel(const float4* z, const float4* x, float4* out, int64_t M, int S4) {
+    const int64_t total = M * S4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / S4;
+        const int c = (int)(i - m * S4);
+        const float4 h = z[m * 2 * S4 + c], t = z[m * 2 * S4 + S4 + c], xv = x[i];
+        float4 o;
+        float g;
+        g = 1.f / (1.f + expf(-t.x)); o.x = fmaxf(h.x, 0.f) * g + xv.x * (1.f - g);
+        g = 1.f / (1.f + expf(-t.y)); o.y = fmaxf(h.y, 0.f) * g + xv.y * (1.f - g);
+        g = 1.f / (1.f + expf(-t.z)); o.z = fmaxf(h.z, 0.f) * g + xv.z * (1.f - g);
+        g = 1.f / (1.f + expf(-t.w)); o.w = fmaxf(h.w, 0.f) * g + xv.w * (1.f - g);
+        out[i] = o;
+    }
+}
+
+hipError_t gt_launch_highway(const float* z, const float* x, float* out, int64_t M, int S, hipStream_t stream) {
+    if (S & 3) return hipErrorInvalidValue;
+    const int64_t total = M * (S / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gt_highway_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(z),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<float4*>(out), M, S / 4);
     return hipGetLastError();
 }

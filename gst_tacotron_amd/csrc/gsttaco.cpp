@@ -95,6 +95,16 @@ struct gsttaco_ctx {
     float *loc_cw = nullptr, *loc_cb = nullptr, *loc_dw = nullptr, *loc_db = nullptr, *att_bias = nullptr;   // LSA extension
     float* w_lsa_state = nullptr;
 
+    // CBHG vocoder
+    std::vector<ConvLayer> voc_bank, voc_proj;
+    float *voc_pd_w = nullptr, *voc_pd_b = nullptr, *voc_hin_w = nullptr, *voc_hin_b = nullptr;
+    std::vector<float*> voc_hw_w, voc_hw_b;      // per highway layer: [S, 2S] = [relu | sigmoid], [2S]
+    PackedLinear voc_bilstm[2];
+    float *voc_dense_w = nullptr, *voc_dense_b = nullptr;
+    int voc_dense_ldw = 0;
+    float *w_vbank = nullptr, *w_vbuf[3] = {nullptr, nullptr, nullptr}, *w_vz = nullptr, *w_vrnn = nullptr, *w_vc = nullptr,
+          *w_spec = nullptr;
+
     // workspace
     int32_t *w_tokens = nullptr, *w_mel_len = nullptr, *w_tok_len = nullptr;
     float *w_mels_in = nullptr, *w_masks = nullptr, *w_noise = nullptr;
@@ -225,6 +235,42 @@ void build_manifest(gsttaco_ctx* c) {
         add_tensor(c, p + ".kernel", {g.post_kernels[i], cin, g.post_filters[i]});
         add_bn(c, p, g.post_filters[i]);
         cin = g.post_filters[i];
+    }
+    if (g.voc_use) {        // CBHG vocoder (reference Taco2.py:234-260, 285-424), same order as weights.py::manifest
+        for (int i = 0; i < g.bank_count; ++i) {
+            std::string p = "vocoder.convbank" + std::to_string(i);
+            add_tensor(c, p + ".kernel", {i + 1, g.mel_dim, g.bank_filters});
+            add_bn(c, p, g.bank_filters);
+        }
+        cin = (int64_t)g.bank_count * g.bank_filters;
+        for (int i = 0; i < g.n_voc_proj; ++i) {
+            std::string p = "vocoder.proj" + std::to_string(i);
+            add_tensor(c, p + ".kernel", {g.voc_proj_kernels[i], cin, g.voc_proj_filters[i]});
+            add_bn(c, p, g.voc_proj_filters[i]);
+            cin = g.voc_proj_filters[i];
+        }
+        if (cin != g.mel_dim) {
+            add_tensor(c, "vocoder.proj_dense.kernel", {cin, g.mel_dim});
+            add_tensor(c, "vocoder.proj_dense.bias", {g.mel_dim});
+        }
+        if (g.mel_dim != g.highway_size) {
+            add_tensor(c, "vocoder.highway_in.kernel", {g.mel_dim, g.highway_size});
+            add_tensor(c, "vocoder.highway_in.bias", {g.highway_size});
+        }
+        for (int i = 0; i < g.highway_count; ++i)
+            for (const char* gt : {"relu", "sigmoid"}) {
+                std::string p = "vocoder.highway" + std::to_string(i) + "." + gt;
+                add_tensor(c, p + ".kernel", {g.highway_size, g.highway_size});
+                add_tensor(c, p + ".bias", {g.highway_size});
+            }
+        for (const char* d : {"fwd", "bwd"}) {
+            std::string p = std::string("vocoder.bilstm.") + d;
+            add_tensor(c, p + ".kernel", {g.highway_size, 4 * (int64_t)g.voc_rnn});
+            add_tensor(c, p + ".recurrent_kernel", {g.voc_rnn, 4 * (int64_t)g.voc_rnn});
+            add_tensor(c, p + ".bias", {4 * (int64_t)g.voc_rnn});
+        }
+        add_tensor(c, "vocoder.dense.kernel", {2 * (int64_t)g.voc_rnn, g.spec_dim});
+        add_tensor(c, "vocoder.dense.bias", {g.spec_dim});
     }
 }
 
@@ -654,6 +700,96 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
     return 0;
 }
 
+// mel [B,Tf,mel] -> spectrogram [B,Tf,spec]  (reference Taco2.py:258-260, 366-380)
+int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* mel_in, float* spec) {
+    const gsttaco_config& g = c->cfg;
+    const int mel = g.mel_dim, NB = g.bank_count * g.bank_filters;
+    // conv bank: kernel sizes 1..N on the INPUT, each + BN + ReLU, concatenated on the channel axis (Taco2.py:383-407)
+    for (int i = 0; i < g.bank_count; ++i) {
+        const ConvLayer& L = c->voc_bank[i];
+        ConvGemmArgs a{};
+        a.x = mel_in; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
+        a.out = c->w_vbank + (size_t)i * g.bank_filters; a.ldo = NB;
+        a.B = B; a.T = Tf; a.Cin = mel; a.N = g.bank_filters; a.taps = L.taps;
+        a.pad_before = same_pad_before(Tf, L.taps, 1, nullptr);       // even kernels pad asymmetrically (F10)
+        a.act = ACT_RELU;
+        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+    }
+    // MaxPool1D(2,1,'same') fused into the first projection conv's gather; Conv1D + BN (+ReLU except the last) (Taco2.py:319-340)
+    const float* x = c->w_vbank;
+    int cin = NB, cur = 0;
+    for (int i = 0; i < g.n_voc_proj; ++i) {
+        const ConvLayer& L = c->voc_proj[i];
+        ConvGemmArgs a{};
+        a.x = x; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
+        a.out = c->w_vbuf[cur]; a.ldo = L.cout;
+        a.B = B; a.T = Tf; a.Cin = cin; a.N = L.cout; a.taps = L.taps;
+        a.pad_before = same_pad_before(Tf, L.taps, 1, nullptr);
+        a.act = i < g.n_voc_proj - 1 ? ACT_RELU : ACT_NONE;
+        a.pool2 = i == 0;
+        const bool last = i == g.n_voc_proj - 1;
+        if (last && !c->voc_pd_w) a.res = mel_in;                     // residual directly when no Dense follows (:373)
+        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        x = a.out; cin = L.cout; cur ^= 1;
+    }
+    if (c->voc_pd_w) {                                                // Dense back to mel width + residual (:342-345, 373)
+        ConvGemmArgs a{};
+        a.x = x; a.w = c->voc_pd_w; a.shift = c->voc_pd_b; a.res = mel_in;
+        a.out = c->w_vbuf[cur]; a.ldo = mel;
+        a.B = B; a.T = Tf; a.Cin = cin; a.N = mel; a.taps = 1; a.act = ACT_NONE;
+        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        x = a.out; cin = mel; cur ^= 1;
+    }
+    const int S = g.highway_size;
+    if (c->voc_hin_w) {                                               // Dense to the highway width (:348-351)
+        ConvGemmArgs a{};
+        a.x = x; a.w = c->voc_hin_w; a.shift = c->voc_hin_b;
+        a.out = c->w_vbuf[cur]; a.ldo = S;
+        a.B = B; a.T = Tf; a.Cin = cin; a.N = S; a.taps = 1; a.act = ACT_NONE;
+        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        x = a.out; cin = S; cur ^= 1;
+    }
+    float* hbuf[2] = {c->w_vbuf[cur], c->w_vbuf[2]};
+    int hcur = 0;
+    for (int i = 0; i < g.highway_count; ++i) {                       // Highwaynet (:409-424)
+        ConvGemmArgs a{};
+        a.x = x; a.w = c->voc_hw_w[i]; a.shift = c->voc_hw_b[i];
+        a.out = c->w_vz; a.ldo = 2 * S;
+        a.B = B; a.T = Tf; a.Cin = S; a.N = 2 * S; a.taps = 1; a.act = ACT_NONE;
+        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        HIPCHECK(c, gt_launch_highway(c->w_vz, x, hbuf[hcur], (int64_t)B * Tf, S, s));
+        x = hbuf[hcur]; hcur ^= 1;
+    }
+    // Bidirectional LSTM over the Tf frames: one launch per time step, both directions in grid.z (:353-361)
+    const int H = g.voc_rnn, EO = 2 * H;
+    HIPCHECK(c, gt_launch_zero(c->w_vc, (size_t)2 * B * H, s));
+    for (int t = 0; t < Tf; ++t) {
+        SkinnyArgs a[2];
+        for (int d = 0; d < 2; ++d) {
+            const int tt = d == 0 ? t : Tf - 1 - t;
+            const int tp = d == 0 ? tt - 1 : tt + 1;
+            SkinnyArgs& k = a[d];
+            memset(&k, 0, sizeof(k));
+            k.wp = c->voc_bilstm[d].wp; k.bias = c->voc_bilstm[d].bias;
+            k.seg[0] = SkinnySeg{x + (size_t)tt * S, (int64_t)Tf * S, S / 16, 0};
+            if (t == 0) k.seg[1] = SkinnySeg{c->w_zero, 0, H / 16, 0};
+            else k.seg[1] = SkinnySeg{c->w_vrnn + (size_t)tp * EO + d * H, (int64_t)Tf * EO, H / 16, 0};
+            k.nkb = c->voc_bilstm[d].nkb; k.M = B; k.N = H; k.MT = (B + 15) / 16;
+            k.c = c->w_vc + (size_t)d * B * H;
+            k.h = c->w_vrnn + (size_t)tt * EO + d * H; k.ldh = (int64_t)Tf * EO;
+        }
+        HIPCHECK(c, gt_launch_skinny(EPI_LSTM, a[0], &a[1], c->voc_bilstm[0].ntiles, s, TAG_ENC_BILSTM));
+    }
+    {   // Dense to the linear-spectrogram width (Taco2.py:252-260)
+        ConvGemmArgs a{};
+        a.x = c->w_vrnn; a.w = c->voc_dense_w; a.shift = c->voc_dense_b; a.ldw = c->voc_dense_ldw;
+        a.out = spec; a.ldo = g.spec_dim;
+        a.B = B; a.T = Tf; a.Cin = EO; a.N = g.spec_dim; a.taps = 1; a.act = ACT_NONE;
+        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+    }
+    return 0;
+}
+
 int check_ready(gsttaco_ctx* c) {
     if (!c) return GSTTACO_E_INVALID;
     if (!c->finalized) return fail(c, GSTTACO_E_WEIGHTS, "weights not finalized (call gsttaco_finalize_weights)");
@@ -744,6 +880,16 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
         if (g.heads < 1 || g.gst_att % g.heads)
             return bad("size must be divisible by num_heads.");   // reference Layers.py:155-156
         if (g.gst_att % 16) return bad("Style_Token.Attention.Size must be a multiple of 16");
+    }
+    if (g.voc_use) {
+        if (g.spec_dim < 1 || g.bank_count < 1 || g.bank_count > 32 || g.bank_filters < 4 || g.bank_filters % 4)
+            return bad("Vocoder_Taco1: Conv_Bank.Filters must be a multiple of 4, Stack_Count 1..32");
+        if (g.n_voc_proj < 1 || g.n_voc_proj > GSTTACO_MAX_LAYERS) return bad("Vocoder_Taco1: bad Conv1D projection count");
+        for (int i = 0; i < g.n_voc_proj; ++i)
+            if (g.voc_proj_filters[i] < 4 || g.voc_proj_filters[i] % 4 || g.voc_proj_kernels[i] < 1)
+                return bad("Vocoder_Taco1: Conv1D.Filters must be multiples of 4");
+        if (g.highway_count < 0 || g.highway_size < 16 || g.highway_size % 16) return bad("Vocoder_Taco1: Highwaynet.Size must be a multiple of 16");
+        if (g.voc_rnn < 16 || g.voc_rnn % 16) return bad("Vocoder_Taco1: RNN.Size must be a multiple of 16");
     }
     if (g.max_batch < 1 || g.max_tokens < 1 || (g.gst_use && g.max_ref_frames < 2)) return bad("bad capacity");
 
@@ -935,6 +1081,63 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     for (int i = 0; i < g.n_post; ++i)
         if ((rc = upload_conv(c, &c->post_conv[i], "postnet.conv" + std::to_string(i)))) return rc;
 
+    // ---- CBHG vocoder
+    if (g.voc_use) {
+        c->voc_bank.resize(g.bank_count);
+        for (int i = 0; i < g.bank_count; ++i)
+            if ((rc = upload_conv(c, &c->voc_bank[i], "vocoder.convbank" + std::to_string(i)))) return rc;
+        c->voc_proj.resize(g.n_voc_proj);
+        for (int i = 0; i < g.n_voc_proj; ++i)
+            if ((rc = upload_conv(c, &c->voc_proj[i], "vocoder.proj" + std::to_string(i)))) return rc;
+        auto upn = [&](float** dst, const std::string& name) {
+            const HostTensor& t = T(c, name);
+            return upload(c, dst, t.data.data(), t.data.size());
+        };
+        if (c->index.count("vocoder.proj_dense.kernel")) {
+            if ((rc = upn(&c->voc_pd_w, "vocoder.proj_dense.kernel"))) return rc;
+            if ((rc = upn(&c->voc_pd_b, "vocoder.proj_dense.bias"))) return rc;
+        }
+        if (c->index.count("vocoder.highway_in.kernel")) {
+            if ((rc = upn(&c->voc_hin_w, "vocoder.highway_in.kernel"))) return rc;
+            if ((rc = upn(&c->voc_hin_b, "vocoder.highway_in.bias"))) return rc;
+        }
+        const int S = g.highway_size;
+        for (int i = 0; i < g.highway_count; ++i) {
+            // one GEMM per layer: columns [0,S) = Dense_Relu, [S,2S) = Dense_Sigmoid (Taco2.py:412-420)
+            const std::string p = "vocoder.highway" + std::to_string(i);
+            const HostTensor &wr = T(c, p + ".relu.kernel"), &br = T(c, p + ".relu.bias");
+            const HostTensor &ws = T(c, p + ".sigmoid.kernel"), &bs = T(c, p + ".sigmoid.bias");
+            std::vector<float> wcat((size_t)S * 2 * S), bcat(2 * S);
+            for (int k = 0; k < S; ++k)
+                for (int n = 0; n < S; ++n) {
+                    wcat[(size_t)k * 2 * S + n] = wr.data[(size_t)k * S + n];
+                    wcat[(size_t)k * 2 * S + S + n] = ws.data[(size_t)k * S + n];
+                }
+            for (int n = 0; n < S; ++n) { bcat[n] = br.data[n]; bcat[S + n] = bs.data[n]; }
+            float *dw = nullptr, *db = nullptr;
+            if ((rc = upload(c, &dw, wcat.data(), wcat.size()))) return rc;
+            if ((rc = upload(c, &db, bcat.data(), bcat.size()))) return rc;
+            c->voc_hw_w.push_back(dw); c->voc_hw_b.push_back(db);
+        }
+        int d = 0;
+        for (const char* dir : {"fwd", "bwd"}) {
+            std::string p = std::string("vocoder.bilstm.") + dir;
+            const HostTensor &k = T(c, p + ".kernel"), &u = T(c, p + ".recurrent_kernel"), &b = T(c, p + ".bias");
+            if ((rc = pack_linear(c, &c->voc_bilstm[d], {{k.data.data(), (int)k.shape[0]}, {u.data.data(), (int)u.shape[0]}},
+                                  4 * g.voc_rnn, b.data.data(), g.voc_rnn))) return rc;
+            ++d;
+        }
+        {   // final Dense: rows padded to a multiple of 4 columns so the GEMM can load 16 bytes per lane
+            const HostTensor &k = T(c, "vocoder.dense.kernel"), &b = T(c, "vocoder.dense.bias");
+            const int K = (int)k.shape[0], N = g.spec_dim, ldw = (N + 3) / 4 * 4;
+            std::vector<float> wpad((size_t)K * ldw, 0.f);
+            for (int r = 0; r < K; ++r) memcpy(&wpad[(size_t)r * ldw], &k.data[(size_t)r * N], (size_t)N * sizeof(float));
+            c->voc_dense_ldw = ldw;
+            if ((rc = upload(c, &c->voc_dense_w, wpad.data(), wpad.size()))) return rc;
+            if ((rc = upload(c, &c->voc_dense_b, b.data.data(), b.data.size()))) return rc;
+        }
+    }
+
     // ---- workspace, sized once for the capacity given at create
     const size_t B = g.max_batch, Tv = g.max_tokens, S = c->steps_max, Tf = S * c->r, mel = g.mel_dim;
     auto fa = [&](float** p, size_t n) { return dev_alloc(c, (void**)p, n * sizeof(float)); };
@@ -952,7 +1155,8 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         if ((rc = fa(&c->w_act[i], B * Tv * actc))) return rc;
     if ((rc = fa(&c->w_enc, B * Tv * c->enc_out))) return rc;
     if ((rc = fa(&c->w_cenc, 2 * B * g.enc_rnn))) return rc;
-    c->zero_floats = ((B + 15) / 16 * 16) * std::max<size_t>({(size_t)mel, (size_t)g.enc_rnn, (size_t)c->H1, (size_t)c->H2});
+    c->zero_floats = ((B + 15) / 16 * 16) * std::max<size_t>({(size_t)mel, (size_t)g.enc_rnn, (size_t)c->H1, (size_t)c->H2,
+                                                               (size_t)(g.voc_use ? g.voc_rnn : 0)});
     if ((rc = fa(&c->w_zero, c->zero_floats))) return rc;
     HIPCHECK(c, hipMemset(c->w_zero, 0, c->zero_floats * sizeof(float)));
     if (g.gst_use) {
@@ -993,6 +1197,18 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     for (int i = 0; i < 2; ++i)
         if ((rc = fa(&c->w_post[i], B * Tf * postc))) return rc;
     if ((rc = fa(&c->w_mel, B * Tf * mel))) return rc;
+    if (g.voc_use) {
+        const size_t banks = (size_t)g.bank_count * g.bank_filters;
+        size_t wide = std::max<size_t>({(size_t)mel, (size_t)g.highway_size});
+        for (int i = 0; i < g.n_voc_proj; ++i) wide = std::max<size_t>(wide, g.voc_proj_filters[i]);
+        if ((rc = fa(&c->w_vbank, B * Tf * banks))) return rc;
+        for (int i = 0; i < 3; ++i)
+            if ((rc = fa(&c->w_vbuf[i], B * Tf * wide))) return rc;
+        if ((rc = fa(&c->w_vz, B * Tf * 2 * g.highway_size))) return rc;
+        if ((rc = fa(&c->w_vrnn, B * Tf * 2 * g.voc_rnn))) return rc;
+        if ((rc = fa(&c->w_vc, 2 * B * g.voc_rnn))) return rc;
+        if ((rc = fa(&c->w_spec, B * Tf * g.spec_dim))) return rc;
+    }
     HIPCHECK(c, gt_attn_init());
     HIPCHECK(c, gt_dec_front_init());
     HIPCHECK(c, hipDeviceSynchronize());
@@ -1086,9 +1302,24 @@ int gsttaco_postnet(gsttaco_ctx* c, const float* pre_mel, int B, int Tf, float* 
     return 0;
 }
 
+int gsttaco_vocoder(gsttaco_ctx* c, const float* mel, int B, int Tf, float* spectrogram, void* stream) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (!c->cfg.voc_use) return fail(c, GSTTACO_E_INVALID, "the context was created without Vocoder_Taco1");
+    if (!mel || !spectrogram) return fail(c, GSTTACO_E_INVALID, "null argument");
+    if (B < 1 || Tf < 1) return fail(c, GSTTACO_E_INVALID, "bad B / T");
+    if (B > c->cfg.max_batch || Tf > c->steps_max * c->r) return fail(c, GSTTACO_E_CAPACITY, "batch / frames exceed capacity");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHECK(c, hipMemcpyAsync(c->w_mel, mel, (size_t)B * Tf * c->cfg.mel_dim * 4, hipMemcpyDeviceToDevice, s));
+    GraphKey key{5, B, 0, 0, Tf, 0, 0, 0, 0};
+    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_vocoder(c, st, B, Tf, c->w_mel, c->w_spec); }))) return rc;
+    HIPCHECK(c, hipMemcpyAsync(spectrogram, c->w_spec, (size_t)B * Tf * c->cfg.spec_dim * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t* token_lengths, const float* mels_for_gst, const int32_t* mel_lengths,
                            const float* mask, const float* noise, uint64_t seed, int B, int Tv, int Tref1, int steps,
-                           float* mel, float* stop, float* align, float* pre_mel, void* stream) {
+                           float* mel, float* stop, float* align, float* pre_mel, float* spectrogram, void* stream) {
     int rc = check_ready(c);
     if (rc) return rc;
     const bool gst = c->cfg.gst_use != 0;
@@ -1096,9 +1327,11 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
     if (gst && (!mels_for_gst || !mel_lengths)) return fail(c, GSTTACO_E_INVALID, "GST is enabled, but no mel information.");
     if (!gst) Tref1 = 0;
     if (gst && Tref1 < 2) return fail(c, GSTTACO_E_INVALID, "mels_for_gst needs at least one frame after the prepended zero frame");
+    if (spectrogram && !c->cfg.voc_use) return fail(c, GSTTACO_E_INVALID, "the context was created without Vocoder_Taco1");
     if ((rc = check_shape(c, B, Tv, Tref1, steps))) return rc;
     if (steps == 0) steps = c->steps_max;
     hipStream_t s = (hipStream_t)stream;
+    const bool voc = spectrogram != nullptr;
     const size_t meld = c->cfg.mel_dim;
     HIPCHECK(c, hipMemcpyAsync(c->w_tokens, tokens, (size_t)B * Tv * 4, hipMemcpyDeviceToDevice, s));
     if (gst) {
@@ -1108,19 +1341,22 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
     if ((rc = stage_randomness(c, s, mask, noise, seed, B, Tv, steps))) return rc;
     const bool masked = token_lengths != nullptr;
     if (masked) HIPCHECK(c, hipMemcpyAsync(c->w_tok_len, token_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-    GraphKey key{0, B, Tv, Tref1, steps, mask != nullptr, noise != nullptr, c->prof_every, masked};
+    GraphKey key{voc ? 6 : 0, B, Tv, Tref1, steps, mask != nullptr, noise != nullptr, c->prof_every, masked};
     rc = run_cached(c, s, key, [&](hipStream_t st) {
         int r2 = enqueue_encoder(c, st, B, Tv, masked);
         if (!r2 && gst) r2 = enqueue_gst(c, st, B, Tref1);
         if (!r2) r2 = enqueue_value_proj(c, st, B, Tv);
         if (!r2) r2 = enqueue_decode(c, st, B, Tv, steps, mask != nullptr, noise != nullptr, masked);
         if (!r2) r2 = enqueue_postnet(c, st, B, steps * c->r, c->w_pre, c->w_mel);
+        if (!r2 && voc) r2 = enqueue_vocoder(c, st, B, steps * c->r, c->w_mel, c->w_spec);     // Model.py:126-129
         return r2;
     });
     if (rc) return rc;
     const size_t nf = (size_t)B * steps * c->r * meld;
     HIPCHECK(c, hipMemcpyAsync(mel, c->w_mel, nf * 4, hipMemcpyDeviceToDevice, s));
     if (pre_mel) HIPCHECK(c, hipMemcpyAsync(pre_mel, c->w_pre, nf * 4, hipMemcpyDeviceToDevice, s));
+    if (voc)
+        HIPCHECK(c, hipMemcpyAsync(spectrogram, c->w_spec, (size_t)B * steps * c->r * c->cfg.spec_dim * 4, hipMemcpyDeviceToDevice, s));
     HIPCHECK(c, hipMemcpyAsync(stop, c->w_stop, (size_t)B * steps * 4, hipMemcpyDeviceToDevice, s));
     HIPCHECK(c, hipMemcpyAsync(align, c->w_align, (size_t)B * steps * Tv * 4, hipMemcpyDeviceToDevice, s));
     return 0;

@@ -71,12 +71,17 @@ struct ConvGemmArgs {
     const float* rowbias;   // [B, N] or NULL
     const float* res;       // [B*T, ldo] residual or NULL
     const int32_t* row_len; // masked-mode extension (A12): input rows t >= row_len[b] read as zero, or NULL
+    int ldw;                // row stride of w in floats (0 = N); lets N be odd (513) over a zero-padded multiple of 4
+    int pool2;              // 1: the input row is max(x[t], x[t+1]) -- MaxPool1D(2, stride 1, 'same') fused into the gather
     float* out;             // [B*T, ldo]
     int64_t ldo;
     int B, T, Cin, N, taps, pad_before, act;
 };
 
 hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
+// Highwaynet combine (reference Taco2.py:409-424): z [M, 2S] = [relu-branch | sigmoid-branch] pre-activations,
+// out = relu(z_h) * sigmoid(z_t) + x * (1 - sigmoid(z_t));  S % 4 == 0
+hipError_t gt_launch_highway(const float* z, const float* x, float* out, int64_t M, int S, hipStream_t stream);
 
 // ---------------------------------------------------------------- attention.hip
 struct AttnStepArgs {

@@ -120,3 +120,17 @@ class Dims:
         else:
             self.mem = self.enc_out
         self.proj_out = self.mel * self.r + 1           # Taco2.py:88
+        # CBHG vocoder (reference Taco2.py:234-260, 285-424): SURVEY row N1, optional third output of Inference_Step
+        self.vocoder = "Vocoder_Taco1" in hp
+        if self.vocoder:
+            cb = hp["Vocoder_Taco1"]["CBHG"]
+            self.spec = int(hp["Sound"]["Spectrogram_Dim"])
+            self.bank_count = int(cb["Conv_Bank"]["Stack_Count"])
+            self.bank_filters = int(cb["Conv_Bank"]["Filters"])
+            if int(cb["Pool"]["Pool_Size"]) != 2 or int(cb["Pool"]["Strides"]) != 1:
+                raise ValueError("Vocoder_Taco1.CBHG.Pool other than Pool_Size 2 / Strides 1 is not supported")
+            self.voc_proj_filters = [int(x) for x in cb["Conv1D"]["Filters"]]
+            self.voc_proj_kernels = [int(x) for x in cb["Conv1D"]["Kernel_Size"]]
+            self.highway_count = int(cb["Highwaynet"]["Count"])
+            self.highway_size = int(cb["Highwaynet"]["Size"])
+            self.voc_rnn = int(cb["RNN"]["Size"])

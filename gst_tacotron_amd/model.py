@@ -91,11 +91,13 @@ class GST_Tacotron:
     # ------------------------------------------------------------------ hot path
     def Inference_Step(self, tokens, token_lengths=None, initial_mels=None, mels_for_gst=None,
                        mel_lengths_for_gst=None, prenet_masks=None, attn_noise=None, seed=None,
-                       steps=None, return_pre_mel=False, masked=False):
+                       steps=None, return_pre_mel=False, masked=False, with_vocoder=False):
         """reference Model.py:249-255.  Returns (mel_Logits [B,S*r,mel], stop_Logits [B,S],
         spectrogram_Logits (None), alignments [B,S,T_v]) as CUDA tensors on the current stream.
         ``masked=True`` (extension): honour ``token_lengths`` so each utterance of a ragged batch equals
-        that utterance run alone; the default ignores them like the reference does."""
+        that utterance run alone; the default ignores them like the reference does.
+        ``with_vocoder=True`` also runs Vocoder_Taco1 (CBHG) and returns spectrogram_Logits [B,S*r,513]
+        as the third element like the reference; the default returns None there (the north-star metric excludes it)."""
         self._require_ready()
         d = self.dims
         tok = self._dev(tokens, torch.int32)
@@ -128,6 +130,11 @@ class GST_Tacotron:
             raise ValueError("attn_noise must be [steps, batch, T_v]")
         mel = torch.empty((B, S * d.r, d.mel), dtype=torch.float32, device=self.device)
         pre = torch.empty_like(mel) if return_pre_mel else None
+        spec = None
+        if with_vocoder:
+            if not d.vocoder:
+                raise ValueError("Hyper_Parameters has no Vocoder_Taco1 section")
+            spec = torch.empty((B, S * d.r, d.spec), dtype=torch.float32, device=self.device)
         stop = torch.empty((B, S), dtype=torch.float32, device=self.device)
         align = torch.empty((B, S, Tv), dtype=torch.float32, device=self.device)
         if seed is None:
@@ -136,11 +143,11 @@ class GST_Tacotron:
         with torch.cuda.device(self.device):
             self.ctx.check(self.ctx.lib.gsttaco_inference_step(
                 self.ctx.handle, _ptr(tok), _ptr(tlen), _ptr(mels), _ptr(lens), _ptr(masks), _ptr(noise),
-                ctypes.c_uint64(int(seed)), B, Tv, Tref1, S, _ptr(mel), _ptr(stop), _ptr(align), _ptr(pre),
+                ctypes.c_uint64(int(seed)), B, Tv, Tref1, S, _ptr(mel), _ptr(stop), _ptr(align), _ptr(pre), _ptr(spec),
                 self._stream()))
         if return_pre_mel:
-            return mel, stop, None, align, pre
-        return mel, stop, None, align
+            return mel, stop, spec, align, pre
+        return mel, stop, spec, align
 
     def Inference_GST_Step(self, mels_for_gst, mel_lengths_for_gst):
         """reference Model.py:257-265"""
@@ -193,6 +200,16 @@ class GST_Tacotron:
                 self.ctx.handle, _ptr(enc), _ptr(gst), _ptr(tlen), _ptr(masks), _ptr(noise), ctypes.c_uint64(int(seed)),
                 B, Tv, S, _ptr(pre), _ptr(stop), _ptr(align), self._stream()))
         return pre, stop, align
+
+    def vocoder(self, mel):
+        """Vocoder_Taco1 alone: mel [B,T,Mel_Dim] -> linear spectrogram [B,T,Spectrogram_Dim] (reference Taco2.py:234-260)."""
+        self._require_ready()
+        x = self._dev(mel, torch.float32)
+        B, T = x.shape[0], x.shape[1]
+        spec = torch.empty((B, T, self.dims.spec), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.ctx.check(self.ctx.lib.gsttaco_vocoder(self.ctx.handle, _ptr(x), B, T, _ptr(spec), self._stream()))
+        return spec
 
     def postnet(self, pre_mel):
         self._require_ready()

@@ -84,6 +84,34 @@ def manifest(hp, vocab=None):
         for b in BN_FIELDS:
             m[f"postnet.conv{i}.bn.{b}"] = (f,)
         cin = f
+    # --- CBHG vocoder (reference Taco2.py:234-260, 285-424), SURVEY row N1
+    if d.vocoder:
+        for i in range(d.bank_count):
+            m[f"vocoder.convbank{i}.kernel"] = (i + 1, d.mel, d.bank_filters)
+            for b in BN_FIELDS:
+                m[f"vocoder.convbank{i}.bn.{b}"] = (d.bank_filters,)
+        cin = d.bank_count * d.bank_filters
+        for i, (f, k) in enumerate(zip(d.voc_proj_filters, d.voc_proj_kernels)):
+            m[f"vocoder.proj{i}.kernel"] = (k, cin, f)
+            for b in BN_FIELDS:
+                m[f"vocoder.proj{i}.bn.{b}"] = (f,)
+            cin = f
+        if cin != d.mel:                                    # Taco2.py:342-345
+            m["vocoder.proj_dense.kernel"] = (cin, d.mel)
+            m["vocoder.proj_dense.bias"] = (d.mel,)
+        if d.mel != d.highway_size:                         # Taco2.py:348-351
+            m["vocoder.highway_in.kernel"] = (d.mel, d.highway_size)
+            m["vocoder.highway_in.bias"] = (d.highway_size,)
+        for i in range(d.highway_count):
+            for g in ("relu", "sigmoid"):
+                m[f"vocoder.highway{i}.{g}.kernel"] = (d.highway_size, d.highway_size)
+                m[f"vocoder.highway{i}.{g}.bias"] = (d.highway_size,)
+        for direction in ("fwd", "bwd"):
+            m[f"vocoder.bilstm.{direction}.kernel"] = (d.highway_size, 4 * d.voc_rnn)
+            m[f"vocoder.bilstm.{direction}.recurrent_kernel"] = (d.voc_rnn, 4 * d.voc_rnn)
+            m[f"vocoder.bilstm.{direction}.bias"] = (4 * d.voc_rnn,)
+        m["vocoder.dense.kernel"] = (2 * d.voc_rnn, d.spec)
+        m["vocoder.dense.bias"] = (d.spec,)
     return m
 
 

@@ -17,6 +17,7 @@
  *                          Decoder_Step :96-120, Prenet :262-283,
  *                          Modules/Attention/Steps.py:107-229 (BMA / SMA)
  *   gsttaco_postnet     <- Modules/Taco2.py:131-149, 230
+ *   gsttaco_vocoder     <- Modules/Taco2.py:234-260 Vocoder_Taco1.call, CBHG :285-380
  *
  * Conventions
  *   - every function returns 0 on success or a negative GSTTACO_E_* code; nothing throws
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 3
+#define GSTTACO_ABI_VERSION 4
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -97,6 +98,17 @@ typedef struct gsttaco_config {
     int32_t token_emb;          /* Style_Token.Embedding.Size */
     int32_t heads;              /* Style_Token.Attention.Head */
     int32_t gst_att;            /* Style_Token.Attention.Size */
+    /* Vocoder_Taco1 (CBHG mel -> linear spectrogram, reference Taco2.py:234-260, 285-424); optional */
+    int32_t voc_use;            /* 0: no vocoder weights / entry point */
+    int32_t spec_dim;           /* Sound.Spectrogram_Dim */
+    int32_t bank_count;         /* CBHG.Conv_Bank.Stack_Count (kernel sizes 1..count) */
+    int32_t bank_filters;       /* CBHG.Conv_Bank.Filters */
+    int32_t n_voc_proj;
+    int32_t voc_proj_filters[GSTTACO_MAX_LAYERS];
+    int32_t voc_proj_kernels[GSTTACO_MAX_LAYERS];
+    int32_t highway_count;
+    int32_t highway_size;
+    int32_t voc_rnn;            /* CBHG.RNN.Size (per direction) */
     /* capacity: workspace is sized once, at finalize */
     int32_t max_batch;
     int32_t max_tokens;
@@ -149,14 +161,18 @@ int gsttaco_decode(gsttaco_ctx* ctx, const float* enc, const float* gst, const i
 /* pre_mel [B,T,mel] -> mel [B,T,mel] (5 x Conv1D+BN, tanh on the first post_tanh layers, + residual) */
 int gsttaco_postnet(gsttaco_ctx* ctx, const float* pre_mel, int B, int T, float* mel, void* stream);
 
-/* The whole Inference_Step (Model.py:249-255) minus the CBHG vocoder: encoder, GST, decode loop,
- * postnet, replayed from one cached hipGraph per (B,Tv,Tref1,steps) shape.
- * mels_for_gst / mel_lengths are ignored (may be NULL) when GST is off; pre_mel may be NULL. */
+/* mel [B,T,mel] (the post-net mel) -> spectrogram [B,T,spec_dim]: Vocoder_Taco1 = CBHG (conv bank k=1..N + BN + ReLU,
+ * max-pool 2/1, two projection convs, residual, highway stack, BiLSTM) + Dense (reference Taco2.py:234-260, 285-424). */
+int gsttaco_vocoder(gsttaco_ctx* ctx, const float* mel, int B, int T, float* spectrogram, void* stream);
+
+/* The whole Inference_Step (Model.py:249-255): encoder, GST, decode loop, postnet and -- when `spectrogram` is not
+ * NULL -- the CBHG vocoder, replayed from one cached hipGraph per (B,Tv,Tref1,steps) shape.
+ * mels_for_gst / mel_lengths are ignored (may be NULL) when GST is off; pre_mel and spectrogram may be NULL. */
 int gsttaco_inference_step(gsttaco_ctx* ctx, const int32_t* tokens, const int32_t* token_lengths,
                            const float* mels_for_gst, const int32_t* mel_lengths,
                            const float* prenet_mask, const float* attn_noise, uint64_t seed,
                            int B, int Tv, int Tref1, int steps,
-                           float* mel, float* stop, float* align, float* pre_mel, void* stream);
+                           float* mel, float* stop, float* align, float* pre_mel, float* spectrogram, void* stream);
 
 /* Measurement support (bench.py): per-kernel timing of the last gsttaco_inference_step replay.
  * When enabled, HIP event-record nodes bracket the four kernels of every `every`-th decode step inside the graph. */

@@ -39,9 +39,13 @@ def make_case(name, hp, wseed, iseed, B, Tv, Tref, ref_lengths=None, token_lengt
         mels, ml = None, None
     steps = steps or d.steps
     masks, noise = synthetic.make_randomness(rng, steps, B, Tv, d.prenet, rate=d.prenet_rate)
-    o = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
-    t = torch_ref.TorchReference(hp, w, torch.float64).inference_step(tokens, mels, ml, masks, noise, steps=steps)
-    for a, b, what in ((o[0], t[0], "mel"), (o[1], t[1], "stop"), (o[3], t[3], "align")):
+    o = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64, with_vocoder=d.vocoder)
+    t = torch_ref.TorchReference(hp, w, torch.float64).inference_step(tokens, mels, ml, masks, noise, steps=steps,
+                                                                      with_vocoder=d.vocoder)
+    checks = [(o[0], t[0], "mel"), (o[1], t[1], "stop"), (o[3], t[3], "align")]
+    if d.vocoder:
+        checks.append((o[2], t[2], "spectrogram"))
+    for a, b, what in checks:
         err = np.abs(a - b.numpy()).max()
         assert err < 1e-9, (name, what, err)
     out = {
@@ -53,6 +57,8 @@ def make_case(name, hp, wseed, iseed, B, Tv, Tref, ref_lengths=None, token_lengt
         "alignments": o[3].astype(np.float32), "pre_mel": o[4]["pre_mel"].astype(np.float32),
         "encoder": o[4]["encoder"].astype(np.float32),
     }
+    if d.vocoder:
+        out["spectrograms"] = o[2].astype(np.float32)
     if d.gst:
         out["mels_for_gst"] = mels
         out["mel_lengths_for_gst"] = ml

@@ -328,8 +328,57 @@ def postnet(hp, w, pre, dt):
     return x + pre
 
 
+def conv1d_same_general(x, kernel):
+    """Conv1D stride 1 padding same for ANY kernel size (even sizes pad asymmetrically: before = (k-1)//2)."""
+    return conv1d_same(x, kernel)       # conv1d_same already uses same_pad(); kept as a named alias for the bank
+
+
+def maxpool1d_same2(y):
+    """MaxPool1D(pool 2, strides 1, 'same') (reference Taco2.py:319-324): TF pads one frame AFTER and padding never
+    wins a max, so frame t = max(y[t], y[t+1]) and the last frame is unchanged."""
+    return np.concatenate([np.maximum(y[:, :-1], y[:, 1:]), y[:, -1:]], 1)
+
+
+def highway(y, w_relu, b_relu, w_sig, b_sig):
+    """One Highwaynet layer (reference Taco2.py:409-424): H*T + x*(1-T), H = relu dense, T = sigmoid dense."""
+    h = np.maximum(y @ w_relu + b_relu, 0)
+    t = sigmoid(y @ w_sig + b_sig)
+    return h * t + y * (1.0 - t)
+
+
+def vocoder_taco1(hp, w, mels, dt):
+    """Reference Taco2.py:234-260 (Vocoder_Taco1) + CBHG :285-380 + ConvBank :383-407 + Highwaynet :409-424:
+    mel [B,T,mel] -> linear spectrogram [B,T,Spectrogram_Dim].  SURVEY row N1."""
+    cb = hp["Vocoder_Taco1"]["CBHG"]
+    x = np.asarray(mels, dt)
+    banks = []
+    for i in range(int(cb["Conv_Bank"]["Stack_Count"])):                      # kernel sizes 1..Stack_Count, all on the INPUT
+        y = conv1d_same(x, w[f"vocoder.convbank{i}.kernel"])
+        banks.append(np.maximum(batch_norm(y, w, f"vocoder.convbank{i}.bn"), 0))
+    y = np.concatenate(banks, -1)                                             # :404-407
+    y = maxpool1d_same2(y)
+    n = len(cb["Conv1D"]["Filters"])
+    for i in range(n):                                                        # :326-340
+        y = batch_norm(conv1d_same(y, w[f"vocoder.proj{i}.kernel"]), w, f"vocoder.proj{i}.bn")
+        if i < n - 1:
+            y = np.maximum(y, 0)
+    if "vocoder.proj_dense.kernel" in w:                                      # :342-345
+        y = y @ w["vocoder.proj_dense.kernel"] + w["vocoder.proj_dense.bias"]
+    y = y + x                                                                 # residual :373
+    if "vocoder.highway_in.kernel" in w:                                      # :348-351
+        y = y @ w["vocoder.highway_in.kernel"] + w["vocoder.highway_in.bias"]
+    for i in range(int(cb["Highwaynet"]["Count"])):                           # :409-424
+        y = highway(y, w[f"vocoder.highway{i}.relu.kernel"], w[f"vocoder.highway{i}.relu.bias"],
+                    w[f"vocoder.highway{i}.sigmoid.kernel"], w[f"vocoder.highway{i}.sigmoid.bias"])
+    p = "vocoder.bilstm."
+    fwd = lstm_sequence(y, w[p + "fwd.kernel"], w[p + "fwd.recurrent_kernel"], w[p + "fwd.bias"])
+    bwd = lstm_sequence(y, w[p + "bwd.kernel"], w[p + "bwd.recurrent_kernel"], w[p + "bwd.bias"], reverse=True)
+    y = np.concatenate([fwd, bwd], -1)                                        # :357-361
+    return y @ w["vocoder.dense.kernel"] + w["vocoder.dense.bias"]            # :252-260
+
+
 def inference_step(hp, weights, tokens, mels_for_gst=None, mel_lengths_for_gst=None,
-                   prenet_masks=None, attn_noise=None, steps=None, dt=np.float64, token_lengths=None):
+                   prenet_masks=None, attn_noise=None, steps=None, dt=np.float64, token_lengths=None, with_vocoder=False):
     """Reference Model.py:249-255 with the wiring of Model.py:108-129,145-156.
     Returns (mels [B,S*r,mel] post-net, stops [B,S], None (vocoder out of scope), alignments [B,S,T_v])
     plus a dict of intermediates for per-module parity tests."""
@@ -348,4 +397,5 @@ def inference_step(hp, weights, tokens, mels_for_gst=None, mel_lengths_for_gst=N
     pre, stops, aligns = decoder(hp, w, memory, dt, prenet_masks, attn_noise, steps, token_lengths=token_lengths)
     inter["pre_mel"] = pre
     mels = postnet(hp, w, pre, dt)
-    return mels, stops, None, aligns, inter
+    spec = vocoder_taco1(hp, w, mels, dt) if with_vocoder else None          # Model.py:126-129 (training=False)
+    return mels, stops, spec, aligns, inter

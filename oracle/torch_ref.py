@@ -236,8 +236,35 @@ class TorchReference:
                 x = torch.tanh(x)
         return decodings, x + decodings, stops, alignments
 
+    def vocoder(self, mels):
+        """reference Taco2.py:234-260, 285-424 with torch's own conv1d / max_pool1d / fused LSTM cell"""
+        w, cb = self.w, self.hp["Vocoder_Taco1"]["CBHG"]
+        x = mels
+        banks = []
+        for i in range(int(cb["Conv_Bank"]["Stack_Count"])):
+            banks.append(torch.relu(self._conv1d_bn(x, f"vocoder.convbank{i}")))
+        y = torch.cat(banks, dim=-1)
+        y = F.max_pool1d(F.pad(y.transpose(1, 2), (0, 1), value=float("-inf")), kernel_size=2, stride=1).transpose(1, 2)
+        n = len(cb["Conv1D"]["Filters"])
+        for i in range(n):
+            y = self._conv1d_bn(y, f"vocoder.proj{i}")
+            if i < n - 1:
+                y = torch.relu(y)
+        if "vocoder.proj_dense.kernel" in w:
+            y = y @ w["vocoder.proj_dense.kernel"] + w["vocoder.proj_dense.bias"]
+        y = y + x
+        if "vocoder.highway_in.kernel" in w:
+            y = y @ w["vocoder.highway_in.kernel"] + w["vocoder.highway_in.bias"]
+        for i in range(int(cb["Highwaynet"]["Count"])):
+            h = torch.relu(y @ w[f"vocoder.highway{i}.relu.kernel"] + w[f"vocoder.highway{i}.relu.bias"])
+            t = torch.sigmoid(y @ w[f"vocoder.highway{i}.sigmoid.kernel"] + w[f"vocoder.highway{i}.sigmoid.bias"])
+            y = h * t + y * (1.0 - t)
+        fwd = self._lstm_seq_native(y, "vocoder.bilstm.fwd", False)
+        bwd = self._lstm_seq_native(y, "vocoder.bilstm.bwd", True)
+        return torch.cat([fwd, bwd], dim=-1) @ w["vocoder.dense.kernel"] + w["vocoder.dense.bias"]
+
     def inference_step(self, tokens, mels_for_gst=None, mel_lengths_for_gst=None,
-                       prenet_masks=None, attn_noise=None, steps=None):
+                       prenet_masks=None, attn_noise=None, steps=None, with_vocoder=False):
         """reference Model.py:249-255 (vocoder excluded; north_star metric is mel frames)."""
         with torch.no_grad():
             enc = self.encoder(tokens)
@@ -250,4 +277,5 @@ class TorchReference:
             if attn_noise is not None:
                 attn_noise = torch.as_tensor(np.asarray(attn_noise), dtype=self.dt)
             pre, mels, stops, aligns = self.decoder(memory, prenet_masks, attn_noise, steps)
-        return mels, stops, None, aligns, {"pre_mel": pre, "encoder": enc}
+            spec = self.vocoder(mels) if with_vocoder else None
+        return mels, stops, spec, aligns, {"pre_mel": pre, "encoder": enc}

@@ -33,7 +33,9 @@ def _run_case(name, **kw):
         prenet_masks=g["prenet_masks"], attn_noise=g["attn_noise"], steps=int(g["steps"]), return_pre_mel=True, **kw)
     torch.cuda.synchronize()
     mel, stop, spec, align, pre = out
-    assert spec is None
+    assert (spec is None) == (not kw.get("with_vocoder"))
+    if spec is not None:
+        g = dict(g); g["_spec"] = spec.cpu().numpy()
     return g, mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy(), pre.cpu().numpy(), m
 
 
@@ -48,6 +50,37 @@ def test_inference_step_matches_golden(name):
         assert np.isfinite(got).all()
         assert err <= TOL, (name, what, err)
         assert err <= BAR
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_inference_step_with_vocoder_matches_golden(name):
+    """spectrogram_Logits of Inference_Step (CBHG Vocoder_Taco1 on the post-net mels, Model.py:126-129)."""
+    g, mel, stop, align, pre, _ = _run_case(name, with_vocoder=True)
+    assert g["_spec"].shape == g["spectrograms"].shape
+    err = np.abs(g["_spec"] - g["spectrograms"]).max()
+    print(name, "spectrograms max abs err", err)
+    assert np.isfinite(g["_spec"]).all() and err <= TOL
+    assert np.abs(mel - g["mels"]).max() <= TOL
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 7), (2, 130), (17, 33)])
+def test_vocoder_alone_matches_oracle(B, T):
+    """gsttaco_vocoder on caller-supplied mels at the reference's full CBHG dimensions (8 banks x 256, 513 bins):
+    1 frame, fewer frames than the widest bank kernel, more than one 128-row GEMM tile, a ragged batch."""
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    from oracle import oracle_np
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, seed=3)
+    rng = np.random.default_rng(B * 100 + T)
+    mel = np.clip(rng.normal(0, 1.5, (B, T, 80)), -4, 4).astype(np.float32)
+    m = _model(hp, w, B, 8, 2)
+    spec = m.vocoder(mel)
+    torch.cuda.synchronize()
+    ref = oracle_np.vocoder_taco1(hp, oracle_np.cast_weights(w, np.float64), mel.astype(np.float64), np.float64)
+    err = np.abs(spec.cpu().numpy() - ref).max()
+    print("vocoder", B, T, "max abs err", err, "scale", np.abs(ref).max())
+    assert spec.shape == (B, T, 513) and err <= TOL
 
 
 # ------------------------------------------------------------------ per-module parity against the oracle

@@ -112,8 +112,12 @@ def test_dims_of_the_reference_defaults():
     assert d.sigmoid_noise == 2.0 and d.att_type == "SMA" and d.post_tanh == 3 and d.gru_in == 256
     d2 = hparams.Dims(synthetic.config_hp("cfg2"))
     assert d2.proj_out == 161 and d2.steps == 500
-    n = sum(int(np.prod(s)) for s in weights.manifest(synthetic.config_hp("cfg2")).values())
-    assert 24.5e6 < n < 25.5e6            # ~24.9 M parameters
+    man = weights.manifest(synthetic.config_hp("cfg2"))
+    n = sum(int(np.prod(s)) for k, s in man.items() if not k.startswith("vocoder."))
+    assert 24.5e6 < n < 25.5e6            # ~24.9 M parameters (vocoder excluded)
+    nv = sum(int(np.prod(s)) for k, s in man.items() if k.startswith("vocoder."))
+    assert 2.5e6 < nv < 3.2e6             # CBHG Vocoder_Taco1 (row N1)
+    assert (d2.spec, d2.bank_count, d2.bank_filters, d2.highway_count, d2.voc_rnn) == (513, 8, 256, 4, 256)
 
 
 def test_feeder_inference_pattern_conventions():

@@ -21,7 +21,8 @@ def _inputs(hp, g):
 def test_numpy_oracle_reproduces_golden(name):
     hp, w, g = load_golden(name)
     tok, mels, ml, masks, noise = _inputs(hp, g)
-    out = oracle_np.inference_step(hp, w, tok, mels, ml, masks, noise, steps=int(g["steps"]), dt=np.float64)
+    out = oracle_np.inference_step(hp, w, tok, mels, ml, masks, noise, steps=int(g["steps"]), dt=np.float64, with_vocoder=True)
+    np.testing.assert_allclose(out[2], g["spectrograms"], atol=F32_STORE, rtol=0)
     np.testing.assert_allclose(out[0], g["mels"], atol=F32_STORE, rtol=0)
     np.testing.assert_allclose(out[1], g["stops"], atol=F32_STORE, rtol=0)
     np.testing.assert_allclose(out[3], g["alignments"], atol=F32_STORE, rtol=0)
@@ -36,7 +37,9 @@ def test_torch_restatement_matches_golden_in_fp32(name):
     """The independent torch-CPU restatement (the cpu_baseline "port") in float32: fp32 noise only."""
     hp, w, g = load_golden(name)
     tok, mels, ml, masks, noise = _inputs(hp, g)
-    out = torch_ref.TorchReference(hp, w, torch.float32).inference_step(tok, mels, ml, masks, noise, steps=int(g["steps"]))
+    out = torch_ref.TorchReference(hp, w, torch.float32).inference_step(tok, mels, ml, masks, noise, steps=int(g["steps"]),
+                                                                        with_vocoder=True)
+    assert np.abs(out[2].numpy() - g["spectrograms"]).max() < 5e-5
     assert np.abs(out[0].numpy() - g["mels"]).max() < 5e-5
     assert np.abs(out[3].numpy() - g["alignments"]).max() < 5e-5
     assert np.abs(out[1].numpy() - g["stops"]).max() < 5e-5
@@ -162,3 +165,29 @@ def test_masked_mode_extension_equals_running_each_utterance_alone(att):
         np.testing.assert_allclose(one[0][0], full[0][b], atol=1e-12)
         np.testing.assert_allclose(one[3][0], full[3][b][:, :n], atol=1e-12)
         assert not full[3][b][:, n:].any() and not full[4]["encoder"][b, n:].any()
+
+
+def test_vocoder_known_answers():
+    """CBHG pieces with hand-checkable answers (reference Taco2.py:383-424): the 'same' max-pool of width 2 looks one
+    frame AHEAD (TF pads after), a highway layer with a saturated-closed gate is the identity, and the conv bank
+    concatenates kernel sizes 1..N in order."""
+    x = np.array([[[1.0], [5.0], [2.0], [-3.0]]])
+    assert oracle_np.maxpool1d_same2(x).ravel().tolist() == [5.0, 5.0, 2.0, -3.0]
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=(2, 3, 8))
+    wr, br = rng.normal(size=(8, 8)), rng.normal(size=8)
+    closed = oracle_np.highway(v, wr, br, np.zeros((8, 8)), np.full(8, -80.0))
+    np.testing.assert_allclose(closed, v, atol=1e-12)
+    opened = oracle_np.highway(v, wr, br, np.zeros((8, 8)), np.full(8, 80.0))
+    np.testing.assert_allclose(opened, np.maximum(v @ wr + br, 0.0), atol=1e-12)
+
+
+def test_vocoder_output_shape_and_no_time_leak_across_batch():
+    hp = synthetic.tiny_hp()
+    w = oracle_np.cast_weights(weights.synthetic_weights(hp, seed=2), np.float64)
+    rng = np.random.default_rng(1)
+    mel = rng.normal(size=(3, 10, 16))
+    spec = oracle_np.vocoder_taco1(hp, w, mel, np.float64)
+    assert spec.shape == (3, 10, 21)
+    alone = oracle_np.vocoder_taco1(hp, w, mel[1:2], np.float64)
+    np.testing.assert_allclose(spec[1:2], alone, atol=1e-12)
