@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsttaco.so")
 
 MAX_LAYERS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 ATT_CODES = {"BMA": 0, "SMA": 1, "LSA": 2}
 
 # every symbol include/gsttaco.h declares
@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "gsttaco_abi_version", "gsttaco_create", "gsttaco_destroy", "gsttaco_last_error",
     "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight", "gsttaco_finalize_weights",
     "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder", "gsttaco_inference_step",
+    "gsttaco_mel_frontend", "gsttaco_mel_basis",
     "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_lstm_launch_bytes", "gsttaco_debug_stamps",
 )
 
@@ -52,6 +53,8 @@ class Config(ctypes.Structure):
         ("bank_filters", ctypes.c_int32), ("n_voc_proj", ctypes.c_int32), ("voc_proj_filters", _I32A),
         ("voc_proj_kernels", _I32A), ("highway_count", ctypes.c_int32), ("highway_size", ctypes.c_int32),
         ("voc_rnn", ctypes.c_int32),
+        ("sample_rate", ctypes.c_int32), ("frame_length", ctypes.c_int32), ("frame_shift", ctypes.c_int32),
+        ("max_abs_mel", ctypes.c_float), ("max_wav_samples", ctypes.c_int32),
         ("max_batch", ctypes.c_int32), ("max_tokens", ctypes.c_int32), ("max_ref_frames", ctypes.c_int32),
     ]
 
@@ -94,6 +97,8 @@ def load_library(path=None):
     lib.gsttaco_postnet.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.gsttaco_vocoder.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.gsttaco_inference_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.gsttaco_mel_frontend.argtypes = [vp, vp, vp, i32, i32, ctypes.c_float, vp, vp, i32, vp]
+    lib.gsttaco_mel_basis.argtypes = [vp, f32p]
     lib.gsttaco_set_profiling.argtypes = [vp, i32]
     lib.gsttaco_get_profile.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     lib.gsttaco_lstm_launch_bytes.argtypes = [vp, i32, i32]
@@ -102,14 +107,15 @@ def load_library(path=None):
     lib.gsttaco_debug_stamps.restype = ctypes.c_int
     for fn in ("gsttaco_create", "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight",
                "gsttaco_finalize_weights", "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder",
-               "gsttaco_inference_step", "gsttaco_set_profiling", "gsttaco_get_profile"):
+               "gsttaco_inference_step", "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_mel_frontend",
+               "gsttaco_mel_basis"):
         getattr(lib, fn).restype = ctypes.c_int
     if path is None:
         _lib = lib
     return lib
 
 
-def make_config(hp, vocab=None, device=0, max_batch=32, max_tokens=256, max_ref_frames=1025):
+def make_config(hp, vocab=None, device=0, max_batch=32, max_tokens=256, max_ref_frames=1025, max_wav_seconds=0.0):
     d = Dims(hp, vocab)
     c = Config()
     c.abi_version, c.device = ABI_VERSION, device
@@ -143,11 +149,17 @@ def make_config(hp, vocab=None, device=0, max_batch=32, max_tokens=256, max_ref_
             c.ref_filters[i], c.ref_kernels[i], c.ref_strides[i] = f, k, s
         c.ref_rnn, c.ref_dense, c.n_tokens = d.ref_rnn, d.ref_dense, d.n_tokens
         c.token_emb, c.heads, c.gst_att = d.token_emb, d.heads, d.gst_att
+    c.spec_dim = d.spec
+    if d.audio:
+        c.sample_rate, c.frame_length, c.frame_shift, c.max_abs_mel = d.sample_rate, d.frame_length, d.frame_shift, d.max_abs_mel
+        c.max_wav_samples = int(max_wav_seconds * d.sample_rate)
+    elif max_wav_seconds:
+        raise ValueError("Hyper_Parameters has no complete Sound section for the audio entry points")
     c.voc_use = int(d.vocoder)
     if d.vocoder:
         if len(d.voc_proj_filters) > MAX_LAYERS:
             raise ValueError("too many vocoder projection layers")
-        c.spec_dim, c.bank_count, c.bank_filters = d.spec, d.bank_count, d.bank_filters
+        c.bank_count, c.bank_filters = d.bank_count, d.bank_filters
         c.n_voc_proj = len(d.voc_proj_filters)
         for i, (f, k) in enumerate(zip(d.voc_proj_filters, d.voc_proj_kernels)):
             c.voc_proj_filters[i], c.voc_proj_kernels[i] = f, k
@@ -159,9 +171,10 @@ def make_config(hp, vocab=None, device=0, max_batch=32, max_tokens=256, max_ref_
 class Context:
     """RAII wrapper around gsttaco_ctx."""
 
-    def __init__(self, hp, vocab=None, device=0, max_batch=32, max_tokens=256, max_ref_frames=1025, lib=None):
+    def __init__(self, hp, vocab=None, device=0, max_batch=32, max_tokens=256, max_ref_frames=1025, lib=None,
+                 max_wav_seconds=0.0):
         self.lib = lib or load_library()
-        self.cfg = make_config(hp, vocab, device, max_batch, max_tokens, max_ref_frames)
+        self.cfg = make_config(hp, vocab, device, max_batch, max_tokens, max_ref_frames, max_wav_seconds)
         self.handle = ctypes.c_void_p()
         rc = self.lib.gsttaco_create(ctypes.byref(self.cfg), ctypes.byref(self.handle))
         if rc != 0:

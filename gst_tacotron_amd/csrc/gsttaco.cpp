@@ -105,6 +105,16 @@ struct gsttaco_ctx {
     float *w_vbank = nullptr, *w_vbuf[3] = {nullptr, nullptr, nullptr}, *w_vz = nullptr, *w_vrnn = nullptr, *w_vc = nullptr,
           *w_spec = nullptr;
 
+    // audio front / back end, initialised on first use
+    bool audio_ready = false;
+    int n_fft = 0;
+    std::vector<float> h_mel_basis;
+    float *a_window = nullptr, *a_mel_basis = nullptr;
+    float2* a_twiddle = nullptr;
+    int32_t *a_band_lo = nullptr, *a_band_hi = nullptr, *a_bounds = nullptr;
+    double* a_mse = nullptr;
+    int a_ld_mse = 0;
+
     // workspace
     int32_t *w_tokens = nullptr, *w_mel_len = nullptr, *w_tok_len = nullptr;
     float *w_mels_in = nullptr, *w_masks = nullptr, *w_noise = nullptr;
@@ -700,6 +710,92 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
     return 0;
 }
 
+// librosa.filters.mel(sr, n_fft, n_mels) with the 0.7.2 defaults the reference relies on (Audio.py:81-83): fmin 0,
+// fmax sr/2, Slaney scale (htk=False), area normalisation (norm=1), float32.  [n_mels, n_fft/2+1] row-major.
+std::vector<float> slaney_mel_basis(int sr, int n_fft, int n_mels) {
+    const int nb = n_fft / 2 + 1;
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    auto hz_to_mel = [&](double f) { return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp; };
+    auto mel_to_hz = [&](double m) { return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m; };
+    auto linspace = [](double a, double b, int n) {
+        std::vector<double> v(n);
+        const double step = (b - a) / (n - 1);
+        for (int i = 0; i < n; ++i) v[i] = i * step + a;
+        v[n - 1] = b;
+        return v;
+    };
+    const std::vector<double> fftfreqs = linspace(0.0, sr / 2.0, nb);
+    std::vector<double> mel_f = linspace(hz_to_mel(0.0), hz_to_mel(sr / 2.0), n_mels + 2);
+    for (double& m : mel_f) m = mel_to_hz(m);
+    std::vector<float> w((size_t)n_mels * nb, 0.f);
+    for (int i = 0; i < n_mels; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int k = 0; k < nb; ++k) {
+            const double lower = -(mel_f[i] - fftfreqs[k]) / fd0;
+            const double upper = (mel_f[i + 2] - fftfreqs[k]) / fd1;
+            const float tri = (float)std::max(0.0, std::min(lower, upper));     // stored in a float32 array first
+            w[(size_t)i * nb + k] = (float)((double)tri * enorm);               // then scaled in place
+        }
+    }
+    return w;
+}
+
+int ensure_device(gsttaco_ctx* c) {
+    const gsttaco_config& g = c->cfg;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= g.device)
+        return fail(c, GSTTACO_E_NO_DEVICE, "no HIP device: the gfx950 kernels are the only compute path (no CPU fallback)");
+    HIPCHECK(c, hipSetDevice(g.device));
+    hipDeviceProp_t prop;
+    HIPCHECK(c, hipGetDeviceProperties(&prop, g.device));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(c, GSTTACO_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    return 0;
+}
+
+void host_audio_tables(gsttaco_ctx* c) {
+    if (!c->h_mel_basis.empty()) return;
+    c->n_fft = 2 * (c->cfg.spec_dim - 1);
+    c->h_mel_basis = slaney_mel_basis(c->cfg.sample_rate, c->n_fft, c->cfg.mel_dim);
+}
+
+int ensure_audio(gsttaco_ctx* c) {
+    if (c->audio_ready) return 0;
+    const gsttaco_config& g = c->cfg;
+    if (g.max_wav_samples <= 0) return fail(c, GSTTACO_E_INVALID, "the context was created without audio capacity (max_wav_samples = 0)");
+    int rc = ensure_device(c);
+    if (rc) return rc;
+    host_audio_tables(c);
+    const int N = c->n_fft, H = N / 2, nb = H + 1;
+    // scipy.signal.get_window('hann', win, fftbins=True), zero-padded centred to n_fft (librosa.util.pad_center)
+    std::vector<float> win(N, 0.f);
+    const int wl = g.frame_length, lpad = (N - wl) / 2;
+    for (int i = 0; i < wl; ++i) win[lpad + i] = (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * i / wl));
+    std::vector<float> tw(2 * (size_t)H);
+    for (int k = 0; k < H; ++k) {
+        tw[2 * k] = (float)std::cos(-2.0 * M_PI * k / N);
+        tw[2 * k + 1] = (float)std::sin(-2.0 * M_PI * k / N);
+    }
+    std::vector<int32_t> lo(g.mel_dim), hi(g.mel_dim);
+    for (int m = 0; m < g.mel_dim; ++m) {
+        int a = nb, b = 0;
+        for (int k = 0; k < nb; ++k)
+            if (c->h_mel_basis[(size_t)m * nb + k] != 0.f) { a = std::min(a, k); b = std::max(b, k + 1); }
+        lo[m] = a < b ? a : 0; hi[m] = a < b ? b : 0;
+    }
+    if ((rc = upload(c, &c->a_window, win.data(), win.size()))) return rc;
+    if ((rc = upload(c, reinterpret_cast<float**>(&c->a_twiddle), tw.data(), tw.size()))) return rc;
+    if ((rc = upload(c, &c->a_mel_basis, c->h_mel_basis.data(), c->h_mel_basis.size()))) return rc;
+    if ((rc = upload(c, reinterpret_cast<float**>(&c->a_band_lo), reinterpret_cast<const float*>(lo.data()), lo.size()))) return rc;
+    if ((rc = upload(c, reinterpret_cast<float**>(&c->a_band_hi), reinterpret_cast<const float*>(hi.data()), hi.size()))) return rc;
+    c->a_ld_mse = g.max_wav_samples / 16 + 1;
+    if ((rc = dev_alloc(c, (void**)&c->a_mse, (size_t)g.max_batch * c->a_ld_mse * sizeof(double)))) return rc;
+    if ((rc = dev_alloc(c, (void**)&c->a_bounds, (size_t)g.max_batch * 2 * sizeof(int32_t)))) return rc;
+    c->audio_ready = true;
+    return 0;
+}
+
 // mel [B,Tf,mel] -> spectrogram [B,Tf,spec]  (reference Taco2.py:258-260, 366-380)
 int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* mel_in, float* spec) {
     const gsttaco_config& g = c->cfg;
@@ -892,6 +988,13 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
         if (g.voc_rnn < 16 || g.voc_rnn % 16) return bad("Vocoder_Taco1: RNN.Size must be a multiple of 16");
     }
     if (g.max_batch < 1 || g.max_tokens < 1 || (g.gst_use && g.max_ref_frames < 2)) return bad("bad capacity");
+    if (g.max_wav_samples > 0) {
+        const int n_fft = 2 * (g.spec_dim - 1);
+        if (g.spec_dim < 33 || n_fft > 8192 || (n_fft & (n_fft - 1))) return bad("Sound.Spectrogram_Dim must be 2^k + 1 with 64 <= n_fft <= 8192");
+        if (g.frame_length < 1 || g.frame_length > n_fft) return bad("Sound.Frame_Length must be in [1, n_fft]");
+        if (g.frame_shift < 1 || g.sample_rate < 1 || g.max_abs_mel < 0.f) return bad("bad Sound.Frame_Shift / Sample_Rate / Max_Abs_Mel");
+        if (g.max_wav_samples <= n_fft) return bad("max_wav_samples must exceed n_fft");
+    }
 
     gsttaco_ctx* c = new gsttaco_ctx();
     c->cfg = g;
@@ -1314,6 +1417,39 @@ int gsttaco_vocoder(gsttaco_ctx* c, const float* mel, int B, int Tf, float* spec
     GraphKey key{5, B, 0, 0, Tf, 0, 0, 0, 0};
     if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_vocoder(c, st, B, Tf, c->w_mel, c->w_spec); }))) return rc;
     HIPCHECK(c, hipMemcpyAsync(spectrogram, c->w_spec, (size_t)B * Tf * c->cfg.spec_dim * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int gsttaco_mel_frontend(gsttaco_ctx* c, const float* wav, const int32_t* wav_lengths, int B, int ld_wav, float top_db,
+                         float* mels_for_gst, int32_t* mel_lengths, int cap_frames, void* stream) {
+    if (!c) return GSTTACO_E_INVALID;
+    int rc = ensure_audio(c);
+    if (rc) return rc;
+    const gsttaco_config& g = c->cfg;
+    if (!wav || !wav_lengths || !mels_for_gst || !mel_lengths) return fail(c, GSTTACO_E_INVALID, "null argument");
+    if (B < 1 || ld_wav < 17 || !(top_db > 0.f)) return fail(c, GSTTACO_E_INVALID, "bad B / ld_wav / top_db");
+    if (B > g.max_batch || ld_wav > g.max_wav_samples) return fail(c, GSTTACO_E_CAPACITY, "batch / samples exceed capacity");
+    if (cap_frames < 2 + ld_wav / g.frame_shift) return fail(c, GSTTACO_E_INVALID, "cap_frames must be >= 2 + ld_wav / Frame_Shift");
+    AudioFrontArgs a{};
+    a.wav = wav; a.wav_len = wav_lengths; a.mse = c->a_mse; a.bounds = c->a_bounds;
+    a.mels = mels_for_gst; a.mel_len = mel_lengths;
+    a.window = c->a_window; a.twiddle = c->a_twiddle; a.mel_basis = c->a_mel_basis; a.band_lo = c->a_band_lo; a.band_hi = c->a_band_hi;
+    a.B = B; a.ld_wav = ld_wav; a.ld_mse = c->a_ld_mse; a.cap_frames = cap_frames;
+    a.n_fft = c->n_fft; a.log2_h = 0;
+    while ((1 << a.log2_h) < c->n_fft / 2) ++a.log2_h;
+    a.hop = g.frame_shift; a.n_mels = g.mel_dim;
+    a.trim_frame = 32; a.trim_hop = 16;                 // Pattern_Generator.py:45
+    a.preemph = 0.97f; a.trim_gain = 0.99f;             // Audio.py:11, Pattern_Generator.py:45
+    a.top_db = top_db; a.max_abs = g.max_abs_mel;
+    HIPCHECK(c, gt_launch_audio_front(a, (hipStream_t)stream));
+    return 0;
+}
+
+int gsttaco_mel_basis(gsttaco_ctx* c, float* host_out) {
+    if (!c || !host_out) return GSTTACO_E_INVALID;
+    if (c->cfg.spec_dim < 2 || c->cfg.sample_rate < 1) return fail(c, GSTTACO_E_INVALID, "Sound.Spectrogram_Dim / Sample_Rate not set");
+    host_audio_tables(c);
+    memcpy(host_out, c->h_mel_basis.data(), c->h_mel_basis.size() * sizeof(float));
     return 0;
 }
 

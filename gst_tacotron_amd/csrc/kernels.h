@@ -172,3 +172,22 @@ struct GstTailArgs {
     int B, T2, gru_in, u, D, A, ntok, heads, stride_prod;
 };
 hipError_t gt_launch_gst_tail(const GstTailArgs& a, hipStream_t stream);
+
+// ---------------------------------------------------------------- audio.hip
+struct AudioFrontArgs {
+    const float* wav;           // [B, ld_wav] float samples in [-1, 1)
+    const int32_t* wav_len;     // [B]
+    double* mse;                // [B, ld_mse] workspace: trim frame mean-squares
+    int32_t* bounds;            // [B, 2] workspace: trimmed (start, length) in samples
+    float* mels;                // [B, cap_frames, n_mels] mels_for_gst layout (frame 0 = zeros)
+    int32_t* mel_len;           // [B] frames excluding the prepended one
+    const float* window;        // [n_fft] hann (periodic), zero-padded centred to n_fft
+    const float2* twiddle;      // [n_fft/2] exp(-2 pi i k / n_fft)
+    const float* mel_basis;     // [n_mels, n_fft/2+1]
+    const int32_t* band_lo;     // [n_mels] first non-zero bin of each band
+    const int32_t* band_hi;     // [n_mels] one past the last non-zero bin
+    int B, ld_wav, ld_mse, cap_frames, n_fft, log2_h, hop, n_mels, trim_frame, trim_hop;
+    float preemph, trim_gain, top_db, max_abs;
+};
+hipError_t gt_launch_audio_front(const AudioFrontArgs& a, hipStream_t stream);
+

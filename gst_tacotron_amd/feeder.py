@@ -1,9 +1,11 @@
 """Inference-side input conventions of the reference Feeder (reference Feeder.py:161-252).
 
 Only what the hot path's caller needs: tokenise / pad, zero ``initial_mels``, and the
-``mels_for_gst`` batch layout (a zero frame is prepended, lengths exclude it).  The wav ->
-mel front-end (Pattern_Generator.Mel_Generate, librosa) is a later row, so
-reference audio is accepted as precomputed mel arrays ``[T, Mel_Dim]`` in [-Max_Abs_Mel, Max_Abs_Mel].
+``mels_for_gst`` batch layout (a zero frame is prepended, lengths exclude it).  Reference audio is given
+like in the reference as wav paths (or 1-D sample arrays): the wav -> mel front end
+(Pattern_Generator.Mel_Generate) then runs on the GPU through the ``mel_frontend`` callable the
+model installs, and ``mels_for_gst`` comes back as a device tensor.  Precomputed mel arrays ``[T, Mel_Dim]``
+in [-Max_Abs_Mel, Max_Abs_Mel] are accepted too (no GPU involved).
 """
 import numpy as np
 
@@ -11,9 +13,20 @@ from .hparams import load_token_dict
 
 
 class Feeder:
-    def __init__(self, hp, token_index_dict=None):
+    def __init__(self, hp, token_index_dict=None, mel_frontend=None):
         self.hp = hp
         self.token_Index_Dict = token_index_dict or load_token_dict(hp)
+        self.mel_frontend = mel_frontend          # callable(wav_List, top_db) -> (mels_for_gst, mel_lengths_for_gst)
+
+    @staticmethod
+    def _is_mel(item):
+        return not isinstance(item, (str, bytes)) and not hasattr(item, "__fspath__") and np.ndim(item) == 2
+
+    def _from_wavs(self, wav_List, top_db):
+        if self.mel_frontend is None:
+            raise RuntimeError("wav inputs need the GPU mel front end (GST_Tacotron installs it); there is no CPU path")
+        mels, lens = self.mel_frontend(wav_List, top_db)
+        return {"mels_for_gst": mels, "mel_lengths_for_gst": lens}
 
     def Get_Inference_Pattern(self, sentence_List, mel_List_for_GST=None):
         """reference Feeder.py:161-227.  Out-of-vocabulary characters raise KeyError like the
@@ -42,13 +55,24 @@ class Feeder:
                 print("The length of wav_List_for_GST must be 1 or same to the length of sentence_List "
                       "and wav_List_for_GST must be same.")                                 # :200-202
                 return None
-            pattern.update(self.Get_Inference_GST_Pattern(
-                list(mel_List_for_GST) * (pattern_Count if len(mel_List_for_GST) == 1 else 1)))
+            items = list(mel_List_for_GST)
+            if all(self._is_mel(m) for m in items):
+                pattern.update(self.Get_Inference_GST_Pattern(items * (pattern_Count if len(items) == 1 else 1)))
+            elif len(items) == 1:
+                # one reference wav for every sentence: top_db 60, the mel is repeated (Feeder.py:204-207)
+                one = self._from_wavs(items, 60)
+                pattern["mels_for_gst"] = one["mels_for_gst"].expand(pattern_Count, -1, -1).contiguous()
+                pattern["mel_lengths_for_gst"] = one["mel_lengths_for_gst"].expand(pattern_Count).contiguous()
+            else:
+                pattern.update(self._from_wavs(items, 15))        # several wavs: top_db 15 (Feeder.py:209)
         return pattern
 
     def Get_Inference_GST_Pattern(self, mel_List):
-        """reference Feeder.py:229-252: zero-pad to the longest mel, PREPEND one zero frame."""
+        """reference Feeder.py:229-252: zero-pad to the longest mel, PREPEND one zero frame.  Wav paths / sample
+        arrays go through the GPU front end with top_db 60 (Feeder.py:232)."""
         mel_dim = self.hp["Sound"]["Mel_Dim"]
+        if not all(self._is_mel(m) for m in mel_List):
+            return self._from_wavs(list(mel_List), 60)
         mel_List = [np.asarray(m, dtype=np.float32) for m in mel_List]
         for m in mel_List:
             if m.ndim != 2 or m.shape[1] != mel_dim or m.shape[0] < 1:

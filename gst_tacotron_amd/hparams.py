@@ -120,6 +120,14 @@ class Dims:
         else:
             self.mem = self.enc_out
         self.proj_out = self.mel * self.r + 1           # Taco2.py:88
+        # Sound: audio front / back end (reference Audio.py, Pattern_Generator.py:39-60): SURVEY rows N2 / N4
+        snd = hp["Sound"]
+        self.spec = int(snd.get("Spectrogram_Dim", 0))
+        self.sample_rate = int(snd.get("Sample_Rate", 0))
+        self.frame_length = int(snd.get("Frame_Length", 0))
+        self.frame_shift = int(snd.get("Frame_Shift", 0))
+        self.max_abs_mel = float(snd.get("Max_Abs_Mel") or 0.0)
+        self.audio = self.spec > 1 and self.sample_rate > 0 and self.frame_length > 0 and self.frame_shift > 0
         # CBHG vocoder (reference Taco2.py:234-260, 285-424): SURVEY row N1, optional third output of Inference_Step
         self.vocoder = "Vocoder_Taco1" in hp
         if self.vocoder:

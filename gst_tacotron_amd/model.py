@@ -34,19 +34,20 @@ def _ptr(t):
 
 class GST_Tacotron:
     def __init__(self, is_Training=False, hyper_parameters=None, device=None,
-                 max_batch=32, max_tokens=256, max_ref_frames=1025):
+                 max_batch=32, max_tokens=256, max_ref_frames=1025, max_wav_seconds=20.0):
         if is_Training:
             raise NotImplementedError("only the inference hot path is implemented (training is out of scope)")
         self.hp_Dict = load_hp(hyper_parameters)
         self.token_Index_Dict = load_token_dict(self.hp_Dict)
         self.dims = Dims(self.hp_Dict, vocab=len(self.token_Index_Dict))
-        self.feeder = Feeder(self.hp_Dict, self.token_Index_Dict)
+        self.feeder = Feeder(self.hp_Dict, self.token_Index_Dict, mel_frontend=self.Mel_Generate)
         if device is None:
             dev = self.hp_Dict.get("Device", "0")
             device = int(dev) if str(dev).lstrip("-").isdigit() and int(dev) >= 0 else 0
         self.device_index = int(device)
         self.ctx = capi.Context(self.hp_Dict, vocab=len(self.token_Index_Dict), device=self.device_index,
-                                max_batch=max_batch, max_tokens=max_tokens, max_ref_frames=max_ref_frames)
+                                max_batch=max_batch, max_tokens=max_tokens, max_ref_frames=max_ref_frames,
+                                max_wav_seconds=max_wav_seconds if self.dims.audio else 0.0)
         self._ready = False
         self.seed = 0
 
@@ -149,6 +150,13 @@ class GST_Tacotron:
             return mel, stop, spec, align, pre
         return mel, stop, spec, align
 
+    def Inference_GST(self, wav_List, tag_List=None, label=None):
+        """reference Model.py:427-446 without the TSV export thread: style embeddings [B, Attention.Size] of the wavs."""
+        if not self.hp_Dict["GST"]["Use"]:
+            raise NotImplementedError("GST is not used")
+        print("GST Inference running...")
+        return self.Inference_GST_Step(**self.feeder.Get_Inference_GST_Pattern(wav_List))
+
     def Inference_GST_Step(self, mels_for_gst, mel_lengths_for_gst):
         """reference Model.py:257-265"""
         if not self.hp_Dict["GST"]["Use"]:
@@ -162,10 +170,41 @@ class GST_Tacotron:
             self.ctx.check(self.ctx.lib.gsttaco_gst(self.ctx.handle, _ptr(mels), _ptr(lens), B, Tref1, _ptr(gst), self._stream()))
         return gst
 
-    def Inference(self, sentence_List, mel_List_for_GST=None, label=None, **kwargs):
-        """reference Model.py:342-367 (the export thread -- plots / Griffin-Lim wavs -- is out of scope)."""
+    def Mel_Generate(self, wav_List, top_db=60):
+        """Batched reference Pattern_Generator.Mel_Generate(path, top_db, range_Ignore=True) (Pattern_Generator.py:39-60)
+        on the GPU, already in the mels_for_gst layout of Feeder.py:204-225: returns (mels_for_gst [B, 1+max_len, Mel_Dim]
+        with a zero frame 0 and zero padding, mel_lengths_for_gst [B]) as device tensors.  ``wav_List`` holds wav paths
+        or 1-D float sample arrays at Sound.Sample_Rate.  Works before Restore (no weights involved)."""
+        from .audio import as_signal
+        d = self.dims
+        if not d.audio or not self.ctx.cfg.max_wav_samples:
+            raise ValueError("the audio front end needs the Sound section of Hyper_Parameters and max_wav_seconds > 0")
+        if not torch.cuda.is_available():
+            raise capi.GstTacoError(-2, "no HIP device: the gfx950 kernels are the only compute path (no CPU fallback)")
+        sigs = [as_signal(w, d.sample_rate) for w in wav_List]
+        B, ld = len(sigs), max(s.shape[0] for s in sigs)
+        host = np.zeros((B, ld), dtype=np.float32)
+        for i, s_ in enumerate(sigs):
+            host[i, :s_.shape[0]] = s_
+        wav = torch.from_numpy(host).to(self.device)
+        lens = torch.tensor([s_.shape[0] for s_ in sigs], dtype=torch.int32, device=self.device)
+        cap = 2 + ld // d.frame_shift
+        mels = torch.empty((B, cap, d.mel), dtype=torch.float32, device=self.device)
+        mel_len = torch.empty((B,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.ctx.check(self.ctx.lib.gsttaco_mel_frontend(
+                self.ctx.handle, _ptr(wav), _ptr(lens), B, ld, ctypes.c_float(float(top_db)), _ptr(mels), _ptr(mel_len), cap,
+                self._stream()))
+        n = int(mel_len.max().item())            # the one host sync: the output length is data dependent (trim)
+        if int(mel_len.min().item()) < 1:
+            raise ValueError("a reference wav is shorter than n_fft/2 samples after trimming (librosa.stft raises there)")
+        return mels[:, :n + 1].contiguous(), mel_len
+
+    def Inference(self, sentence_List, wav_List_for_GST=None, label=None, **kwargs):
+        """reference Model.py:342-367 (the export thread -- plots / Griffin-Lim wavs -- is a separate call).
+        ``wav_List_for_GST`` holds wav paths / 1-D sample arrays like the reference's, or precomputed mels [T, Mel_Dim]."""
         print("Inference running...")
-        pattern_Dict = self.feeder.Get_Inference_Pattern(sentence_List, mel_List_for_GST)
+        pattern_Dict = self.feeder.Get_Inference_Pattern(sentence_List, wav_List_for_GST)
         if pattern_Dict is None:
             print("Inference fail.")
             return None

@@ -102,7 +102,8 @@ def tiny_hp(att_type="SMA", r=2, gst=True, max_step=24, prenet_rate=0.5):
     dec["RNN"]["Size"] = [64, 64]
     dec["Attention"] = {"Type": att_type, "Size": 16}
     dec["Conv"]["Filters"] = [32, 32, 32, 32]
-    hp["Sound"]["Spectrogram_Dim"] = 21            # deliberately not a multiple of 4 (the real one is 513)
+    hp["Sound"]["Spectrogram_Dim"] = 33            # n_fft 64; like the real 513 not a multiple of 4
+    hp["Sound"]["Frame_Length"], hp["Sound"]["Frame_Shift"] = 64, 16
     hp["Vocoder_Taco1"]["CBHG"] = {"Conv_Bank": {"Stack_Count": 4, "Filters": 16}, "Pool": {"Pool_Size": 2, "Strides": 1},
                                    "Conv1D": {"Filters": [32, 32], "Kernel_Size": [3, 3]},
                                    "Highwaynet": {"Count": 2, "Size": 32}, "RNN": {"Size": 16, "Zoneout": 0.0}}

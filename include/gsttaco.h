@@ -18,6 +18,9 @@
  *                          Modules/Attention/Steps.py:107-229 (BMA / SMA)
  *   gsttaco_postnet     <- Modules/Taco2.py:131-149, 230
  *   gsttaco_vocoder     <- Modules/Taco2.py:234-260 Vocoder_Taco1.call, CBHG :285-380
+ *   gsttaco_mel_frontend <- Pattern_Generator.py:39-60 Mel_Generate + Audio.py:29-32,49-55,70-96 melspectrogram
+ *                          + the batch layout of Feeder.py:204-225 / 229-250
+ *   gsttaco_mel_basis   <- Audio.py:81-83 _build_mel_basis (librosa.filters.mel); host-side getter for tests
  *
  * Conventions
  *   - every function returns 0 on success or a negative GSTTACO_E_* code; nothing throws
@@ -38,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 4
+#define GSTTACO_ABI_VERSION 5
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -109,6 +112,12 @@ typedef struct gsttaco_config {
     int32_t highway_count;
     int32_t highway_size;
     int32_t voc_rnn;            /* CBHG.RNN.Size (per direction) */
+    /* Sound: audio front end (wav -> mels_for_gst) and back end (spectrogram -> wav, row N4); optional */
+    int32_t sample_rate;        /* Sound.Sample_Rate */
+    int32_t frame_length;       /* Sound.Frame_Length (STFT window, <= n_fft = 2 * (Spectrogram_Dim - 1)) */
+    int32_t frame_shift;        /* Sound.Frame_Shift (hop) */
+    float   max_abs_mel;        /* Sound.Max_Abs_Mel; 0 = the [0,1] normalisation (Audio.py:92-93) */
+    int32_t max_wav_samples;    /* capacity of the audio entry points per utterance; 0 = disabled */
     /* capacity: workspace is sized once, at finalize */
     int32_t max_batch;
     int32_t max_tokens;
@@ -164,6 +173,22 @@ int gsttaco_postnet(gsttaco_ctx* ctx, const float* pre_mel, int B, int T, float*
 /* mel [B,T,mel] (the post-net mel) -> spectrogram [B,T,spec_dim]: Vocoder_Taco1 = CBHG (conv bank k=1..N + BN + ReLU,
  * max-pool 2/1, two projection convs, residual, highway stack, BiLSTM) + Dense (reference Taco2.py:234-260, 285-424). */
 int gsttaco_vocoder(gsttaco_ctx* ctx, const float* mel, int B, int T, float* spectrogram, void* stream);
+
+/* wav -> mels_for_gst without leaving the GPU and without needing weights (works before finalize).
+ * Needs cfg.max_wav_samples > 0.  Reference: Mel_Generate(path, top_db, range_Ignore=True) per utterance
+ * (Pattern_Generator.py:39-60; top_db is 60 for one reference wav and 15 for several, Feeder.py:204-209, and 60 in
+ * Get_Inference_GST_Pattern, Feeder.py:232), stacked as Feeder does: frame 0 of every utterance is zero, frames
+ * 1..mel_lengths[b] hold the mel, the rest is zero padding.
+ * wav          : [B, ld_wav] float32 samples in [-1,1) at Sound.Sample_Rate (librosa.load's output; resampling is the
+ *                caller's job), wav_lengths [B] valid samples (17 <= length <= max_wav_samples)
+ * mels_for_gst : [B, cap_frames, mel_dim] with cap_frames >= 2 + ld_wav / frame_shift
+ * mel_lengths  : [B] int32, frames EXCLUDING the prepended one; 0 when the trimmed signal is shorter than n_fft/2+1
+ *                samples (librosa.stft raises there) */
+int gsttaco_mel_frontend(gsttaco_ctx* ctx, const float* wav, const int32_t* wav_lengths, int B, int ld_wav, float top_db,
+                         float* mels_for_gst, int32_t* mel_lengths, int cap_frames, void* stream);
+
+/* host_out [mel_dim, spec_dim] float32 <- the Slaney mel filterbank the front end uses (librosa.filters.mel defaults) */
+int gsttaco_mel_basis(gsttaco_ctx* ctx, float* host_out);
 
 /* The whole Inference_Step (Model.py:249-255): encoder, GST, decode loop, postnet and -- when `spectrogram` is not
  * NULL -- the CBHG vocoder, replayed from one cached hipGraph per (B,Tv,Tref1,steps) shape.

@@ -1,0 +1,235 @@
+"""Audio front end: oracle vs the committed fixtures and independent cross-checks on CPU;
+the HIP front end (through the C-ABI) vs the oracle on the GPU."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gst_tacotron_amd import capi, hparams, synthetic
+from oracle import audio_np as A
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+F32_STORE = 1e-6
+# GPU: float32 FFT / log10 against the float64 oracle.  Mel values span [-4, 4] (8 units per 100 dB); a 1e-6 relative
+# amplitude error is 7e-7 units, but bands at the 1e-5 amplitude floor amplify absolute FFT noise, hence 2e-3.
+MEL_TOL = 2e-3
+
+
+def _sound(name):
+    g = np.load(os.path.join(GOLD, "audio_synth_%s.npz" % name))
+    return g, json.loads(str(g["sound_json"]))
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_oracle_reproduces_real_speech_fixture():
+    g = np.load(os.path.join(GOLD, "audio_fv_ksp.npz"))
+    y = g["pcm"].astype(np.float32) / 32768.0
+    snd = hparams.load_hp()["Sound"]
+    for top_db in (60, 15):
+        assert tuple(A.trim_bounds(A.preemphasis(y), top_db, 32, 16)) == tuple(g["bounds_%d" % top_db])
+        mel = A.mel_generate(y, snd, top_db)
+        assert mel.dtype == np.float32 and mel.shape == g["mel_%d" % top_db].shape
+        np.testing.assert_allclose(mel, g["mel_%d" % top_db], atol=F32_STORE, rtol=0)
+    assert g["mel_60"].shape == (115, 80) and np.abs(g["mel_60"]).max() <= 4.0      # 115 frames for this wav
+
+
+@pytest.mark.parametrize("name", ["tiny", "full"])
+def test_oracle_reproduces_synthetic_fixtures(name):
+    g, snd = _sound(name)
+    for i in range(int(g["n"])):
+        for top_db in (60, 15):
+            np.testing.assert_allclose(A.mel_generate(g["sig%d" % i], snd, top_db), g["mel%d_%d" % (i, top_db)],
+                                       atol=F32_STORE, rtol=0)
+
+
+def test_stft_matches_scipy():
+    """Independent check of the restated librosa.stft: scipy.signal.stft on the reflect-padded signal, rescaled."""
+    from scipy import signal
+    y = np.random.default_rng(0).normal(size=5000)
+    for n_fft, hop, win in ((1024, 256, 1024), (64, 16, 64), (256, 64, 200)):
+        D = A.stft(y, n_fft, hop, win)
+        w = A.pad_center(A.hann_periodic(win), n_fft)
+        _, _, Z = signal.stft(np.pad(y, n_fft // 2, mode="reflect"), window=w, nperseg=n_fft, noverlap=n_fft - hop,
+                              nfft=n_fft, boundary=None, padded=False)
+        Z = Z * w.sum()
+        assert D.shape == Z.shape == (n_fft // 2 + 1, 1 + len(y) // hop)
+        assert np.abs(D - Z).max() < 1e-4 * np.abs(Z).max()          # complex64 storage
+
+
+def test_istft_inverts_stft():
+    y = np.random.default_rng(1).normal(size=4096).astype(np.float32)
+    z = A.istft(A.stft(y, 1024, 256, 1024), 256, 1024)
+    assert z.shape == y.shape and np.abs(z - y).max() < 1e-5
+
+
+def test_preemphasis_pair_is_the_identity():
+    """Why the HIP front end has no IIR pass: inv_preemphasis then preemphasis from the same first sample is exact."""
+    x = np.random.default_rng(2).normal(size=3000)
+    np.testing.assert_allclose(A.preemphasis(A.inv_preemphasis(x)), x, atol=1e-12)
+    np.testing.assert_allclose(A.inv_preemphasis(A.preemphasis(x)), x, atol=1e-10)
+    assert A.preemphasis(np.array([1.0, 1.0, 1.0])).tolist() == [1.0, 1.0 - 0.97, 1.0 - 0.97]
+
+
+def test_mel_basis_is_slaney_area_normalised_triangles():
+    B = A.mel_basis(16000, 1024, 80)
+    assert B.shape == (80, 513) and B.dtype == np.float32 and (B >= 0).all()
+    assert ((B > 0).sum(0) <= 2).all()                       # adjacent triangles: a bin feeds at most two bands
+    peaks = B.argmax(1)
+    assert (np.diff(peaks) > 0).all()
+    for m in range(80):                                       # unimodal rows
+        nz = np.flatnonzero(B[m])
+        assert (np.diff(nz) == 1).all()
+        k = peaks[m]
+        assert (np.diff(B[m, nz[0]:k + 1]) >= 0).all() and (np.diff(B[m, k:nz[-1] + 1]) <= 0).all()
+    df = 16000 / 1024
+    assert np.abs(B[40:].sum(1) * df - 1.0).max() < 0.02      # area 1 in Hz (wide bands: sampling error is small)
+    # below 1 kHz the Slaney scale is linear: equally spaced centres (up to bin rounding)
+    assert np.ptp(np.diff(peaks[:15])) <= 1
+
+
+def test_trim_bounds_known_answer():
+    sr = 16000
+    y = np.zeros(sr, dtype=np.float64)
+    y[4000:8000] = np.sin(2 * np.pi * 440 * np.arange(4000) / sr)
+    s, e = A.trim_bounds(y, 60, 32, 16)
+    assert 4000 - 32 <= s <= 4000 and 8000 <= e <= 8000 + 32 and s % 16 == 0
+    assert A.trim_bounds(np.zeros(1000), 60, 32, 16) == (0, 1000)        # all frames tie with the max: nothing is trimmed
+
+
+def test_library_mel_basis_equals_the_oracle():
+    """gsttaco_mel_basis is host code (C++ restatement of librosa.filters.mel): checkable without a GPU."""
+    for hp in (hparams.load_hp(), synthetic.tiny_hp()):
+        ctx = capi.Context(hp, max_batch=1, max_tokens=4, max_ref_frames=4, max_wav_seconds=1.0)
+        d = hparams.Dims(hp)
+        out = np.zeros((d.mel, d.spec), dtype=np.float32)
+        ctx.check(ctx.lib.gsttaco_mel_basis(ctx.handle, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        ref = A.mel_basis(d.sample_rate, 2 * (d.spec - 1), d.mel)
+        assert np.abs(out - ref).max() <= 1e-9 and ((out != 0) == (ref != 0)).all()
+        ctx.close()
+
+
+def test_audio_config_validation_and_no_cpu_path(tmp_path):
+    hp = synthetic.tiny_hp()
+    hp["Sound"]["Spectrogram_Dim"] = 21                     # n_fft 40 is not a power of two
+    with pytest.raises(capi.GstTacoError, match="Spectrogram_Dim"):
+        capi.Context(hp, max_batch=1, max_tokens=4, max_ref_frames=4, max_wav_seconds=1.0)
+    capi.Context(hp, max_batch=1, max_tokens=4, max_ref_frames=4).close()     # fine while the audio entry points are off
+    from gst_tacotron_amd.feeder import Feeder
+    f = Feeder(hparams.load_hp())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        f.Get_Inference_GST_Pattern([np.zeros(4000, np.float32)])
+    import torch
+    if not torch.cuda.is_available():
+        from gst_tacotron_amd.model import GST_Tacotron
+        m = GST_Tacotron(hyper_parameters=synthetic.tiny_hp(), max_batch=2, max_tokens=8, max_ref_frames=9)
+        with pytest.raises(capi.GstTacoError, match="no CPU fallback"):
+            m.Mel_Generate([np.zeros(4000, np.float32)])
+
+
+def test_load_wav_matches_librosa_load_conventions(tmp_path):
+    from scipy.io import wavfile
+    from gst_tacotron_amd.audio import load_wav
+    pcm = (np.random.default_rng(3).integers(-2000, 2000, 4000)).astype(np.int16)
+    p = str(tmp_path / "a.wav")
+    wavfile.write(p, 16000, pcm)
+    y = load_wav(p, 16000)
+    assert y.dtype == np.float32 and np.array_equal(y, pcm.astype(np.float32) / 32768.0)
+    assert np.array_equal(y, A.load_wav(p, 16000))
+    wavfile.write(p, 16000, np.stack([pcm, -pcm], 1))       # stereo -> channel mean
+    assert np.abs(load_wav(p, 16000)).max() == 0.0
+    wavfile.write(p, 8000, pcm)                              # other rate: resampled to Sound.Sample_Rate
+    assert abs(load_wav(p, 16000).shape[0] - 8000) <= 1
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _model(hp, B):
+    from gst_tacotron_amd.model import GST_Tacotron
+    return GST_Tacotron(hyper_parameters=hp, max_batch=B, max_tokens=8, max_ref_frames=4, max_wav_seconds=4.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("top_db", [60, 15])
+def test_gpu_front_end_matches_oracle_on_real_speech(top_db):
+    import torch
+    g = np.load(os.path.join(GOLD, "audio_fv_ksp.npz"))
+    y = g["pcm"].astype(np.float32) / 32768.0
+    m = _model(hparams.load_hp(), 2)
+    mels, lens = m.Mel_Generate([y, y[:20000]], top_db)          # no Restore needed: no weights on this path
+    torch.cuda.synchronize()
+    exp = g["mel_%d" % top_db]
+    assert int(lens[0]) == exp.shape[0]
+    got = mels[0, 1:1 + exp.shape[0]].cpu().numpy()
+    err = np.abs(got - exp).max()
+    print("front end top_db", top_db, "max abs err", err)
+    assert err <= MEL_TOL
+    assert float(mels[:, 0].abs().max()) == 0.0                  # prepended zero frame (Feeder.py:219-223)
+    n1 = int(lens[1])
+    assert float(mels[1, 1 + n1:].abs().max()) == 0.0           # zero padding after the shorter utterance
+    ref1 = A.mel_generate(y[:20000], hparams.load_hp()["Sound"], top_db)
+    assert n1 == ref1.shape[0] and np.abs(mels[1, 1:1 + n1].cpu().numpy() - ref1).max() <= MEL_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "full"])
+def test_gpu_front_end_matches_oracle_on_ragged_batches(name):
+    import torch
+    g, snd = _sound(name)
+    hp = synthetic.tiny_hp() if name == "tiny" else hparams.load_hp()
+    assert hp["Sound"]["Spectrogram_Dim"] == snd["Spectrogram_Dim"]
+    n = int(g["n"])
+    m = _model(hp, n)
+    sigs = [g["sig%d" % i] for i in range(n)]
+    for top_db in (60, 15):
+        mels, lens = m.Mel_Generate(sigs, top_db)
+        torch.cuda.synchronize()
+        worst = 0.0
+        for i in range(n):
+            exp = g["mel%d_%d" % (i, top_db)]
+            assert int(lens[i]) == exp.shape[0], (i, top_db)     # the trim decision is taken in float64 like the reference
+            worst = max(worst, float(np.abs(mels[i, 1:1 + exp.shape[0]].cpu().numpy() - exp).max()))
+            assert float(mels[i, 1 + exp.shape[0]:].abs().max() if mels.shape[1] > 1 + exp.shape[0] else 0.0) == 0.0
+        print(name, top_db, "max abs err", worst)
+        assert worst <= MEL_TOL
+
+
+@pytest.mark.gpu
+def test_gpu_wav_to_style_embedding_and_inference_with_wav_references(tmp_path):
+    """Feeder conventions with wav inputs (Feeder.py:197-225, 229-250): one wav -> top_db 60 and repeated; several ->
+    top_db 15; Inference_GST on wavs == the oracle's style_token_layer on the oracle's mels."""
+    import torch
+    from scipy.io import wavfile
+    from gst_tacotron_amd import weights
+    from gst_tacotron_amd.model import GST_Tacotron
+    from oracle import oracle_np
+    hp = hparams.load_hp()
+    hp["Max_Step"] = 8
+    g = np.load(os.path.join(GOLD, "audio_fv_ksp.npz"))
+    paths = []
+    for i, cut in enumerate((29360, 24000)):
+        p = str(tmp_path / ("r%d.wav" % i))
+        wavfile.write(p, 16000, g["pcm"][:cut])
+        paths.append(p)
+    w = weights.synthetic_weights(hp, seed=1)
+    m = GST_Tacotron(hyper_parameters=hp, max_batch=2, max_tokens=32, max_ref_frames=260, max_wav_seconds=4.0)
+    m.Restore(weights=w)
+    gst = m.Inference_GST(paths)
+    torch.cuda.synchronize()
+    w64 = oracle_np.cast_weights(w, np.float64)
+    ref_mels = [A.mel_generate(g["pcm"][:cut].astype(np.float32) / 32768.0, hp["Sound"], 60) for cut in (29360, 24000)]
+    batch = np.zeros((2, 1 + max(x.shape[0] for x in ref_mels), 80))           # Feeder.py:234-248: zero pad + prepended frame
+    for i, x in enumerate(ref_mels):
+        batch[i, 1:1 + x.shape[0]] = x
+    # (the zero padding is seen by the reference encoder's convolutions: an utterance inside a batch is NOT the
+    #  utterance alone -- reference behaviour, SURVEY F5 -- so the oracle runs on the same padded batch)
+    ref = oracle_np.style_token_layer(hp, w64, batch, np.array([x.shape[0] for x in ref_mels]), np.float64)
+    assert np.abs(gst.cpu().numpy() - ref).max() <= 1e-3
+    pat = m.feeder.Get_Inference_Pattern(["Hello there.", "Second one."], [paths[0]])
+    assert pat["mels_for_gst"].shape[0] == 2 and int(pat["mel_lengths_for_gst"][0]) == 115
+    assert torch.equal(pat["mels_for_gst"][0], pat["mels_for_gst"][1])
+    pat2 = m.feeder.Get_Inference_Pattern(["Hello there.", "Second one."], paths)
+    assert int(pat2["mel_lengths_for_gst"][0]) == 88                    # top_db 15 for several references
+    out = m.Inference(["Hello there.", "Second one."], paths)
+    torch.cuda.synchronize()
+    assert out[0].shape == (2, 8, 80) and torch.isfinite(out[0]).all()

@@ -188,6 +188,6 @@ def test_vocoder_output_shape_and_no_time_leak_across_batch():
     rng = np.random.default_rng(1)
     mel = rng.normal(size=(3, 10, 16))
     spec = oracle_np.vocoder_taco1(hp, w, mel, np.float64)
-    assert spec.shape == (3, 10, 21)
+    assert spec.shape == (3, 10, 33)
     alone = oracle_np.vocoder_taco1(hp, w, mel[1:2], np.float64)
     np.testing.assert_allclose(spec[1:2], alone, atol=1e-12)
