@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "gsttaco_abi_version", "gsttaco_create", "gsttaco_destroy", "gsttaco_last_error",
     "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight", "gsttaco_finalize_weights",
     "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder", "gsttaco_inference_step",
-    "gsttaco_mel_frontend", "gsttaco_mel_basis",
+    "gsttaco_mel_frontend", "gsttaco_mel_basis", "gsttaco_griffin_lim",
     "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_lstm_launch_bytes", "gsttaco_debug_stamps",
 )
 
@@ -99,6 +99,7 @@ def load_library(path=None):
     lib.gsttaco_inference_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.gsttaco_mel_frontend.argtypes = [vp, vp, vp, i32, i32, ctypes.c_float, vp, vp, i32, vp]
     lib.gsttaco_mel_basis.argtypes = [vp, f32p]
+    lib.gsttaco_griffin_lim.argtypes = [vp, vp, vp, i32, i32, i32, ctypes.c_float, ctypes.c_float, vp, u64, vp, vp, i32, vp]
     lib.gsttaco_set_profiling.argtypes = [vp, i32]
     lib.gsttaco_get_profile.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]
     lib.gsttaco_lstm_launch_bytes.argtypes = [vp, i32, i32]
@@ -108,7 +109,7 @@ def load_library(path=None):
     for fn in ("gsttaco_create", "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight",
                "gsttaco_finalize_weights", "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder",
                "gsttaco_inference_step", "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_mel_frontend",
-               "gsttaco_mel_basis"):
+               "gsttaco_mel_basis", "gsttaco_griffin_lim"):
         getattr(lib, fn).restype = ctypes.c_int
     if path is None:
         _lib = lib

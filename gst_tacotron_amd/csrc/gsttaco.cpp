@@ -114,6 +114,9 @@ struct gsttaco_ctx {
     int32_t *a_band_lo = nullptr, *a_band_hi = nullptr, *a_bounds = nullptr;
     double* a_mse = nullptr;
     int a_ld_mse = 0;
+    double* a_win_sq = nullptr;
+    float *gl_mag = nullptr, *gl_frm[2] = {nullptr, nullptr};
+    size_t gl_frames_cap = 0;      // B*T frames the Griffin-Lim workspace holds
 
     // workspace
     int32_t *w_tokens = nullptr, *w_mel_len = nullptr, *w_tok_len = nullptr;
@@ -789,6 +792,16 @@ int ensure_audio(gsttaco_ctx* c) {
     if ((rc = upload(c, &c->a_mel_basis, c->h_mel_basis.data(), c->h_mel_basis.size()))) return rc;
     if ((rc = upload(c, reinterpret_cast<float**>(&c->a_band_lo), reinterpret_cast<const float*>(lo.data()), lo.size()))) return rc;
     if ((rc = upload(c, reinterpret_cast<float**>(&c->a_band_hi), reinterpret_cast<const float*>(hi.data()), hi.size()))) return rc;
+    {   // window^2 in float64 (librosa.filters.window_sumsquare squares the float64 window), zero-padded like the window
+        std::vector<double> wsq(N, 0.0);
+        for (int i = 0; i < wl; ++i) {
+            const double w = 0.5 - 0.5 * std::cos(2.0 * M_PI * i / wl);
+            wsq[lpad + i] = w * w;
+        }
+        if ((rc = dev_alloc(c, (void**)&c->a_win_sq, (size_t)N * sizeof(double)))) return rc;
+        HIPCHECK(c, hipMemcpy(c->a_win_sq, wsq.data(), (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPCHECK(c, gt_gl_init());
     c->a_ld_mse = g.max_wav_samples / 16 + 1;
     if ((rc = dev_alloc(c, (void**)&c->a_mse, (size_t)g.max_batch * c->a_ld_mse * sizeof(double)))) return rc;
     if ((rc = dev_alloc(c, (void**)&c->a_bounds, (size_t)g.max_batch * 2 * sizeof(int32_t)))) return rc;
@@ -1442,6 +1455,40 @@ int gsttaco_mel_frontend(gsttaco_ctx* c, const float* wav, const int32_t* wav_le
     a.preemph = 0.97f; a.trim_gain = 0.99f;             // Audio.py:11, Pattern_Generator.py:45
     a.top_db = top_db; a.max_abs = g.max_abs_mel;
     HIPCHECK(c, gt_launch_audio_front(a, (hipStream_t)stream));
+    return 0;
+}
+
+int gsttaco_griffin_lim(gsttaco_ctx* c, const float* spectrogram, const int32_t* frames, int B, int T, int iters,
+                        float power, float ref_level_db, const float* init_phase, uint64_t seed,
+                        float* wav, int32_t* wav_lengths, int ld_wav, void* stream) {
+    if (!c) return GSTTACO_E_INVALID;
+    int rc = ensure_audio(c);
+    if (rc) return rc;
+    const gsttaco_config& g = c->cfg;
+    if (!spectrogram || !wav) return fail(c, GSTTACO_E_INVALID, "null argument");
+    if (B < 1 || T < 1 || iters < 0 || !(power > 0.f)) return fail(c, GSTTACO_E_INVALID, "bad B / T / iters / power");
+    if (B > g.max_batch) return fail(c, GSTTACO_E_CAPACITY, "batch exceeds capacity");
+    if ((int64_t)g.frame_shift * (T - 1) > (int64_t)ld_wav || ld_wav < 1)
+        return fail(c, GSTTACO_E_INVALID, "ld_wav must be >= Frame_Shift * (T - 1)");
+    const size_t need = (size_t)B * T;
+    if (need > c->gl_frames_cap) {                       // grown on demand, kept for the context's lifetime
+        const size_t nb = (size_t)c->n_fft / 2 + 1;
+        float* m = nullptr; float* f0 = nullptr; float* f1 = nullptr;
+        if ((rc = dev_alloc(c, (void**)&m, need * nb * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(c, (void**)&f0, need * c->n_fft * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(c, (void**)&f1, need * c->n_fft * sizeof(float)))) return rc;
+        c->gl_mag = m; c->gl_frm[0] = f0; c->gl_frm[1] = f1; c->gl_frames_cap = need;
+    }
+    GriffinLimArgs a{};
+    a.spec = spectrogram; a.frames = frames; a.init_phase = init_phase; a.mag = c->gl_mag;
+    a.wav = wav; a.wav_len = wav_lengths;
+    a.window = c->a_window; a.win_sq = c->a_win_sq; a.twiddle = c->a_twiddle;
+    a.seed = seed;
+    a.B = B; a.T = T; a.n_fft = c->n_fft; a.log2_h = 0;
+    while ((1 << a.log2_h) < c->n_fft / 2) ++a.log2_h;
+    a.hop = g.frame_shift; a.ld_wav = ld_wav; a.iters = iters;
+    a.power = power; a.ref_level_db = ref_level_db; a.max_abs = g.max_abs_mel; a.preemph = 0.97f;
+    HIPCHECK(c, gt_launch_griffin_lim(a, c->gl_frm[0], c->gl_frm[1], (hipStream_t)stream));
     return 0;
 }
 

@@ -191,3 +191,24 @@ struct AudioFrontArgs {
 };
 hipError_t gt_launch_audio_front(const AudioFrontArgs& a, hipStream_t stream);
 
+struct GriffinLimArgs {
+    const float* spec;          // [B, T, n_fft/2+1] normalised spectrogram (the vocoder's output layout)
+    const int32_t* frames;      // [B] frames to use per utterance, or NULL (= T)
+    const float* init_phase;    // [B, T, n_fft/2+1] uniform [0,1) (x 2 pi), or NULL -> Philox(seed)
+    float* mag;                 // [B, T, n_fft/2+1] workspace: S ^ power
+    const float* frm_old;       // [B, T, n_fft] windowed inverse-FFT frames of the previous iteration
+    float* frm_new;
+    float* ybuf;                // [B, ld_y] final overlap-added signal (before de-emphasis)
+    float* wav;                 // [B, ld_wav] output
+    int32_t* wav_len;           // [B] output: hop * (frames - 1), or NULL
+    const float* window;        // [n_fft]
+    const double* win_sq;       // [n_fft] window^2 in float64
+    const float2* twiddle;      // [n_fft/2]
+    int64_t ld_y;
+    uint64_t seed;
+    int B, T, n_fft, log2_h, hop, ld_wav, iters;
+    float power, ref_level_db, max_abs, preemph;
+};
+hipError_t gt_gl_init();
+hipError_t gt_launch_griffin_lim(GriffinLimArgs a, float* frm_a, float* frm_b, hipStream_t stream);
+

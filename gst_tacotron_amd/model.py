@@ -19,6 +19,8 @@ PyTorch is used for device memory and streams only.  Differences, all additive:
     path and returned as None.
 """
 import ctypes
+import os
+from datetime import datetime
 
 import numpy as np
 import torch
@@ -151,11 +153,15 @@ class GST_Tacotron:
         return mel, stop, spec, align
 
     def Inference_GST(self, wav_List, tag_List=None, label=None):
-        """reference Model.py:427-446 without the TSV export thread: style embeddings [B, Attention.Size] of the wavs."""
+        """reference Model.py:427-446: style embeddings [B, Attention.Size] of the wavs; with ``tag_List`` the table
+        of Model.py:448-459 is written too."""
         if not self.hp_Dict["GST"]["Use"]:
             raise NotImplementedError("GST is not used")
         print("GST Inference running...")
-        return self.Inference_GST_Step(**self.feeder.Get_Inference_GST_Pattern(wav_List))
+        gsts = self.Inference_GST_Step(**self.feeder.Get_Inference_GST_Pattern(wav_List))
+        if tag_List is not None:
+            self.Export_GST(wav_List, tag_List, gsts, label or datetime.now().strftime("%Y%m%d.%H%M%S"))
+        return gsts
 
     def Inference_GST_Step(self, mels_for_gst, mel_lengths_for_gst):
         """reference Model.py:257-265"""
@@ -200,15 +206,82 @@ class GST_Tacotron:
             raise ValueError("a reference wav is shorter than n_fft/2 samples after trimming (librosa.stft raises there)")
         return mels[:, :n + 1].contiguous(), mel_len
 
-    def Inference(self, sentence_List, wav_List_for_GST=None, label=None, **kwargs):
-        """reference Model.py:342-367 (the export thread -- plots / Griffin-Lim wavs -- is a separate call).
-        ``wav_List_for_GST`` holds wav paths / 1-D sample arrays like the reference's, or precomputed mels [T, Mel_Dim]."""
+    def Inference(self, sentence_List, wav_List_for_GST=None, label=None, export=False, **kwargs):
+        """reference Model.py:342-367.  ``wav_List_for_GST`` holds wav paths / 1-D sample arrays like the reference's,
+        or precomputed mels [T, Mel_Dim].  The reference always starts its export thread; here ``export=True`` asks for
+        it (it needs the CBHG vocoder and Griffin-Lim, which are off the mel-frame metric) and runs it synchronously."""
         print("Inference running...")
         pattern_Dict = self.feeder.Get_Inference_Pattern(sentence_List, wav_List_for_GST)
         if pattern_Dict is None:
             print("Inference fail.")
             return None
-        return self.Inference_Step(**pattern_Dict, **kwargs)
+        if export:
+            kwargs["with_vocoder"] = True
+        out = self.Inference_Step(**pattern_Dict, **kwargs)
+        if export:
+            self.Export_Inference(sentence_List, out[0], out[1], out[2], out[3],
+                                  label or datetime.now().strftime("%Y%m%d.%H%M%S"))
+        return out
+
+    def Inv_Spectrogram(self, spectrograms, frames=None, iters=None, power=1.5, ref_level_db=20.0, init_phase=None, seed=0):
+        """Batched reference Audio.inv_spectrogram (Audio.py:23-27) on the GPU: spectrograms [B, T, Spectrogram_Dim] as
+        Inference_Step returns them -> (wav [B, Frame_Shift*(T-1)] float32, wav_lengths [B]).  ``frames`` [B] limits the
+        frames used per utterance; ``init_phase`` [B,T,Spectrogram_Dim] in [0,1) injects the random initial phases."""
+        d = self.dims
+        if not d.audio or not self.ctx.cfg.max_wav_samples:
+            raise ValueError("the audio back end needs the Sound section of Hyper_Parameters and max_wav_seconds > 0")
+        if not torch.cuda.is_available():
+            raise capi.GstTacoError(-2, "no HIP device: the gfx950 kernels are the only compute path (no CPU fallback)")
+        spec = self._dev(spectrograms, torch.float32)
+        B, T = spec.shape[0], spec.shape[1]
+        if iters is None:
+            iters = int(self.hp_Dict.get("Vocoder_Taco1", {}).get("Griffin-Lim_Iter", 60))
+        fr = self._dev(frames, torch.int32)
+        ph = self._dev(init_phase, torch.float32)
+        ld = max(1, d.frame_shift * (T - 1))
+        wav = torch.empty((B, ld), dtype=torch.float32, device=self.device)
+        lens = torch.empty((B,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self.ctx.check(self.ctx.lib.gsttaco_griffin_lim(
+                self.ctx.handle, _ptr(spec), _ptr(fr), B, T, int(iters), ctypes.c_float(float(power)),
+                ctypes.c_float(float(ref_level_db)), _ptr(ph), ctypes.c_uint64(int(seed)), _ptr(wav), _ptr(lens), ld,
+                self._stream()))
+        return wav, lens
+
+    def Export_Inference(self, sentence_List, mel_List, stop_List, spectrogram_List, alignment_List, label, plot=True):
+        """reference Model.py:369-427: per utterance a figure (Plot/<label>.IDX_<i>.PNG) and the Griffin-Lim wav of the
+        spectrogram cut at the stop token (Wav/<label>.IDX_<i>.WAV) under Inference_Path.  Returns the wav paths."""
+        from . import export
+        root = self.hp_Dict["Inference_Path"]
+        os.makedirs(os.path.join(root, "Plot"), exist_ok=True)
+        os.makedirs(os.path.join(root, "Wav"), exist_ok=True)
+        stops = np.asarray(stop_List.cpu() if torch.is_tensor(stop_List) else stop_List, dtype=np.float32)
+        slice_idx = [export.stop_slice_index(s) for s in stops]
+        frames = np.array([max(1, i) * self.dims.r for i in slice_idx], dtype=np.int32)           # Model.py:415
+        wav, lens = self.Inv_Spectrogram(spectrogram_List, frames=frames)
+        wav, lens = wav.cpu().numpy(), lens.cpu().numpy()
+        to_np = lambda a: np.asarray(a.cpu() if torch.is_tensor(a) else a, dtype=np.float32)
+        mels, specs, aligns = to_np(mel_List), to_np(spectrogram_List), to_np(alignment_List)
+        paths = []
+        for i, sentence in enumerate(sentence_List):
+            if plot:
+                try:
+                    export.plot_inference(os.path.join(root, "Plot", "{}.IDX_{}.PNG".format(label, i)), sentence, mels[i],
+                                          specs[i], aligns[i], stops[i], slice_idx[i])
+                except ImportError:
+                    plot = False                      # matplotlib is optional
+            p = os.path.join(root, "Wav", "{}.IDX_{}.WAV".format(label, i))
+            export.write_wav(p, wav[i, :lens[i]], self.dims.sample_rate)
+            paths.append(p)
+        return paths
+
+    def Export_GST(self, wav_List, tag_List, gst_List, label):
+        """reference Model.py:448-459"""
+        from . import export
+        gst = np.asarray(gst_List.cpu() if torch.is_tensor(gst_List) else gst_List)
+        path = os.path.join(self.hp_Dict["Inference_Path"], "GST", "{}.GST.TXT".format(label))
+        export.export_gst(path, wav_List, tag_List, gst)
+        return path
 
     # ------------------------------------------------------------------ per-phase entry points (tests / profiling)
     def encode(self, tokens, token_lengths=None):

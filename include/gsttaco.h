@@ -20,6 +20,8 @@
  *   gsttaco_vocoder     <- Modules/Taco2.py:234-260 Vocoder_Taco1.call, CBHG :285-380
  *   gsttaco_mel_frontend <- Pattern_Generator.py:39-60 Mel_Generate + Audio.py:29-32,49-55,70-96 melspectrogram
  *                          + the batch layout of Feeder.py:204-225 / 229-250
+ *   gsttaco_griffin_lim <- Audio.py:23-27 inv_spectrogram, :57-68 _griffin_lim, :74-75 _istft (SURVEY row N4;
+ *                          called from Model.py:414-422 Export_Inference)
  *   gsttaco_mel_basis   <- Audio.py:81-83 _build_mel_basis (librosa.filters.mel); host-side getter for tests
  *
  * Conventions
@@ -186,6 +188,20 @@ int gsttaco_vocoder(gsttaco_ctx* ctx, const float* mel, int B, int T, float* spe
  *                samples (librosa.stft raises there) */
 int gsttaco_mel_frontend(gsttaco_ctx* ctx, const float* wav, const int32_t* wav_lengths, int B, int ld_wav, float top_db,
                          float* mels_for_gst, int32_t* mel_lengths, int cap_frames, void* stream);
+
+/* spectrogram -> waveform: Audio.inv_spectrogram (reference Audio.py:23-27) = symmetric de-normalisation (max_abs_mel,
+ * or the [0,1] one when it is 0), + ref_level_db, dB -> amplitude, ^power, `iters` Griffin-Lim iterations
+ * (Audio.py:57-68; librosa stft / istft, hann, centred), inverse pre-emphasis 0.97.  Needs cfg.max_wav_samples > 0.
+ * spectrogram : [B, T, spec_dim], the layout gsttaco_vocoder / gsttaco_inference_step write (time-major; the reference
+ *               transposes it before the call, Model.py:415)
+ * frames      : [B] int32 frames to use per utterance (Model.py:415: max(1, stop index) * Step_Reduction) or NULL = T
+ * init_phase  : [B, T, spec_dim] uniform [0,1) numbers (the reference draws np.random.rand unseeded, Audio.py:61) or
+ *               NULL = Philox4x32-10 from `seed`
+ * wav         : [B, ld_wav] float32, ld_wav >= frame_shift * (T - 1); samples beyond an utterance's length are zero
+ * wav_lengths : [B] int32 out (may be NULL): frame_shift * (frames - 1); 0 when that is <= n_fft/2 (librosa raises) */
+int gsttaco_griffin_lim(gsttaco_ctx* ctx, const float* spectrogram, const int32_t* frames, int B, int T, int iters,
+                        float power, float ref_level_db, const float* init_phase, uint64_t seed,
+                        float* wav, int32_t* wav_lengths, int ld_wav, void* stream);
 
 /* host_out [mel_dim, spec_dim] float32 <- the Slaney mel filterbank the front end uses (librosa.filters.mel defaults) */
 int gsttaco_mel_basis(gsttaco_ctx* ctx, float* host_out);

@@ -233,3 +233,132 @@ def test_gpu_wav_to_style_embedding_and_inference_with_wav_references(tmp_path):
     out = m.Inference(["Hello there.", "Second one."], paths)
     torch.cuda.synchronize()
     assert out[0].shape == (2, 8, 80) and torch.isfinite(out[0]).all()
+
+
+# ================================================================================================ N4: back end
+def _realistic_spectrogram(snd, seed, n_samples):
+    """Normalised linear spectrogram [T, bins] of a synthetic voiced-like signal (Audio.spectrogram, Audio.py:18-21)."""
+    rng = np.random.default_rng(seed)
+    sr = snd["Sample_Rate"]
+    t = np.arange(n_samples) / sr
+    y = 0.3 * np.sin(2 * np.pi * 180 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.1 * np.sin(2 * np.pi * 1200 * t) \
+        + 0.02 * rng.standard_normal(n_samples)
+    n_fft = 2 * (snd["Spectrogram_Dim"] - 1)
+    M = A.magnitude(y, n_fft, snd["Frame_Shift"], snd["Frame_Length"])
+    return np.transpose(A.symmetric_normalize(A.amp_to_db(M) - 20, max_abs_value=snd["Max_Abs_Mel"])).astype(np.float32)
+
+
+def _spectral_error(y, S_target, snd):
+    n_fft = 2 * (snd["Spectrogram_Dim"] - 1)
+    M = np.abs(A.stft(y, n_fft, snd["Frame_Shift"], snd["Frame_Length"]))
+    return np.linalg.norm(M - S_target) / np.linalg.norm(S_target)
+
+
+def test_griffin_lim_oracle_converges():
+    snd = synthetic.tiny_hp()["Sound"]
+    spec = _realistic_spectrogram(snd, 0, 3000)
+    S = np.power(10.0, (A.symmetric_denormalize(spec.T, max_abs_value=4) + 20) * 0.05) ** 1.5
+    ph = np.random.default_rng(0).random(S.shape)
+    e = [_spectral_error(A.griffin_lim(S, snd["Frame_Shift"], snd["Frame_Length"], it, ph), S, snd) for it in (0, 5, 30)]
+    assert e[0] > e[1] > e[2] and e[2] < 0.5 * e[0]
+    y = A.inv_spectrogram(spec.T, snd, max_abs_value=4, iters=2, angles0=ph)
+    assert y.shape == (snd["Frame_Shift"] * (spec.shape[0] - 1),)
+
+
+def test_export_helpers(tmp_path):
+    from gst_tacotron_amd import export
+    assert export.stop_slice_index(np.array([1.0, 0.5, -0.1, 2.0, -3.0])) == 2        # Model.py:380
+    assert export.stop_slice_index(np.array([1.0, 0.5])) == 2
+    p = str(tmp_path / "x.wav")
+    sig = np.array([0.0, 0.5, -0.5, 1.5, -1.5, 0.25])
+    export.write_wav(p, sig, 16000)
+    from scipy.io import wavfile
+    sr, pcm = wavfile.read(p)
+    assert sr == 16000 and pcm.tolist() == [0, 16384, -16384, 32767, -32768, 8192]
+    t = str(tmp_path / "GST" / "l.GST.TXT")
+    export.export_gst(t, ["a.wav", "b.wav"], ["A", "B"], np.array([[1.0, 2.0], [3.0, 4.5]]))
+    rows = open(t).read().split("\n")
+    assert rows[0] == "Wav\tTag\tUnit_0\tUnit_1" and rows[2] == "b.wav\tB\t3.0\t4.5"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,iters", [("tiny", 0), ("tiny", 1), ("tiny", 4), ("full", 0), ("full", 3)])
+def test_gpu_griffin_lim_matches_oracle(name, iters):
+    """Injected initial phases; pointwise comparison for a few iterations (float32 FFTs vs the oracle's float64/complex64
+    mix: the tolerance is relative to the waveform's peak)."""
+    import torch
+    hp = synthetic.tiny_hp() if name == "tiny" else hparams.load_hp()
+    snd = hp["Sound"]
+    specs = [_realistic_spectrogram(snd, s, n) for s, n in ((1, 9000 if name == "full" else 1500), (2, 6000 if name == "full" else 1000))]
+    T = max(s.shape[0] for s in specs)
+    nb = snd["Spectrogram_Dim"]
+    batch = np.zeros((2, T, nb), np.float32)
+    for i, s in enumerate(specs):
+        batch[i, :s.shape[0]] = s
+    frames = np.array([s.shape[0] for s in specs], np.int32)
+    ph = np.random.default_rng(5).random((2, T, nb)).astype(np.float32)
+    m = _model(hp, 2)
+    wav, lens = m.Inv_Spectrogram(batch, frames=frames, iters=iters, init_phase=ph)
+    torch.cuda.synchronize()
+    wav, lens = wav.cpu().numpy(), lens.cpu().numpy()
+    for i, s in enumerate(specs):
+        ref = A.inv_spectrogram(s.T.astype(np.float64), snd, max_abs_value=snd["Max_Abs_Mel"], iters=iters,
+                                angles0=ph[i, :s.shape[0]].T.astype(np.float64))
+        assert lens[i] == ref.shape[0] == snd["Frame_Shift"] * (s.shape[0] - 1)
+        err = np.abs(wav[i, :lens[i]] - ref).max() / np.abs(ref).max()
+        print(name, iters, i, "rel err", err)
+        assert err <= 2e-3
+        assert np.abs(wav[i, lens[i]:]).max(initial=0.0) == 0.0
+
+
+@pytest.mark.gpu
+def test_gpu_griffin_lim_60_iterations_converge_like_the_oracle():
+    import torch
+    hp = hparams.load_hp()
+    snd = hp["Sound"]
+    spec = _realistic_spectrogram(snd, 3, 12000)
+    S = np.power(10.0, (A.symmetric_denormalize(spec.T, max_abs_value=4) + 20) * 0.05) ** 1.5
+    ph = np.random.default_rng(6).random(spec.shape).astype(np.float32)
+    m = _model(hp, 1)
+    wav, lens = m.Inv_Spectrogram(spec[None], iters=60, init_phase=ph[None])
+    wav0, _ = m.Inv_Spectrogram(spec[None], iters=0, init_phase=ph[None])
+    wav_rng, _ = m.Inv_Spectrogram(spec[None], iters=60, seed=7)               # Philox initial phases
+    torch.cuda.synchronize()
+    pre = lambda w: A.preemphasis(w.cpu().numpy()[0].astype(np.float64))      # undo the inverse pre-emphasis
+    e60, e0, er = (_spectral_error(pre(w), S, snd) for w in (wav, wav0, wav_rng))
+    ref = A.griffin_lim(S, snd["Frame_Shift"], snd["Frame_Length"], 60, ph.T.astype(np.float64))
+    e_ref = _spectral_error(ref, S, snd)
+    print("spectral error: gpu 60 it", e60, "gpu 0 it", e0, "oracle 60 it", e_ref, "gpu philox", er)
+    assert e60 < 0.5 * e0 and abs(e60 - e_ref) <= 0.05 * e_ref + 1e-3 and er < 0.5 * e0
+
+
+@pytest.mark.gpu
+def test_gpu_export_inference_writes_wavs_and_tables(tmp_path):
+    import torch
+    from scipy.io import wavfile
+    from gst_tacotron_amd import weights
+    from gst_tacotron_amd.model import GST_Tacotron
+    hp = synthetic.tiny_hp(max_step=24)
+    hp["Inference_Path"] = str(tmp_path / "out")
+    hp["Vocoder_Taco1"]["Griffin-Lim_Iter"] = 3
+    m = GST_Tacotron(hyper_parameters=hp, max_batch=2, max_tokens=16, max_ref_frames=200, max_wav_seconds=1.0)
+    m.Restore(weights=weights.synthetic_weights(hp, seed=2))
+    rng = np.random.default_rng(0)
+    ref_mel = np.clip(rng.normal(0, 1.5, (40, 16)), -4, 4).astype(np.float32)
+    sents = ["Hi there.", "Yes."]
+    out = m.Inference(sents, [ref_mel], label="T", export=True)
+    torch.cuda.synchronize()
+    assert out[2] is not None and out[2].shape == (2, 24, 33)
+    for i in range(2):
+        sr, pcm = wavfile.read(os.path.join(hp["Inference_Path"], "Wav", "T.IDX_%d.WAV" % i))
+        from gst_tacotron_amd.export import stop_slice_index
+        frames = max(1, stop_slice_index(out[1][i].cpu().numpy())) * 2
+        assert sr == 16000 and pcm.dtype == np.int16 and pcm.shape[0] == (16 * (frames - 1) if 16 * (frames - 1) > 32 else 0)
+        assert os.path.exists(os.path.join(hp["Inference_Path"], "Plot", "T.IDX_%d.PNG" % i))
+    wavs = []
+    for i, n in enumerate((3000, 2000)):
+        wavs.append(str(tmp_path / ("ref%d.wav" % i)))
+        wavfile.write(wavs[-1], 16000, (3000 * np.sin(np.arange(n) * 0.05 * (i + 1))).astype(np.int16))
+    gst = m.Inference_GST(wavs, tag_List=["a", "b"], label="T")
+    rows = open(os.path.join(hp["Inference_Path"], "GST", "T.GST.TXT")).read().split("\n")
+    assert len(rows) == 3 and rows[0].startswith("Wav\tTag\tUnit_0") and gst.shape == (2, 16)
