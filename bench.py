@@ -115,7 +115,6 @@ def main():
     model = GST_Tacotron(hyper_parameters=hp, device=local_rank, max_batch=B, max_tokens=Tv, max_ref_frames=Tref1)
     model.Restore(weights=w)
     lib, handle = model.ctx.lib, model.ctx.handle
-    model.ctx.check(lib.gsttaco_set_profiling(handle, PROFILE_EVERY))
 
     dev = model.device
     tok = torch.as_tensor(inputs["tokens"]).to(dev)
@@ -127,8 +126,19 @@ def main():
         mel, stop, _, align = model.Inference_Step(tok, None, None, mels, lens, seed=1000 + i)
         return gdist.gather_to_root(mel, n_total=n_total)
 
+    # Two cached graphs: the plain one, and one whose decode launches are bracketed by event-record nodes on every
+    # PROFILE_EVERY-th step.  Only the LAST timed step replays the bracketed graph (each bracket costs ~2.5 us, 200 of
+    # them ~2 % of a step), so the kernel timings come from inside the timed region at 1/K of that cost.
+    def set_prof(on):
+        model.ctx.check(lib.gsttaco_set_profiling(handle, PROFILE_EVERY if on else 0))
+
+    set_prof(True)
+    one_step(-1)                                   # capture + first replay of the bracketed graph (untimed, extra)
+    set_prof(False)
     for i in range(args.warmup):
         one_step(i)
+    if args.warmup == 0:
+        one_step(0)                                # the plain graph must exist before the clock starts
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -136,6 +146,8 @@ def main():
     t0 = time.perf_counter()
     out = None
     for i in range(args.steps):
+        if i == args.steps - 1:
+            set_prof(True)
         out = one_step(args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
@@ -148,7 +160,7 @@ def main():
         elapsed = float(t.item())
 
     # per-kernel timing of the decode step: HIP event-record nodes inside the replayed graph (on the stream the
-    # kernels run on), every PROFILE_EVERY-th step of the last timed replay
+    # kernels run on), every PROFILE_EVERY-th decode step of the last timed replay
     KNAMES = {0: "gt_skinny_kernel<EPI_LSTM> layer 1 (x-half)", 1: "gt_skinny_kernel<EPI_LSTM> layer 2 (x-half)",
               2: "gt_dec_front_kernel (prenet x2 + query + attention per utterance; workers: recurrent halves W_h.h+b)",
               3: "gt_skinny_co_kernel (projection; workers: layer-2 recurrent half)"}

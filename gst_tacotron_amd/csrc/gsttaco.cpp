@@ -689,7 +689,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             rce = prof_end(4); if (rce) return rce;
         }
     }
-    for (int i = 0; i < 5; ++i) c->prof_count[i] = nprof[i];
+    if (c->prof_every > 0)      // an un-bracketed capture must not forget the brackets of an earlier, bracketed graph
+        for (int i = 0; i < 5; ++i) c->prof_count[i] = nprof[i];
     return 0;
 }
 
