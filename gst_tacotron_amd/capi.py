@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = (
     "gsttaco_abi_version", "gsttaco_create", "gsttaco_destroy", "gsttaco_last_error",
     "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight", "gsttaco_finalize_weights",
     "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder", "gsttaco_inference_step",
-    "gsttaco_mel_frontend", "gsttaco_mel_basis", "gsttaco_griffin_lim",
+    "gsttaco_mel_frontend", "gsttaco_mel_basis", "gsttaco_griffin_lim", "gsttaco_crc32c",
     "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_lstm_launch_bytes", "gsttaco_debug_stamps",
 )
 

@@ -1572,6 +1572,35 @@ int gsttaco_debug_stamps(gsttaco_ctx* c, unsigned long long* host_out48) {
     return 0;
 }
 
+// CRC-32C (Castagnoli, reflected 0x82F63B78), slicing-by-8: the checksum of TensorFlow checkpoint bundles
+// (gst_tacotron_amd/tf_checkpoint.py reads / writes them).  Host only.
+uint32_t gsttaco_crc32c(const void* data, size_t n, uint32_t crc) {
+    static uint32_t tab[8][256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            tab[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xff];
+        ready = true;
+    }
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    uint32_t c = crc ^ 0xffffffffu;
+    while (n >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= c;
+        c = tab[7][lo & 0xff] ^ tab[6][(lo >> 8) & 0xff] ^ tab[5][(lo >> 16) & 0xff] ^ tab[4][lo >> 24] ^
+            tab[3][hi & 0xff] ^ tab[2][(hi >> 8) & 0xff] ^ tab[1][(hi >> 16) & 0xff] ^ tab[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) c = tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+    return c ^ 0xffffffffu;
+}
+
 int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int which, int B) {
     if (!c || which < 0 || which > 3) return GSTTACO_E_INVALID;
     // Algorithmic bytes of one launch at batch B and T_v = max_tokens: every weight once, every activation row once

@@ -55,14 +55,23 @@ class GST_Tacotron:
 
     # ------------------------------------------------------------------ weights
     def Restore(self, checkpoint_File_Path=None, weights=None):
-        """reference Model.py:267-276.  Loads a flat ``.npz`` weight file (names/shapes:
-        gst_tacotron_amd.weights.manifest) or an in-memory dict; prints and returns like the
-        reference when nothing is found."""
+        """reference Model.py:267-276.  Loads (a) a flat ``.npz`` weight file (names/shapes:
+        gst_tacotron_amd.weights.manifest), (b) a reference ``tf.train.Checkpoint`` prefix (``<prefix>.index`` +
+        ``.data-*``, read without TensorFlow by gst_tacotron_amd.tf_checkpoint -- SURVEY N3), (c) with no argument the
+        latest checkpoint under ``Checkpoint_Path`` like the reference, or (d) an in-memory dict; prints and returns
+        like the reference when nothing is found."""
+        from . import tf_checkpoint
         if weights is None:
-            if checkpoint_File_Path is None or not __import__("os").path.exists(checkpoint_File_Path):
+            if checkpoint_File_Path is None:
+                checkpoint_File_Path = tf_checkpoint.latest_checkpoint(self.hp_Dict.get("Checkpoint_Path", "."))   # :268-270
+            if checkpoint_File_Path is not None and os.path.exists(str(checkpoint_File_Path) + ".index"):
+                weights = tf_checkpoint.load_reference_checkpoint(checkpoint_File_Path, self.hp_Dict,
+                                                                  vocab=len(self.token_Index_Dict))
+            elif checkpoint_File_Path is not None and os.path.exists(checkpoint_File_Path):
+                weights = weights_mod.load_npz(checkpoint_File_Path)
+            else:
                 print("There is no checkpoint.")
                 return self
-            weights = weights_mod.load_npz(checkpoint_File_Path)
             print("Checkpoint '{}' is loaded.".format(checkpoint_File_Path))
         weights_mod.check_weights(self.hp_Dict, weights, vocab=len(self.token_Index_Dict))
         if not torch.cuda.is_available():

@@ -37,6 +37,7 @@
 #ifndef GSTTACO_H
 #define GSTTACO_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -202,6 +203,10 @@ int gsttaco_mel_frontend(gsttaco_ctx* ctx, const float* wav, const int32_t* wav_
 int gsttaco_griffin_lim(gsttaco_ctx* ctx, const float* spectrogram, const int32_t* frames, int B, int T, int iters,
                         float power, float ref_level_db, const float* init_phase, uint64_t seed,
                         float* wav, int32_t* wav_lengths, int ld_wav, void* stream);
+
+/* CRC-32C of a host buffer continued from `crc` (0 to start): the checksum of TensorFlow checkpoint bundles, used by
+ * gst_tacotron_amd/tf_checkpoint.py for the reference's tf.train.Checkpoint files (Model.py:186-189, 267-276).  Host only. */
+uint32_t gsttaco_crc32c(const void* data, size_t n, uint32_t crc);
 
 /* host_out [mel_dim, spec_dim] float32 <- the Slaney mel filterbank the front end uses (librosa.filters.mel defaults) */
 int gsttaco_mel_basis(gsttaco_ctx* ctx, float* host_out);

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 struct Sync { unsigned int count; unsigned int error; };
 
 __device__ __forceinline__ void grid_barrier(Sync* s, unsigned int target, bool fences) {
@@ -64,6 +65,61 @@ __global__ __launch_bounds__(512) void k_persist2(Sync2* s, float* buf, float* o
             const float v = __hip_atomic_load(&cur[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             mism += v != (float)(it * 7 + i / pub);
             acc += v;
+        }
+    }
+    if (mism) atomicAdd(bad, mism);
+    if (acc == 1.2345f) out[0] = acc;
+}
+
+// variant C: only the workgroups with blockIdx % 8 == 0 take part (32 of 256): if workgroups are dealt round-robin to
+// the 8 XCDs they share ONE L2, so the counter can be a plain L2 atomic (workgroup scope) and the exchanged data needs
+// no write-back / invalidate of L2 -- only the reader's L1 has to be bypassed.  xcc[] records HW_REG_XCC_ID per WG.
+struct Sync3 { unsigned int count; unsigned int error; unsigned int xcc[64]; };
+__global__ __launch_bounds__(256) void k_persist3(Sync3* s, float* buf, float* out, int iters, int scope_agent, int read_mode, int pub, unsigned int* bad) {
+    if (blockIdx.x & 7) return;
+    const int me = blockIdx.x >> 3, n = gridDim.x >> 3;
+    if (threadIdx.x == 0) s->xcc[me] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;   // XCC_ID[3:0]
+    float acc = 0.f;
+    unsigned int mism = 0;
+    for (int it = 0; it < iters; ++it) {
+        float* cur = buf + (size_t)(it & 1) * n * pub;
+        for (int i = threadIdx.x; i < pub; i += blockDim.x) {
+            const float v = (float)(it * 7 + me);
+            if (read_mode == 0) __hip_atomic_store(&cur[(size_t)me * pub + i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else cur[(size_t)me * pub + i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const unsigned int target = (unsigned int)(it + 1) * n;
+            if (scope_agent) __hip_atomic_fetch_add(&s->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(&s->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unsigned int spins = 0;
+            while ((scope_agent ? __hip_atomic_load(&s->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                : __hip_atomic_load(&s->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target) {
+                if (++spins > (1u << 18) || __hip_atomic_load(&s->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(&s->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();
+        if (__hip_atomic_load(&s->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const int total = n * pub;
+        if (read_mode == 0) {
+            for (int i = threadIdx.x; i < total; i += blockDim.x) {
+                const float v = __hip_atomic_load(&cur[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mism += v != (float)(it * 7 + i / pub); acc += v;
+            }
+        } else {
+            if (read_mode == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (read_mode == 3) asm volatile("buffer_inv sc0" ::: "memory");
+            const float4* c4 = reinterpret_cast<const float4*>(cur);
+            for (int i = threadIdx.x; i < total / 4; i += blockDim.x) {
+                float4 v;
+                if (read_mode == 4) { const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(c4 + i)); v = make_float4(t[0], t[1], t[2], t[3]); }
+                else v = c4[i];
+                const float e = (float)(it * 7 + (i * 4) / pub);
+                mism += (v.x != e) + (v.y != e) + (v.z != e) + (v.w != e); acc += v.x + v.y + v.z + v.w;
+            }
         }
     }
     if (mism) atomicAdd(bad, mism);
@@ -142,6 +198,30 @@ int main() {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             Sync2 h; unsigned int hb; CK(hipMemcpy(&h, s2, sizeof(h), hipMemcpyDeviceToHost)); CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
             if (rep == 1) printf("%s: %.2f us / hand-off  (error flag %u, stale reads %u)\n", c.name, ms * 1e3 / iters, h.error, hb);
+        }
+    }
+    Sync3* s3; CK(hipMalloc(&s3, sizeof(Sync3)));
+    struct Case3 { const char* name; int agent, read_mode, pub; } cases3[] = {
+        {"C 32 WGs one XCD, agent atomics, bare        ", 1, 1, 0},
+        {"C 32 WGs one XCD, L2 atomics, bare           ", 0, 1, 0},
+        {"C L2 atomics, sc1 publish 1K / sc1 read 32K  ", 0, 0, 256},
+        {"C L2 atomics, plain publish / plain read 32K ", 0, 1, 256},
+        {"C L2 atomics, plain publish / wg-acq read 32K", 0, 2, 256},
+        {"C L2 atomics, plain publish / inv sc0 read   ", 0, 3, 256},
+        {"C L2 atomics, plain publish / nt read 32K    ", 0, 4, 256},
+        {"C agent atomics, sc1 publish / sc1 read 32K  ", 1, 0, 256},
+    };
+    for (const Case3& c : cases3) {
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipMemset(s3, 0, sizeof(Sync3))); CK(hipMemset(bad, 0, 4));
+            CK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL(k_persist3, dim3(nwg), dim3(256), 0, 0, s3, buf, out, iters, c.agent, c.read_mode, c.pub, bad);
+            CK(hipEventRecord(e1, 0));
+            CK(hipDeviceSynchronize());
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            Sync3 h; unsigned int hb; CK(hipMemcpy(&h, s3, sizeof(h), hipMemcpyDeviceToHost)); CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
+            unsigned int xmask = 0; for (int i = 0; i < nwg / 8; ++i) xmask |= 1u << h.xcc[i];
+            if (rep == 1) { printf("%s: %.2f us / hand-off  (error %u, stale reads %u, XCC mask 0x%x)\n", c.name, ms * 1e3 / iters, h.error, hb, xmask); fflush(stdout); }
         }
     }
     return 0;
