@@ -273,3 +273,44 @@ def test_lsa_extension_full_dims_and_masked():
             assert np.abs(out[0].cpu().numpy() - ref[0]).max() <= TOL
             assert np.abs(out[3].cpu().numpy() - ref[3]).max() <= TOL
             assert np.allclose(out[3].cpu().numpy().sum(-1), 1.0, atol=1e-5)
+
+
+def test_config3_batch128_variable_length_with_padding_masks():
+    """BASELINE configs[2]: batch 128, 32-256 tokens, padding masks.  Too big for the oracle, so through the property the
+    masks exist for: every utterance of the padded batch equals that utterance decoded alone at its own length (a batch
+    of 1, 4 M-chunks vs 1, one vs several attention row passes), alignments are zero beyond each length, and bucketing
+    by length (sorting the batch) permutes the outputs and changes nothing else."""
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    B, Tv, Tref, steps = 128, 256, 120, 24
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, seed=0)
+    rng = np.random.default_rng(123)
+    lens = rng.integers(32, 257, B).astype(np.int32)
+    lens[0], lens[1] = 256, 32
+    tokens, _ = synthetic.make_tokens(rng, B, Tv, lengths=lens)
+    mels, ml = synthetic.make_ref_mels(rng, B, Tref, lengths=rng.integers(40, Tref + 1, B))
+    masks, noise = synthetic.make_randomness(rng, steps, B, Tv, [256, 256])
+    m = _model(hp, w, B, Tv, Tref + 1)
+    mel, stop, _, align = m.Inference_Step(tokens, lens, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps,
+                                           masked=True)
+    torch.cuda.synchronize()
+    mel, stop, align = mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy()
+    assert np.isfinite(mel).all() and mel.shape == (B, steps * 2, 80)
+    for b in range(B):
+        assert not align[b][:, lens[b]:].any()
+    for b in (0, 1, 77, 127):
+        n = int(lens[b])
+        # the reference encoder's convolutions see the batch's zero padding of the reference mel (reference behaviour, F5):
+        # keep the padded width when decoding alone
+        one = m.Inference_Step(tokens[b:b + 1, :n], None, None, mels[b:b + 1], ml[b:b + 1], prenet_masks=masks[:, :, b:b + 1],
+                               attn_noise=np.ascontiguousarray(noise[:, b:b + 1, :n]), steps=steps)
+        torch.cuda.synchronize()
+        assert np.abs(one[0].cpu().numpy()[0] - mel[b]).max() <= TOL, b
+        assert np.abs(one[3].cpu().numpy()[0] - align[b][:, :n]).max() <= TOL, b
+    order = np.argsort(lens, kind="stable")                      # a length bucket = a permutation of the batch
+    srt = m.Inference_Step(tokens[order], lens[order], None, mels[order], ml[order], prenet_masks=masks[:, :, order],
+                           attn_noise=noise[:, order], steps=steps, masked=True)
+    torch.cuda.synchronize()
+    assert np.abs(srt[0].cpu().numpy() - mel[order]).max() <= TOL
+    assert np.abs(srt[1].cpu().numpy() - stop[order]).max() <= TOL
