@@ -34,9 +34,27 @@ for k in sorted(set(fetch) | set(write)):
     res[k] = {"dispatches": max(f[1], w_[1]), "FETCH_SIZE_KiB_avg": f[0], "WRITE_SIZE_KiB_avg": w_[0],
               "hbm_read_bytes_corrected": 2.0 * f[0] * 1024.0, "hbm_write_bytes": w_[0] * 1024.0}
 json.dump(res, open(os.path.join(summ, f"{tag}_hbm_pmc.json"), "w"), indent=1)
+# MFMA utilisation per kernel = MFMA-busy SIMD-cycles / (kernel cycles x 1024 SIMDs).  SQ_VALU_MFMA_BUSY_CYCLES is in cycles
+# summed over all SIMDs (MI355X_MICROARCH.md, "s_memtime tick vs SQ PMC units"; checked: the 512->512 postnet conv reads
+# 1.31e9 = 20.5 M v_mfma_f32_32x32x2 x 64 cycles); GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (12.3 M for a 0.69 ms
+# kernel), hence the / 8.  Kernel durations under --pmc are inflated for the microsecond kernels (serialised dispatches), so
+# their utilisation is a lower bound; profiles/*_kernel_stats.csv has the undisturbed durations.
+mf, act, bcu = pmc("pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES"), pmc("pmc_mfma", "GRBM_GUI_ACTIVE"), pmc("pmc_mfma", "SQ_BUSY_CU_CYCLES")
+util = {}
+for k in sorted(mf):
+    a = act.get(k, (0.0, 0))[0]
+    util[k] = {"dispatches": mf[k][1], "SQ_VALU_MFMA_BUSY_CYCLES_avg": mf[k][0], "GRBM_GUI_ACTIVE_avg": a,
+               "SQ_BUSY_CU_CYCLES_avg": bcu.get(k, (0.0, 0))[0],
+               "mfma_util": (mf[k][0] / (a / 8.0 * 256 * 4)) if a else None}
+if util:
+    json.dump(util, open(os.path.join(summ, f"{tag}_mfma_pmc.json"), "w"), indent=1)
 for name in ("bench_trace.log",):
+    if not os.path.exists(os.path.join(out, name)):
+        continue
     for line in open(os.path.join(out, name)):
         if line.startswith("{"):
             open(os.path.join(summ, f"{tag}_bench_under_rocprof.json"), "w").write(line)
-print(open(os.path.join(summ, f"{tag}_kernel_stats.csv")).read()[:3000])
+if stats:
+    print(open(os.path.join(summ, f"{tag}_kernel_stats.csv")).read()[:3000])
 print(json.dumps({k: v for k, v in res.items() if "skinny" in k or "front" in k}, indent=1)[:3000])
+print(json.dumps({k[:50]: v for k, v in util.items() if v["mfma_util"]}, indent=1)[:3000])
