@@ -259,6 +259,43 @@ hipError_t gt_attn_init() {
 
 __global__ void gt_set_seed_kernel(uint64_t* dst, uint64_t seed) { *dst = seed; }
 
+// Throughput-mode randomness for a whole decode (reference: tf.nn.dropout in the always-on prenet, Taco2.py:283, and the
+// SMA sigmoid noise, Steps.py:220-221), generated ONCE per Inference_Step instead of inside every step's dependent chain
+// (3 Philox evaluations per thread cost ~0.6 us of the front kernel's 13 us).  Same Philox4x32-10 counters the step
+// kernels use, same buffer layout as injected tensors: masks [steps][mask0 B*P0 | mask1 B*P1] of 0/1, noise [steps][B][Tv].
+__global__ __launch_bounds__(256) void gt_rng_fill_kernel(const uint64_t* seed_ptr, float* masks, float* noise, int steps, int B,
+                                                          int P0, int P1, int Tv, float drop_rate) {
+    const uint64_t seed = *seed_ptr;
+    const int64_t per_step = (int64_t)B * (P0 + P1);
+    const int64_t nmask = masks ? (int64_t)steps * per_step : 0;
+    const int64_t nnoise = noise ? (int64_t)steps * B * Tv : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nmask + nnoise; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < nmask) {
+            const int t = (int)(i / per_step);
+            const int64_t e = i - (int64_t)t * per_step;
+            const bool second = e >= (int64_t)B * P0;
+            const uint32_t idx = (uint32_t)(second ? e - (int64_t)B * P0 : e);         // b * P + column
+            const Philox4 ph = gt_philox(seed, idx, (uint32_t)t, 0u, second ? 0x1001u : 0x1000u);
+            masks[i] = (gt_u01(ph.x) > drop_rate) ? 1.f : 0.f;
+        } else {
+            const int64_t j = i - nmask;
+            const int t = (int)(j / ((int64_t)B * Tv));
+            const uint32_t idx = (uint32_t)(j - (int64_t)t * B * Tv);                   // b * Tv + position
+            const Philox4 r = gt_philox(seed, idx, (uint32_t)t, 0u, GT_RNG_NOISE);
+            noise[j] = gt_normal(r.x, r.y);
+        }
+    }
+}
+
+hipError_t gt_launch_rng_fill(const uint64_t* seed_ptr, float* masks, float* noise, int steps, int B, int P0, int P1, int Tv,
+                              float drop_rate, hipStream_t stream) {
+    const int64_t n = (masks ? (int64_t)steps * B * (P0 + P1) : 0) + (noise ? (int64_t)steps * B * Tv : 0);
+    if (n == 0) return hipSuccess;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gt_rng_fill_kernel, dim3(blocks), dim3(256), 0, stream, seed_ptr, masks, noise, steps, B, P0, P1, Tv, drop_rate);
+    return hipGetLastError();
+}
+
 // State re-initialisation inside captured graphs is a KERNEL node, not a memset node: on ROCm 7.x a
 // hipMemsetAsync node was observed to race with the kernel node that follows it (stale LSTM state after a
 // replay with a different batch), while kernel->kernel edges are always honoured.

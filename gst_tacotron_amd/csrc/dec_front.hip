@@ -103,6 +103,8 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         const int n0 = P.rec_end[0] - P.rec_begin[0];
         const int total = n0 + (P.rec_end[1] - P.rec_begin[1]);
         const int mchunks = (P.B + 31) / 32;
+        const int wslot = (int)blockIdx.x == P.B ? 8 : ((int)blockIdx.x == (int)gridDim.x - 1 ? 10 : -1);   // diagnostics
+        if (P.dbg && wslot >= 0 && threadIdx.x == 0) P.dbg[wslot] = __builtin_amdgcn_s_memrealtime();
         for (int job = (int)blockIdx.x - P.B; job < total; job += P.n_workers) {
             const int layer = job < n0 ? 0 : 1;
             const int tile = layer == 0 ? P.rec_begin[0] + job : P.rec_begin[1] + (job - n0);
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
                 __syncthreads();
             }
         }
+        if (P.dbg && wslot >= 0 && threadIdx.x == 0) P.dbg[wslot + 1] = __builtin_amdgcn_s_memrealtime();
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,7 +133,15 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     float* pv = sc + ((TvFull + 3) & ~3);
     float* al = pv + ((TvFull + 3) & ~3);
     float* red = al + ((TvFull + 3) & ~3);
-    float* partial = red + FT;
+    // staged at kernel start so that no phase of the dependent chain issues a global load of its own: loads return in
+    // issue order, so waiting for a late small load also waits for every weight prefetch issued before it (~2 us)
+    float* sb0 = red + FT;                     // prenet0 bias [P0]
+    float* sb1 = sb0 + P0;                     // prenet1 bias [P1]
+    float* sbq = sb1 + P1;                     // query bias [A]
+    float* sk0 = sbq + A;                      // prenet0 keep * scale [P0] (injected mask or Philox)
+    float* sk1 = sk0 + P0;                     // prenet1 keep * scale [P1]
+    float* snz = sk1 + P1;                     // sigmoid noise [Tv] (injected or Philox)
+    float* partial = snz + ((TvFull + 3) & ~3);
     float* tile = partial + 4 * FT;
 
     // ---- issue every independent global load first
@@ -153,6 +164,16 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     if (tid < mel) in_x = P.frame[(size_t)b * P.ldframe + tid];                    // mel <= FT (checked on the host)
     if (tid < A) in_v = P.v[tid];
     if (tid < Tv) in_p = P.prev ? P.prev[(size_t)b * P.ldprev + tid] : (tid == 0 ? 1.f : 0.f);
+    const uint64_t seed = *P.seed_ptr;
+    const float sbias = P.score_bias[0];
+    // small vectors staged into LDS (see the carve): requested before the big loads, written after they are issued
+    float t_b0 = 0.f, t_b1 = 0.f, t_bq = 0.f, t_k0 = 1.f, t_k1 = 1.f, t_nz = 0.f;
+    if (tid < P0) t_b0 = P.b0[tid];
+    if (tid < P1) t_b1 = P.b1[tid];
+    if (tid < A) t_bq = P.bq[tid];
+    if (P.drop_rate > 0.f && P.mask0 && tid < P0) t_k0 = P.mask0[(size_t)b * P0 + tid];
+    if (P.drop_rate > 0.f && P.mask1 && tid < P1) t_k1 = P.mask1[(size_t)b * P1 + tid];
+    if (P.sigmoid_noise > 0.f && P.noise && tid < Tv) t_nz = P.noise[(size_t)b * P.ldnoise + tid];
     float4 v0[NP];
     load_rows(v0, 0);                                   // processed-memory rows of chunk 0 (64 KiB at 128x128)
 
@@ -164,13 +185,60 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     gemv_load<8>(P.w0, mel, P0, g0, 0, r0a);
     gemv_load<8>(P.w1, P0, P1, g1, 0, r1a);
 
+    // dropout keep-scales and sigmoid noise (Philox, ~100 VALU ops each) while the first loads are in flight
+    if (P.drop_rate > 0.f) {
+        if (!P.mask0 && tid < P0) t_k0 = (gt_u01(gt_philox(seed, (uint32_t)(b * P0 + tid), P.rng_step, 0u, 0x1000u).x) > P.drop_rate) ? 1.f : 0.f;
+        if (!P.mask1 && tid < P1) t_k1 = (gt_u01(gt_philox(seed, (uint32_t)(b * P1 + tid), P.rng_step, 0u, 0x1001u).x) > P.drop_rate) ? 1.f : 0.f;
+        t_k0 *= P.drop_scale; t_k1 *= P.drop_scale;
+    }
+    if (P.sigmoid_noise > 0.f && !P.noise && tid < Tv) {
+        const Philox4 r = gt_philox(seed, (uint32_t)(b * TvFull + tid), P.rng_step, 0u, GT_RNG_NOISE);
+        t_nz = gt_normal(r.x, r.y);
+    }
+    if (tid < P0) sk0[tid] = t_k0;
+    if (tid < P1) sk1[tid] = t_k1;
+    if (tid < Tv) snz[tid] = P.sigmoid_noise * t_nz;
+    // (sizes beyond one pass of the workgroup: never at the reference's dimensions)
+    for (int c = tid + FT; c < P0; c += FT) {
+        sb0[c] = P.b0[c];
+        float keep = 1.f;
+        if (P.drop_rate > 0.f) {
+            keep = P.mask0 ? P.mask0[(size_t)b * P0 + c]
+                           : ((gt_u01(gt_philox(seed, (uint32_t)(b * P0 + c), P.rng_step, 0u, 0x1000u).x) > P.drop_rate) ? 1.f : 0.f);
+            keep *= P.drop_scale;
+        }
+        sk0[c] = keep;
+    }
+    for (int c = tid + FT; c < P1; c += FT) {
+        sb1[c] = P.b1[c];
+        float keep = 1.f;
+        if (P.drop_rate > 0.f) {
+            keep = P.mask1 ? P.mask1[(size_t)b * P1 + c]
+                           : ((gt_u01(gt_philox(seed, (uint32_t)(b * P1 + c), P.rng_step, 0u, 0x1001u).x) > P.drop_rate) ? 1.f : 0.f);
+            keep *= P.drop_scale;
+        }
+        sk1[c] = keep;
+    }
+    for (int c = tid + FT; c < A; c += FT) sbq[c] = P.bq[c];
+    for (int t = tid + FT; t < Tv; t += FT) {
+        float nz = 0.f;
+        if (P.sigmoid_noise > 0.f) {
+            if (P.noise) nz = P.noise[(size_t)b * P.ldnoise + t];
+            else {
+                const Philox4 r = gt_philox(seed, (uint32_t)(b * TvFull + t), P.rng_step, 0u, GT_RNG_NOISE);
+                nz = gt_normal(r.x, r.y);
+            }
+        }
+        snz[t] = P.sigmoid_noise * nz;
+    }
+    if (tid < P0) sb0[tid] = t_b0;
+    if (tid < P1) sb1[tid] = t_b1;
+    if (tid < A) sbq[tid] = t_bq;
     if (tid < mel) xs[tid] = in_x;
     if (tid < A) vs[tid] = in_v;
     if (tid < Tv) pv[tid] = in_p;
     for (int t = tid + FT; t < Tv; t += FT) pv[t] = P.prev ? P.prev[(size_t)b * P.ldprev + t] : 0.f;
     GT_STAMP(P.dbg, 0);
-    const float sbias = P.score_bias[0];
-    const uint64_t seed = *P.seed_ptr;
     store_rows(v0);                                     // the rows were requested first, so they are back first
     asm volatile("" ::: "memory");                        // keep the next request BEHIND the tile write (register budget)
     float4 r1b[8];
@@ -188,19 +256,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     float4 r2a[8];
     gemv_load<8>(P.wq, P1, A, g2, 0, r2a);              // query weights: in flight while prenet0/1 compute
     __syncthreads();
-    for (int c = tid; c < P0; c += FT) {
-        float v = fmaxf(reduce_partial(partial, g0.kparts, P0, c) + P.b0[c], 0.f);
-        if (P.drop_rate > 0.f) {
-            float keep;
-            if (P.mask0) keep = P.mask0[(size_t)b * P0 + c];
-            else {
-                Philox4 ph = gt_philox(seed, (uint32_t)(b * P0 + c), P.rng_step, 0u, 0x1000u);
-                keep = (gt_u01(ph.x) > P.drop_rate) ? 1.f : 0.f;
-            }
-            v = v * P.drop_scale * keep;
-        }
-        y0[c] = v;
-    }
+    for (int c = tid; c < P0; c += FT) y0[c] = fmaxf(reduce_partial(partial, g0.kparts, P0, c) + sb0[c], 0.f) * sk0[c];
     __syncthreads();
     GT_STAMP(P.dbg, 2);
     // ---- prenet layer 1
@@ -212,16 +268,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     }
     __syncthreads();
     for (int c = tid; c < P1; c += FT) {
-        float v = fmaxf(reduce_partial(partial, g1.kparts, P1, c) + P.b1[c], 0.f);
-        if (P.drop_rate > 0.f) {
-            float keep;
-            if (P.mask1) keep = P.mask1[(size_t)b * P1 + c];
-            else {
-                Philox4 ph = gt_philox(seed, (uint32_t)(b * P1 + c), P.rng_step, 0u, 0x1001u);
-                keep = (gt_u01(ph.x) > P.drop_rate) ? 1.f : 0.f;
-            }
-            v = v * P.drop_scale * keep;
-        }
+        const float v = fmaxf(reduce_partial(partial, g1.kparts, P1, c) + sb1[c], 0.f) * sk1[c];
         y1[c] = v;
         P.xa[gt_blk_off(b, c, P.MT)] = v;           // LSTM-1 input (blocked), k in [0, P1)
     }
@@ -234,7 +281,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         gemv_store(g2, A, acc, partial);
     }
     __syncthreads();
-    for (int c = tid; c < A; c += FT) qs[c] = reduce_partial(partial, g2.kparts, A, c) + P.bq[c];
+    for (int c = tid; c < A; c += FT) qs[c] = reduce_partial(partial, g2.kparts, A, c) + sbq[c];
     __syncthreads();
     GT_STAMP(P.dbg, 4);
 
@@ -270,15 +317,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     // ---- noise + sigmoid
     for (int t = tid; t < Tv; t += FT) {
         float s = sc[t];
-        if (P.sigmoid_noise > 0.f) {
-            float nz;
-            if (P.noise) nz = P.noise[(size_t)b * P.ldnoise + t];
-            else {
-                Philox4 r = gt_philox(seed, (uint32_t)(b * TvFull + t), P.rng_step, 0u, GT_RNG_NOISE);
-                nz = gt_normal(r.x, r.y);
-            }
-            s += P.sigmoid_noise * nz;
-        }
+        if (P.sigmoid_noise > 0.f) s += snz[t];
         sc[t] = gt_sigmoid(s);
     }
     __syncthreads();
@@ -354,6 +393,7 @@ static size_t front_lds_bytes(const DecFrontArgs& a) {
     const size_t tv4 = (a.Tv + 3) & ~3;
     const int L = a.A == 16 ? 4 : 8;
     size_t fl = ((mx + 3) & ~3) + a.P0 + a.P1 + 2 * (size_t)a.A + 3 * tv4 + FT + 4 * (size_t)FT;
+    fl += 2 * (size_t)a.P0 + 2 * (size_t)a.P1 + a.A + tv4;      // staged biases, keep-scales, noise
     fl += (size_t)(FT / L) * (a.A + 4);             // processed-memory tile
     const size_t worker = SkinnyLds<FT / 64>::kFloats;
     if (fl < worker) fl = worker;

@@ -525,6 +525,15 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     if (g.att_type == GSTTACO_ATT_LSA) HIPCHECK(c, gt_launch_zero(c->w_lsa_state, (size_t)B * Tv, s));   // Layers.py:356
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
+    // throughput mode: the whole decode's dropout masks and sigmoid noise are generated up front (same Philox streams the
+    // step kernels would draw) into the buffers injected tensors use, so no step spends time on random numbers
+    {
+        float* fm = (!has_mask && g.prenet_rate > 0.f) ? c->w_masks : nullptr;
+        float* fn = (!has_noise && g.sigmoid_noise > 0.f && g.att_type != GSTTACO_ATT_LSA) ? c->w_noise : nullptr;
+        if (fm || fn) HIPCHECK(c, gt_launch_rng_fill(c->w_seed, fm, fn, steps, B, P0, P1, Tv, g.prenet_rate, s));
+        if (fm) has_mask = true;
+        if (fn) has_noise = true;
+    }
     int nprof[5] = {0, 0, 0, 0, 0};
     auto prof_begin = [&](int which) -> int {
         const size_t need = (size_t)2 * (nprof[which] + 1);

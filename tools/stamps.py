@@ -23,3 +23,5 @@ f = [buf[i] for i in range(16)]
 t0 = f[0]
 print("front raw (us since stamp0):", {i: round((f[i]-t0)/100.0, 2) for i in range(16) if f[i]})
 print("front -> lstm1 start gap (us):", (buf[16] - buf[7]) / 100.0, " lstm1 end -> lstm2 start:", (buf[32] - buf[19]) / 100.0)
+w = {i: round((f[i]-t0)/100.0, 2) for i in (8, 9, 10, 11) if f[i]}
+print("front workers (us since utterance-WG0 stamp0): first worker start/end", w.get(8), w.get(9), " last worker start/end", w.get(10), w.get(11))
