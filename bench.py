@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mixed", action="store_true", help="Use_Mixed_Precision: bf16 GEMM operands, fp32 accumulation (BASELINE "
+                    "configs[4]); NOT the headline metric -- dtype is then reported as bf16")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
@@ -109,6 +111,7 @@ def main():
     torch.cuda.set_device(local_rank)
 
     hp, inputs = synthetic.config_inputs("cfg2", batch=BATCH_PER_GPU, seed=1 + rank)
+    hp["Use_Mixed_Precision"] = bool(args.mixed)
     w = weights.synthetic_weights(hp, seed=0)
     B, Tv = inputs["tokens"].shape
     Tref1 = inputs["mels_for_gst"].shape[1]
@@ -191,7 +194,7 @@ def main():
             "metric": "mel-frames/s", "value": frames / elapsed, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.mixed else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: GST on, batch 32 per GPU, 128-token utterances, "
                                    "Step_Reduction 2, Max_Step 1000, LJSpeech 80-mel hparams; whole Inference_Step "
                                    "(encoder+GST+decode+postnet, vocoder excluded)",

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsttaco.so")
 
 MAX_LAYERS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 ATT_CODES = {"BMA": 0, "SMA": 1, "LSA": 2}
 
 # every symbol include/gsttaco.h declares
@@ -55,6 +55,7 @@ class Config(ctypes.Structure):
         ("voc_rnn", ctypes.c_int32),
         ("sample_rate", ctypes.c_int32), ("frame_length", ctypes.c_int32), ("frame_shift", ctypes.c_int32),
         ("max_abs_mel", ctypes.c_float), ("max_wav_samples", ctypes.c_int32),
+        ("mixed_precision", ctypes.c_int32),
         ("max_batch", ctypes.c_int32), ("max_tokens", ctypes.c_int32), ("max_ref_frames", ctypes.c_int32),
     ]
 
@@ -165,6 +166,7 @@ def make_config(hp, vocab=None, device=0, max_batch=32, max_tokens=256, max_ref_
         for i, (f, k) in enumerate(zip(d.voc_proj_filters, d.voc_proj_kernels)):
             c.voc_proj_filters[i], c.voc_proj_kernels[i] = f, k
         c.highway_count, c.highway_size, c.voc_rnn = d.highway_count, d.highway_size, d.voc_rnn
+    c.mixed_precision = int(bool(hp.get("Use_Mixed_Precision", False)))
     c.max_batch, c.max_tokens, c.max_ref_frames = max_batch, max_tokens, max_ref_frames
     return c
 

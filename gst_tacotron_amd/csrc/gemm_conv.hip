@@ -162,8 +162,158 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- mixed precision
+// Same GEMM with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Workgroup tile (RM*64) x 128, 4 waves as
+// 2 x 2, BK = 64.  A rows are gathered as in the fp32 kernel (float4 pieces of an im2col row), rounded to bf16 (RNE) and
+// written k-contiguous into LDS; the weights are stored transposed ([n][k], k contiguous) at finalize so both operands are
+// one ds_read_b128 per lane per MFMA.  Row pitch BKH + 8 halves (144 B): the 16 lanes of a b128 phase hit 16 distinct
+// 4-bank groups.
+#define BKH 64
+#define LDH (BKH + 8)
+
+template <int RM>
+__global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) {
+    constexpr int BM = 2 * RM * 32, BN = 128, RN = 2;
+    constexpr int A_F4 = BM * (BKH / 4) / 256;          // float4 (4 k of one row) per thread per slice
+    constexpr int B_U4 = BN * (BKH / 8) / 256;          // 16-byte pieces (8 k of one column) per thread per slice
+    __shared__ __attribute__((aligned(16))) __bf16 As[BM * LDH];
+    __shared__ __attribute__((aligned(16))) __bf16 Bs[BN * LDH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int Mtot = A.B * A.T;
+    const int K = A.taps * A.Cin;
+
+    int a_b[A_F4], a_t[A_F4], a_len[A_F4];
+    bool a_ok[A_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int f = tid + i * 256;
+        const int m = m0 + (f >> 4);                    // 16 float4 per row
+        a_ok[i] = m < Mtot;
+        const int mm = a_ok[i] ? m : 0;
+        a_b[i] = mm / A.T;
+        a_t[i] = mm - a_b[i] * A.T;
+        a_len[i] = A.row_len ? min(A.T, A.row_len[a_b[i]]) : A.T;
+    }
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[A_F4];
+    uint4 rb[B_U4];
+    const __bf16* wt = reinterpret_cast<const __bf16*>(A.wt_bf16);
+    auto load_slice = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int f = tid + i * 256;
+            const int kk = k0 + (f & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_ok[i] && kk < K) {
+                const int tap = kk / A.Cin;
+                const int c = kk - tap * A.Cin;
+                const int ts = a_t[i] + tap - A.pad_before;
+                if (ts >= 0 && ts < a_len[i]) {
+                    const int64_t rowi = (int64_t)a_b[i] * A.T + ts;
+                    const float* rp = A.tokens ? A.x + (int64_t)A.tokens[rowi] * A.Cin : A.x + rowi * A.Cin;
+                    v = *reinterpret_cast<const float4*>(rp + c);
+                    if (A.pool2 && ts + 1 < a_len[i]) {
+                        const float4 v2 = *reinterpret_cast<const float4*>(rp + A.Cin + c);
+                        v.x = fmaxf(v.x, v2.x); v.y = fmaxf(v.y, v2.y); v.z = fmaxf(v.z, v2.z); v.w = fmaxf(v.w, v2.w);
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_U4; ++i) {
+            const int f = tid + i * 256;
+            const int n = f >> 3, kq = f & 7;           // 8 pieces of 8 k per column
+            rb[i] = *reinterpret_cast<const uint4*>(wt + (size_t)(n0 + n) * A.ldk + k0 + kq * 8);   // padded: always in range
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int f = tid + i * 256;
+            const int row = f >> 4, kq = (f & 15) * 4;
+            bf16x4 h;
+            h[0] = (__bf16)ra[i].x; h[1] = (__bf16)ra[i].y; h[2] = (__bf16)ra[i].z; h[3] = (__bf16)ra[i].w;
+            *reinterpret_cast<bf16x4*>(&As[row * LDH + kq]) = h;
+        }
+#pragma unroll
+        for (int i = 0; i < B_U4; ++i) {
+            const int f = tid + i * 256;
+            const int n = f >> 3, kq = f & 7;
+            *reinterpret_cast<uint4*>(&Bs[n * LDH + kq * 8]) = rb[i];
+        }
+    };
+
+    const int nslices = (K + BKH - 1) / BKH;
+    load_slice(0);
+    const int kh = lane >> 5, l31 = lane & 31;
+    for (int s = 0; s < nslices; ++s) {
+        __syncthreads();
+        store_slice();
+        __syncthreads();
+        if (s + 1 < nslices) load_slice((s + 1) * BKH);
+#pragma unroll
+        for (int ks = 0; ks < BKH / 16; ++ks) {
+            bf16x8 av[RM], bv[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+                av[i] = *reinterpret_cast<const bf16x8*>(&As[((wm * RM + i) * 32 + l31) * LDH + ks * 16 + kh * 8]);
+#pragma unroll
+            for (int j = 0; j < RN; ++j)
+                bv[j] = *reinterpret_cast<const bf16x8*>(&Bs[((wn * RN + j) * 32 + l31) * LDH + ks * 16 + kh * 8]);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int n = n0 + (wn * RN + j) * 32 + l31;
+        if (n >= A.N) continue;
+        const float sc = A.scale ? A.scale[n] : 1.f;
+        const float sh = A.shift ? A.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * RM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (m >= Mtot) continue;
+                float v = acc[i][j][e] * sc + sh;
+                if (A.rowbias) v += A.rowbias[(int64_t)(m / A.T) * A.N + n];
+                if (A.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (A.act == ACT_TANH) v = gt_tanh(v);
+                if (A.res) v += A.res[(int64_t)m * A.ldo + n];
+                A.out[(int64_t)m * A.ldo + n] = v;
+            }
+        }
+    }
+}
+
 hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const int M = a.B * a.T;
+    if (a.wt_bf16) {
+        const int nb = (a.N + 127) / 128;
+        if (((M + 127) / 128) * nb >= 256) {
+            hipLaunchKernelGGL((gt_conv_gemm_bf16_kernel<2>), dim3((M + 127) / 128, nb), dim3(256), 0, stream, a);
+        } else {
+            hipLaunchKernelGGL((gt_conv_gemm_bf16_kernel<1>), dim3((M + 63) / 64, nb), dim3(256), 0, stream, a);
+        }
+        return hipGetLastError();
+    }
     if (a.N > 96) {
         const int wg128 = ((M + 127) / 128) * ((a.N + 127) / 128);
         if (wg128 >= 256) {

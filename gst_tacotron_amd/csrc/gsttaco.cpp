@@ -39,6 +39,7 @@ struct PackedLinear {       // skinny-GEMM operand set
     float* wp = nullptr;
     float* bias = nullptr;
     int nkb = 0, ntiles = 0, N = 0;
+    int bf16 = 0;           // the pack holds bf16 weights (mixed precision)
 };
 
 struct ConvLayer {
@@ -104,6 +105,10 @@ struct gsttaco_ctx {
     int voc_dense_ldw = 0;
     float *w_vbank = nullptr, *w_vbuf[3] = {nullptr, nullptr, nullptr}, *w_vz = nullptr, *w_vrnn = nullptr, *w_vc = nullptr,
           *w_spec = nullptr;
+
+    // mixed precision (Use_Mixed_Precision): bf16 transposed copies of the conv-GEMM weights, keyed by the fp32 device pointer
+    struct Bf16W { void* wt; int ldk; };
+    std::map<const float*, Bf16W> bf16_w;
 
     // audio front / back end, initialised on first use
     bool audio_ready = false;
@@ -303,6 +308,48 @@ int upload(gsttaco_ctx* c, float** dst, const float* src, size_t n) {
     return 0;
 }
 
+// float -> bf16 bits, round to nearest even (what v_cvt_pk_bf16_f32 does for finite values)
+inline uint16_t bf16_bits(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN stays NaN
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// Mixed precision: registers the bf16 TRANSPOSED copy [ceil(N/128)*128][ldk] (k contiguous, zero padded, ldk =
+// ceil(K/64)*64) of a conv-GEMM weight [K, N] (row stride ldw) under its fp32 device pointer.
+int add_bf16(gsttaco_ctx* c, const float* dev_w, const float* host_w, int K, int N, int ldw) {
+    if (!c->cfg.mixed_precision) return 0;
+    const int ldk = (K + 63) / 64 * 64, npad = (N + 127) / 128 * 128;
+    std::vector<uint16_t> t((size_t)npad * ldk, 0);
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) t[(size_t)n * ldk + k] = bf16_bits(host_w[(size_t)k * ldw + n]);
+    void* d = nullptr;
+    int rc = dev_alloc(c, &d, t.size() * sizeof(uint16_t));
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpy(d, t.data(), t.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->bf16_w[dev_w] = gsttaco_ctx::Bf16W{d, ldk};
+    return 0;
+}
+
+hipError_t launch_conv(gsttaco_ctx* c, ConvGemmArgs a, hipStream_t s) {
+    if (c->cfg.mixed_precision) {
+        auto it = c->bf16_w.find(a.w);
+        if (it != c->bf16_w.end()) { a.wt_bf16 = it->second.wt; a.ldk = it->second.ldk; }
+    }
+    return gt_launch_conv_gemm(a, s);
+}
+
+hipError_t launch_skinny(gsttaco_ctx* c, int epi, SkinnyArgs a0, const SkinnyArgs* a1, int ntiles, hipStream_t s, int tag = TAG_GENERIC) {
+    (void)c;
+    return gt_launch_skinny(epi, a0, a1, ntiles, s, tag);
+}
+
+hipError_t launch_skinny_co(gsttaco_ctx* c, SkinnyArgs m, int ntiles, SkinnyArgs co, int co_begin, int co_end, hipStream_t s) {
+    (void)c;
+    return gt_launch_skinny_co(m, ntiles, co, co_begin, co_end, s);
+}
+
 // Fold inference BatchNorm into y = x*scale + shift (Appendix A.4).
 void fold_bn(const gsttaco_ctx* c, const std::string& prefix, std::vector<float>& scale, std::vector<float>& shift) {
     const auto& g = T(c, prefix + ".bn.gamma").data;
@@ -323,7 +370,7 @@ void fold_bn(const gsttaco_ctx* c, const std::string& prefix, std::vector<float>
 // lstm_units > 0: tile-local column g*4+u maps to source column g*H + tile*4 + u (gate-major Keras
 // layout i,f,c,o -> unit-major tiles so a workgroup owns whole hidden units).
 int pack_linear(gsttaco_ctx* c, PackedLinear* out, const std::vector<std::pair<const float*, int>>& mats,
-                int ncols, const float* bias, int lstm_units) {
+                int ncols, const float* bias, int lstm_units, bool allow_bf16 = true) {
     int K = 0;
     for (auto& m : mats) {
         if (m.second % 16) return fail(c, GSTTACO_E_INVALID, "skinny GEMM segment length must be a multiple of 16");
@@ -364,7 +411,30 @@ int pack_linear(gsttaco_ctx* c, PackedLinear* out, const std::vector<std::pair<c
     out->nkb = nkb;
     out->ntiles = ntiles;
     out->N = lstm_units > 0 ? lstm_units : ncols;
-    int rc = upload(c, &out->wp, wp.data(), wp.size());
+    int rc = 0;
+    out->bf16 = (c->cfg.mixed_precision && allow_bf16) ? 1 : 0;
+    if (out->bf16) {
+        // bf16 pack [tile][32-k block][lane][8]: slot i of lane (col = lane&15, q = lane>>4) holds
+        // k = 32 j + 16 (i>>2) + 4 q + (i&3) -- the order in which the step kernels meet the activations (skinny_body.h)
+        const int nkb32 = (nkb + 1) / 2;
+        std::vector<uint16_t> wq((size_t)ntiles * nkb32 * 64 * 8, 0);
+        for (int tile = 0; tile < ntiles; ++tile)
+            for (int j = 0; j < nkb32; ++j)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int sc = colmap(tile, lane & 15);
+                    if (sc < 0) continue;
+                    for (int i = 0; i < 8; ++i) {
+                        const int k = 32 * j + 16 * (i >> 2) + 4 * (lane >> 4) + (i & 3);
+                        if (k < K) wq[(((size_t)tile * nkb32 + j) * 64 + lane) * 8 + i] = bf16_bits(rowptr[k][sc]);
+                    }
+                }
+        void* d = nullptr;
+        if ((rc = dev_alloc(c, &d, wq.size() * sizeof(uint16_t)))) return rc;
+        HIPCHECK(c, hipMemcpy(d, wq.data(), wq.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        out->wp = reinterpret_cast<float*>(d);
+    } else {
+        rc = upload(c, &out->wp, wp.data(), wp.size());
+    }
     if (rc) return rc;
     return upload(c, &out->bias, bp.data(), bp.size());
 }
@@ -377,6 +447,7 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
     std::vector<float> sc, sh;
     fold_bn(c, prefix, sc, sh);
     int rc = upload(c, &L->w, k.data.data(), k.data.size());
+    if (!rc) rc = add_bf16(c, L->w, k.data.data(), L->taps * L->cin, L->cout, L->cout);
     if (!rc) rc = upload(c, &L->scale, sc.data(), sc.size());
     if (!rc) rc = upload(c, &L->shift, sh.data(), sh.size());
     return rc;
@@ -427,7 +498,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked) {
         a.pad_before = same_pad_before(Tv, L.taps, 1, nullptr);
         a.act = ACT_RELU;
         a.row_len = tlen;
-        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        HIPCHECK(c, launch_conv(c, a, s));
         x = c->w_act[cur]; tok = nullptr; cur ^= 1;
     }
     // BiLSTM: one launch per time step, both directions in grid.z; h is written straight into enc_out.
@@ -440,7 +511,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked) {
             const int tp = d == 0 ? tt - 1 : tt + 1;
             SkinnyArgs& k = a[d];
             memset(&k, 0, sizeof(k));
-            k.wp = c->bilstm[d].wp; k.bias = c->bilstm[d].bias;
+            k.wp = c->bilstm[d].wp; k.bf16 = c->bilstm[d].bf16; k.bias = c->bilstm[d].bias;
             k.seg[0] = SkinnySeg{x + (size_t)tt * C, (int64_t)Tv * C, C / 16, 0};
             if (t == 0) k.seg[1] = SkinnySeg{c->w_zero, 0, H / 16, 0};
             else k.seg[1] = SkinnySeg{c->w_enc + (size_t)tp * EO + d * H, (int64_t)Tv * EO, H / 16, 0};
@@ -449,7 +520,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked) {
             k.h = c->w_enc + (size_t)tt * EO + d * H; k.ldh = (int64_t)Tv * EO;
             k.row_len = tlen; k.t_index = tt;
         }
-        HIPCHECK(c, gt_launch_skinny(EPI_LSTM, a[0], &a[1], c->bilstm[0].ntiles, s, TAG_ENC_BILSTM));
+        HIPCHECK(c, launch_skinny(c, EPI_LSTM, a[0], &a[1], c->bilstm[0].ntiles, s, TAG_ENC_BILSTM));
     }
     return 0;
 }
@@ -493,11 +564,11 @@ int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
     if (g.gst_use) {
         SkinnyArgs k;
         memset(&k, 0, sizeof(k));
-        k.wp = c->val_gst.wp; k.bias = c->val_gst.bias;
+        k.wp = c->val_gst.wp; k.bf16 = c->val_gst.bf16; k.bias = c->val_gst.bias;
         k.seg[0] = SkinnySeg{c->w_gst, g.gst_att, g.gst_att / 16, 0};
         k.nkb = c->val_gst.nkb; k.M = B; k.N = g.att_size; k.n_split = g.att_size; k.MT = (B + 15) / 16;
         k.out = c->w_rowbias; k.ldo = g.att_size;
-        HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->val_gst.ntiles, s));
+        HIPCHECK(c, launch_skinny(c, EPI_LINEAR, k, nullptr, c->val_gst.ntiles, s));
         rowbias = c->w_rowbias;
     }
     ConvGemmArgs a{};
@@ -506,7 +577,7 @@ int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
     a.rowbias = rowbias;
     a.out = c->w_pm; a.ldo = g.att_size;
     a.B = B; a.T = Tv; a.Cin = c->enc_out; a.N = g.att_size; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
-    HIPCHECK(c, gt_launch_conv_gemm(a, s));
+    HIPCHECK(c, launch_conv(c, a, s));
     return 0;
 }
 
@@ -584,7 +655,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                     SkinnyArgs& rk = f.rec[layer];
                     const PackedLinear& L = c->lstm_h[layer];
                     const int H = layer == 0 ? H1 : H2;
-                    rk.wp = L.wp; rk.bias = L.bias; rk.nkb = L.nkb;
+                    rk.wp = L.wp; rk.bf16 = L.bf16; rk.bias = L.bias; rk.nkb = L.nkb;
                     rk.seg[0] = SkinnySeg{layer == 0 ? c->w_h1[p ^ 1] : c->w_h2[p ^ 1], 0, H / 16, 1};
                     rk.M = B; rk.N = H; rk.MT = MT;
                     rk.partial_out = c->w_part[layer];
@@ -600,31 +671,31 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         } else {
         // 1. prenet layer 0 on the last emitted frame (Taco2.py:186: decodings[:, -1]; zeros at t=0)
         memset(&k, 0, sizeof(k));
-        k.wp = c->prenet0.wp; k.bias = c->prenet0.bias;
+        k.wp = c->prenet0.wp; k.bf16 = c->prenet0.bf16; k.bias = c->prenet0.bias;
         k.seg[0] = SkinnySeg{frame_ptr, frame_ld, mel / 16, 0};
         k.nkb = c->prenet0.nkb; k.M = B; k.N = P0; k.n_split = P0; k.MT = MT;
         k.out = c->w_p1; k.ldo = P0;
         k.mask = mask0; k.ldm = P0;
         k.drop_rate = g.prenet_rate; k.drop_scale = drop_scale;
         k.seed_ptr = c->w_seed; k.rng_step = (uint32_t)t; k.rng_stream = 0x1000u;
-        HIPCHECK(c, gt_launch_skinny(EPI_RELU_DROP, k, nullptr, c->prenet0.ntiles, s));
+        HIPCHECK(c, launch_skinny(c, EPI_RELU_DROP, k, nullptr, c->prenet0.ntiles, s));
         // 2. prenet layer 1 -> xa[:, 0:P1]
         memset(&k, 0, sizeof(k));
-        k.wp = c->prenet1.wp; k.bias = c->prenet1.bias;
+        k.wp = c->prenet1.wp; k.bf16 = c->prenet1.bf16; k.bias = c->prenet1.bias;
         k.seg[0] = SkinnySeg{c->w_p1, P0, P0 / 16, 0};
         k.nkb = c->prenet1.nkb; k.M = B; k.N = P1; k.n_split = P1; k.MT = MT;
         k.out = c->w_xa; k.out_blocked = 1;
         k.mask = mask1; k.ldm = P1;
         k.drop_rate = g.prenet_rate; k.drop_scale = drop_scale;
         k.seed_ptr = c->w_seed; k.rng_step = (uint32_t)t; k.rng_stream = 0x1001u;
-        HIPCHECK(c, gt_launch_skinny(EPI_RELU_DROP, k, nullptr, c->prenet1.ntiles, s));
+        HIPCHECK(c, launch_skinny(c, EPI_RELU_DROP, k, nullptr, c->prenet1.ntiles, s));
         // 3. attention query projection (Steps.py:122)
         memset(&k, 0, sizeof(k));
-        k.wp = c->query.wp; k.bias = c->query.bias;
+        k.wp = c->query.wp; k.bf16 = c->query.bf16; k.bias = c->query.bias;
         k.seg[0] = SkinnySeg{c->w_xa, 0, P1 / 16, 1};
         k.nkb = c->query.nkb; k.M = B; k.N = att; k.n_split = att; k.MT = MT;
         k.out = c->w_q; k.ldo = att;
-        HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->query.ntiles, s));
+        HIPCHECK(c, launch_skinny(c, EPI_LINEAR, k, nullptr, c->query.ntiles, s));
         // 4. score / monotonic alignment / context -> xa[:, P1:P1+att]
         AttnStepArgs a{};
         a.q = c->w_q; a.ldq = att; a.pm = c->w_pm; a.v = c->att_v; a.score_bias = c->att_sb;
@@ -647,14 +718,14 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             if (split) {
                 // only the half that depends on this step's inputs; + partial_in (recurrent half + bias)
                 const PackedLinear& L = c->lstm_x[layer];
-                k.wp = L.wp; k.bias = L.bias; k.nkb = L.nkb;
+                k.wp = L.wp; k.bf16 = L.bf16; k.bias = L.bias; k.nkb = L.nkb;
                 if (layer == 0) k.seg[0] = SkinnySeg{c->w_xa, 0, XA / 16, 1};
                 else k.seg[0] = SkinnySeg{c->w_h1[p], 0, H1 / 16, 1};
                 k.partial_in = c->w_part[layer];
                 k.keep_weights = c->keep_x_weights;
             } else {
                 const PackedLinear& L = layer == 0 ? c->lstm0 : c->lstm1;
-                k.wp = L.wp; k.bias = L.bias; k.nkb = L.nkb;
+                k.wp = L.wp; k.bf16 = L.bf16; k.bias = L.bias; k.nkb = L.nkb;
                 if (layer == 0) {
                     k.seg[0] = SkinnySeg{c->w_xa, 0, XA / 16, 1};
                     k.seg[1] = SkinnySeg{c->w_h1[p ^ 1], 0, H1 / 16, 1};
@@ -667,12 +738,12 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             k.M = B; k.MT = MT;
             k.dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
             if (prof) { int rce = prof_begin(layer); if (rce) return rce; }
-            HIPCHECK(c, gt_launch_skinny(EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));
+            HIPCHECK(c, launch_skinny(c, EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));
             if (prof) { int rce = prof_end(layer); if (rce) return rce; }
         }
         // 7. projection [h2, ctx] -> r mel frames + stop logit, written in place (Taco2.py:112-118,194-205)
         memset(&k, 0, sizeof(k));
-        k.wp = c->proj.wp; k.bias = c->proj.bias;
+        k.wp = c->proj.wp; k.bf16 = c->proj.bf16; k.bias = c->proj.bias;
         k.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
         k.seg[1] = SkinnySeg{c->w_xa + (size_t)(P1 / 16) * BLK, 0, att / 16, 1};
         k.nkb = c->proj.nkb; k.M = B; k.N = c->proj_out; k.n_split = mel * r; k.MT = MT;
@@ -684,13 +755,13 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             SkinnyArgs rk;
             memset(&rk, 0, sizeof(rk));
             const PackedLinear& L = c->lstm_h[1];
-            rk.wp = L.wp; rk.bias = L.bias; rk.nkb = L.nkb;
+            rk.wp = L.wp; rk.bf16 = L.bf16; rk.bias = L.bias; rk.nkb = L.nkb;
             rk.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
             rk.M = B; rk.N = H2; rk.MT = MT;
             rk.partial_out = c->w_part[1];
-            HIPCHECK(c, gt_launch_skinny_co(k, c->proj.ntiles, rk, 0, co_tiles, s));
+            HIPCHECK(c, launch_skinny_co(c, k, c->proj.ntiles, rk, 0, co_tiles, s));
         } else {
-            HIPCHECK(c, gt_launch_skinny(EPI_LINEAR, k, nullptr, c->proj.ntiles, s));
+            HIPCHECK(c, launch_skinny(c, EPI_LINEAR, k, nullptr, c->proj.ntiles, s));
         }
         if (prof) { int rce = prof_end(3); if (rce) return rce; }
         if (prof) {     // empty bracket
@@ -717,7 +788,7 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
         a.B = B; a.T = Tf; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;
         a.pad_before = same_pad_before(Tf, L.taps, 1, nullptr);
         a.act = i < g.post_tanh ? ACT_TANH : ACT_NONE;     // tanh on the first post_tanh layers only (F9)
-        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        HIPCHECK(c, launch_conv(c, a, s));
         x = a.out; cur ^= 1;
     }
     return 0;
@@ -832,7 +903,7 @@ int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* m
         a.B = B; a.T = Tf; a.Cin = mel; a.N = g.bank_filters; a.taps = L.taps;
         a.pad_before = same_pad_before(Tf, L.taps, 1, nullptr);       // even kernels pad asymmetrically (F10)
         a.act = ACT_RELU;
-        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        HIPCHECK(c, launch_conv(c, a, s));
     }
     // MaxPool1D(2,1,'same') fused into the first projection conv's gather; Conv1D + BN (+ReLU except the last) (Taco2.py:319-340)
     const float* x = c->w_vbank;
@@ -848,7 +919,7 @@ int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* m
         a.pool2 = i == 0;
         const bool last = i == g.n_voc_proj - 1;
         if (last && !c->voc_pd_w) a.res = mel_in;                     // residual directly when no Dense follows (:373)
-        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        HIPCHECK(c, launch_conv(c, a, s));
         x = a.out; cin = L.cout; cur ^= 1;
     }
     if (c->voc_pd_w) {                                                // Dense back to mel width + residual (:342-345, 373)
@@ -856,7 +927,7 @@ int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* m
         a.x = x; a.w = c->voc_pd_w; a.shift = c->voc_pd_b; a.res = mel_in;
         a.out = c->w_vbuf[cur]; a.ldo = mel;
         a.B = B; a.T = Tf; a.Cin = cin; a.N = mel; a.taps = 1; a.act = ACT_NONE;
-        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        HIPCHECK(c, launch_conv(c, a, s));
         x = a.out; cin = mel; cur ^= 1;
     }
     const int S = g.highway_size;
@@ -865,7 +936,7 @@ int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* m
         a.x = x; a.w = c->voc_hin_w; a.shift = c->voc_hin_b;
         a.out = c->w_vbuf[cur]; a.ldo = S;
         a.B = B; a.T = Tf; a.Cin = cin; a.N = S; a.taps = 1; a.act = ACT_NONE;
-        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        HIPCHECK(c, launch_conv(c, a, s));
         x = a.out; cin = S; cur ^= 1;
     }
     float* hbuf[2] = {c->w_vbuf[cur], c->w_vbuf[2]};
@@ -875,7 +946,7 @@ int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* m
         a.x = x; a.w = c->voc_hw_w[i]; a.shift = c->voc_hw_b[i];
         a.out = c->w_vz; a.ldo = 2 * S;
         a.B = B; a.T = Tf; a.Cin = S; a.N = 2 * S; a.taps = 1; a.act = ACT_NONE;
-        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        HIPCHECK(c, launch_conv(c, a, s));
         HIPCHECK(c, gt_launch_highway(c->w_vz, x, hbuf[hcur], (int64_t)B * Tf, S, s));
         x = hbuf[hcur]; hcur ^= 1;
     }
@@ -889,7 +960,7 @@ int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* m
             const int tp = d == 0 ? tt - 1 : tt + 1;
             SkinnyArgs& k = a[d];
             memset(&k, 0, sizeof(k));
-            k.wp = c->voc_bilstm[d].wp; k.bias = c->voc_bilstm[d].bias;
+            k.wp = c->voc_bilstm[d].wp; k.bf16 = c->voc_bilstm[d].bf16; k.bias = c->voc_bilstm[d].bias;
             k.seg[0] = SkinnySeg{x + (size_t)tt * S, (int64_t)Tf * S, S / 16, 0};
             if (t == 0) k.seg[1] = SkinnySeg{c->w_zero, 0, H / 16, 0};
             else k.seg[1] = SkinnySeg{c->w_vrnn + (size_t)tp * EO + d * H, (int64_t)Tf * EO, H / 16, 0};
@@ -897,14 +968,14 @@ int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* m
             k.c = c->w_vc + (size_t)d * B * H;
             k.h = c->w_vrnn + (size_t)tt * EO + d * H; k.ldh = (int64_t)Tf * EO;
         }
-        HIPCHECK(c, gt_launch_skinny(EPI_LSTM, a[0], &a[1], c->voc_bilstm[0].ntiles, s, TAG_ENC_BILSTM));
+        HIPCHECK(c, launch_skinny(c, EPI_LSTM, a[0], &a[1], c->voc_bilstm[0].ntiles, s, TAG_ENC_BILSTM));
     }
     {   // Dense to the linear-spectrogram width (Taco2.py:252-260)
         ConvGemmArgs a{};
         a.x = c->w_vrnn; a.w = c->voc_dense_w; a.shift = c->voc_dense_b; a.ldw = c->voc_dense_ldw;
         a.out = spec; a.ldo = g.spec_dim;
         a.B = B; a.T = Tf; a.Cin = EO; a.N = g.spec_dim; a.taps = 1; a.act = ACT_NONE;
-        HIPCHECK(c, gt_launch_conv_gemm(a, s));
+        HIPCHECK(c, launch_conv(c, a, s));
     }
     return 0;
 }
@@ -1157,8 +1228,8 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     {
         const HostTensor &k0 = T(c, "decoder.prenet0.kernel"), &b0 = T(c, "decoder.prenet0.bias");
         const HostTensor &k1 = T(c, "decoder.prenet1.kernel"), &b1 = T(c, "decoder.prenet1.bias");
-        if ((rc = pack_linear(c, &c->prenet0, {{k0.data.data(), (int)k0.shape[0]}}, c->P0, b0.data.data(), 0))) return rc;
-        if ((rc = pack_linear(c, &c->prenet1, {{k1.data.data(), (int)k1.shape[0]}}, c->P1, b1.data.data(), 0))) return rc;
+        if ((rc = pack_linear(c, &c->prenet0, {{k0.data.data(), (int)k0.shape[0]}}, c->P0, b0.data.data(), 0, false))) return rc;
+        if ((rc = pack_linear(c, &c->prenet1, {{k1.data.data(), (int)k1.shape[0]}}, c->P1, b1.data.data(), 0, false))) return rc;
         if ((rc = upload(c, &c->pw0, k0.data.data(), k0.data.size()))) return rc;
         if ((rc = upload(c, &c->pb0, b0.data.data(), b0.data.size()))) return rc;
         if ((rc = upload(c, &c->pw1, k1.data.data(), k1.data.size()))) return rc;
@@ -1166,12 +1237,13 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         const HostTensor &qk = T(c, "decoder.attention.query.kernel"), &qb = T(c, "decoder.attention.query.bias");
         if ((rc = upload(c, &c->pwq, qk.data.data(), qk.data.size()))) return rc;
         if ((rc = upload(c, &c->pbq, qb.data.data(), qb.data.size()))) return rc;
-        if ((rc = pack_linear(c, &c->query, {{qk.data.data(), (int)qk.shape[0]}}, c->att, qb.data.data(), 0))) return rc;
+        if ((rc = pack_linear(c, &c->query, {{qk.data.data(), (int)qk.shape[0]}}, c->att, qb.data.data(), 0, false))) return rc;
         const HostTensor &vk = T(c, "decoder.attention.value.kernel"), &vb = T(c, "decoder.attention.value.bias");
         const int goff = g.gst_use ? g.gst_att : 0;     // memory channel order [gst | enc] (GST.py:121-124)
         if (g.gst_use)
             if ((rc = pack_linear(c, &c->val_gst, {{vk.data.data(), g.gst_att}}, c->att, vb.data.data(), 0))) return rc;
         if ((rc = upload(c, &c->val_enc_w, vk.data.data() + (size_t)goff * c->att, (size_t)c->enc_out * c->att))) return rc;
+        if ((rc = add_bf16(c, c->val_enc_w, vk.data.data() + (size_t)goff * c->att, c->enc_out, c->att, c->att))) return rc;
         if ((rc = upload(c, &c->val_bias, vb.data.data(), vb.data.size()))) return rc;
         if (g.att_type == GSTTACO_ATT_LSA) {
             auto up = [&](float** dst, const char* name) {
@@ -1217,7 +1289,9 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
             if ((rc = upload_conv(c, &c->voc_proj[i], "vocoder.proj" + std::to_string(i)))) return rc;
         auto upn = [&](float** dst, const std::string& name) {
             const HostTensor& t = T(c, name);
-            return upload(c, dst, t.data.data(), t.data.size());
+            int r = upload(c, dst, t.data.data(), t.data.size());
+            if (!r && t.shape.size() == 2) r = add_bf16(c, *dst, t.data.data(), (int)t.shape[0], (int)t.shape[1], (int)t.shape[1]);
+            return r;
         };
         if (c->index.count("vocoder.proj_dense.kernel")) {
             if ((rc = upn(&c->voc_pd_w, "vocoder.proj_dense.kernel"))) return rc;
@@ -1242,6 +1316,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
             for (int n = 0; n < S; ++n) { bcat[n] = br.data[n]; bcat[S + n] = bs.data[n]; }
             float *dw = nullptr, *db = nullptr;
             if ((rc = upload(c, &dw, wcat.data(), wcat.size()))) return rc;
+            if ((rc = add_bf16(c, dw, wcat.data(), S, 2 * S, 2 * S))) return rc;
             if ((rc = upload(c, &db, bcat.data(), bcat.size()))) return rc;
             c->voc_hw_w.push_back(dw); c->voc_hw_b.push_back(db);
         }
@@ -1260,6 +1335,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
             for (int r = 0; r < K; ++r) memcpy(&wpad[(size_t)r * ldw], &k.data[(size_t)r * N], (size_t)N * sizeof(float));
             c->voc_dense_ldw = ldw;
             if ((rc = upload(c, &c->voc_dense_w, wpad.data(), wpad.size()))) return rc;
+            if ((rc = add_bf16(c, c->voc_dense_w, wpad.data(), K, N, ldw))) return rc;
             if ((rc = upload(c, &c->voc_dense_b, b.data.data(), b.data.size()))) return rc;
         }
     }

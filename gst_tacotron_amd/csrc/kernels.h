@@ -22,7 +22,7 @@ __host__ __device__ inline size_t gt_blk_off(int row, int k, int MT) {
 }
 
 struct SkinnyArgs {
-    const float* wp;    // packed weights [ntiles][nkb][64 lanes][4]
+    const float* wp;    // packed weights [ntiles][nkb][64 lanes][4]; when `bf16`: bf16 [ntiles][ceil(nkb/2)][64 lanes][8]
     const float* bias;  // [ntiles*16] in packed column order
     SkinnySeg seg[3];
     int nkb;            // sum of seg nkb
@@ -46,6 +46,8 @@ struct SkinnyArgs {
     // masked-mode extension: EPI_LSTM rows whose time index t_index >= row_len[row] do not exist --
     // h is written as 0 and the cell state is left untouched (NULL = the reference's unmasked behaviour)
     const int32_t* row_len; int t_index;
+    int bf16;           // mixed precision (Use_Mixed_Precision): weights are bf16, activations are rounded to bf16 on load,
+                        // products accumulate in fp32 on v_mfma_f32_16x16x32_bf16; everything else stays fp32
     int keep_weights;   // 1: load the weights with the default cache policy (they are re-read every step and small enough
                         // to stay L2-resident) instead of non-temporally
     unsigned long long* dbg;   // diagnostic phase stamps (s_memrealtime, 100 MHz) of block 0, or NULL
@@ -73,6 +75,11 @@ struct ConvGemmArgs {
     const int32_t* row_len; // masked-mode extension (A12): input rows t >= row_len[b] read as zero, or NULL
     int ldw;                // row stride of w in floats (0 = N); lets N be odd (513) over a zero-padded multiple of 4
     int pool2;              // 1: the input row is max(x[t], x[t+1]) -- MaxPool1D(2, stride 1, 'same') fused into the gather
+    // mixed precision (Use_Mixed_Precision): the weights TRANSPOSED in bf16, [ceil(N/128)*128][ldk] with k contiguous and
+    // zero padding (ldk = ceil(taps*Cin/64)*64), or NULL = fp32 path.  Activations are rounded to bf16 on their way into
+    // LDS, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16), the epilogue and the output stay fp32.
+    const void* wt_bf16;
+    int ldk;
     float* out;             // [B*T, ldo]
     int64_t ldo;
     int B, T, Cin, N, taps, pad_before, act;

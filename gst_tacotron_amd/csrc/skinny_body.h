@@ -72,40 +72,95 @@ __device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int ti
         }
     }
 
-    for (int base = wave; base < nkb; base += NW * MAXI) {
-        float4 b[MAXI], x0[MAXI], x1[MAXI];
-        // issue every load of this chunk before the first MFMA: the wave's whole K range is in flight at once
+    if (A.bf16) {
+        // ---- mixed precision: K in blocks of 32 = two consecutive 16-blocks (2j, 2j+1).  MFMA k-slot (q = lane>>4, i = 0..7)
+        // <-> k = 32 j + 16 (i>>2) + 4 q + (i&3): a lane's A fragment is exactly the two float4 it loads today from the two
+        // 16-blocks, rounded to bf16 (v_cvt_pk_bf16_f32, RNE); the weights are packed to the same slot order at finalize,
+        // one 16-byte load per lane per 32 k.
+        constexpr int MAXB = MAXI / 2;
+        const int nkb32 = (nkb + 1) >> 1;
+        const uint4* wq = reinterpret_cast<const uint4*>(A.wp) + (size_t)tile * nkb32 * 64 + lane;
+        for (int base = wave; base < nkb32; base += NW * MAXB) {
+            uint4 b[MAXB];
+            float4 x0[MAXB][2], x1[MAXB][2];
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int kb = base + i * NW;               // wave-uniform
-            if (kb < nkb) {
-                const float *p0, *p1;
-                int lk, st;
-                if (kb < e0) { p0 = sp0[0]; p1 = sp1[0]; lk = kb; st = sstep[0]; }
-                else if (kb < e1) { p0 = sp0[1]; p1 = sp1[1]; lk = kb - e0; st = sstep[1]; }
-                else { p0 = sp0[2]; p1 = sp1[2]; lk = kb - e1; st = sstep[2]; }
-                if (NT_WEIGHTS && !A.keep_weights) {
-                    const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)kb * 64));
-                    b[i] = make_float4(t[0], t[1], t[2], t[3]);
-                } else {
-                    b[i] = wp[(size_t)kb * 64];
+            for (int i = 0; i < MAXB; ++i) {
+                const int kb32 = base + i * NW;             // wave-uniform
+                if (kb32 < nkb32) {
+                    if (NT_WEIGHTS && !A.keep_weights) {
+                        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wq + (size_t)kb32 * 64));
+                        b[i] = make_uint4(t[0], t[1], t[2], t[3]);
+                    } else {
+                        b[i] = wq[(size_t)kb32 * 64];
+                    }
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int kb = 2 * kb32 + hf;
+                        x0[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        x1[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (kb < nkb) {
+                            const float *p0, *p1;
+                            int lk, st;
+                            if (kb < e0) { p0 = sp0[0]; p1 = sp1[0]; lk = kb; st = sstep[0]; }
+                            else if (kb < e1) { p0 = sp0[1]; p1 = sp1[1]; lk = kb - e0; st = sstep[1]; }
+                            else { p0 = sp0[2]; p1 = sp1[2]; lk = kb - e1; st = sstep[2]; }
+                            x0[i][hf] = *reinterpret_cast<const float4*>(p0 + (size_t)lk * st);
+                            x1[i][hf] = *reinterpret_cast<const float4*>(p1 + (size_t)lk * st);
+                        }
+                    }
                 }
-                x0[i] = *reinterpret_cast<const float4*>(p0 + (size_t)lk * st);
-                x1[i] = *reinterpret_cast<const float4*>(p1 + (size_t)lk * st);
+            }
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int kb32 = base + i * NW;
+                if (kb32 < nkb32) {
+                    bf16x8 a0, a1, bw;
+                    a0[0] = (__bf16)x0[i][0].x; a0[1] = (__bf16)x0[i][0].y; a0[2] = (__bf16)x0[i][0].z; a0[3] = (__bf16)x0[i][0].w;
+                    a0[4] = (__bf16)x0[i][1].x; a0[5] = (__bf16)x0[i][1].y; a0[6] = (__bf16)x0[i][1].z; a0[7] = (__bf16)x0[i][1].w;
+                    a1[0] = (__bf16)x1[i][0].x; a1[1] = (__bf16)x1[i][0].y; a1[2] = (__bf16)x1[i][0].z; a1[3] = (__bf16)x1[i][0].w;
+                    a1[4] = (__bf16)x1[i][1].x; a1[5] = (__bf16)x1[i][1].y; a1[6] = (__bf16)x1[i][1].z; a1[7] = (__bf16)x1[i][1].w;
+                    __builtin_memcpy(&bw, &b[i], 16);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw, acc1, 0, 0, 0);
+                }
             }
         }
+    } else {
+    for (int base = wave; base < nkb; base += NW * MAXI) {
+            float4 b[MAXI], x0[MAXI], x1[MAXI];
+            // issue every load of this chunk before the first MFMA: the wave's whole K range is in flight at once
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i) {
-            const int kb = base + i * NW;
-            if (kb < nkb) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, b[i].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, b[i].x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, b[i].y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, b[i].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, b[i].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, b[i].z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, b[i].w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, b[i].w, acc1, 0, 0, 0);
+            for (int i = 0; i < MAXI; ++i) {
+                const int kb = base + i * NW;               // wave-uniform
+                if (kb < nkb) {
+                    const float *p0, *p1;
+                    int lk, st;
+                    if (kb < e0) { p0 = sp0[0]; p1 = sp1[0]; lk = kb; st = sstep[0]; }
+                    else if (kb < e1) { p0 = sp0[1]; p1 = sp1[1]; lk = kb - e0; st = sstep[1]; }
+                    else { p0 = sp0[2]; p1 = sp1[2]; lk = kb - e1; st = sstep[2]; }
+                    if (NT_WEIGHTS && !A.keep_weights) {
+                        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + (size_t)kb * 64));
+                        b[i] = make_float4(t[0], t[1], t[2], t[3]);
+                    } else {
+                        b[i] = wp[(size_t)kb * 64];
+                    }
+                    x0[i] = *reinterpret_cast<const float4*>(p0 + (size_t)lk * st);
+                    x1[i] = *reinterpret_cast<const float4*>(p1 + (size_t)lk * st);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int kb = base + i * NW;
+                if (kb < nkb) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, b[i].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, b[i].x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, b[i].y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, b[i].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, b[i].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, b[i].z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, b[i].w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, b[i].w, acc1, 0, 0, 0);
+                }
             }
         }
     }

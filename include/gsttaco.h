@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 5
+#define GSTTACO_ABI_VERSION 6
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -121,6 +121,9 @@ typedef struct gsttaco_config {
     int32_t frame_shift;        /* Sound.Frame_Shift (hop) */
     float   max_abs_mel;        /* Sound.Max_Abs_Mel; 0 = the [0,1] normalisation (Audio.py:92-93) */
     int32_t max_wav_samples;    /* capacity of the audio entry points per utterance; 0 = disabled */
+    /* Use_Mixed_Precision (reference Model.py:31-35 selects Keras mixed_float16; here: bf16 GEMM operands, fp32 accumulation,
+     * fp32 state / epilogues / outputs -- BASELINE configs[4]).  0 = everything fp32 (the parity path). */
+    int32_t mixed_precision;
     /* capacity: workspace is sized once, at finalize */
     int32_t max_batch;
     int32_t max_tokens;

@@ -21,6 +21,25 @@ BN_EPS = 1e-3   # tf.keras.layers.BatchNormalization default epsilon
 
 
 # ----------------------------------------------------------------------------- helpers
+# Mixed precision (Use_Mixed_Precision; BASELINE configs[4]): the HIP path rounds the operands of its MFMA GEMMs (Conv1D,
+# LSTM gates, Value / projection / vocoder Dense layers) to bfloat16 and accumulates in fp32; everything else -- prenet,
+# attention query and scores, GST, BN, activations, state -- stays fp32.  `mm` emulates exactly that when MIXED is set
+# (inference_step(mixed=True)); the reference's own mixed policy is float16 (Model.py:31-35), see DESIGN.md.
+MIXED = False
+
+
+def bf16_round(a):
+    """float -> nearest-even bfloat16 -> back (finite values), in the input's dtype."""
+    a = np.asarray(a)
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32)
+    return r.view(np.float32).reshape(a.shape).astype(a.dtype)
+
+
+def mm(a, b):
+    return bf16_round(a) @ bf16_round(b) if MIXED else a @ b
+
+
 def sigmoid(x):
     return 1.0 / (1.0 + np.exp(-x))
 
@@ -50,7 +69,7 @@ def conv1d_same(x, kernel):
     xp = np.pad(x, ((0, 0), (pb, pa), (0, 0)))
     y = np.zeros((B, T, kernel.shape[2]), dtype=x.dtype)
     for j in range(k):
-        y += xp[:, j:j + T, :] @ kernel[j]
+        y += mm(xp[:, j:j + T, :], kernel[j])
     return y
 
 
@@ -72,7 +91,7 @@ def conv2d_same(x, kernel, stride):
 
 def lstm_cell(x, h, c, kernel, rec, bias):
     """Keras LSTMCell (Appendix A.6): z=x.W+h.U+b, split i,f,c~,o."""
-    z = x @ kernel + h @ rec + bias
+    z = mm(x, kernel) + mm(h, rec) + bias
     u = h.shape[-1]
     i, f = sigmoid(z[:, :u]), sigmoid(z[:, u:2 * u])
     g, o = np.tanh(z[:, 2 * u:3 * u]), sigmoid(z[:, 3 * u:])
@@ -267,7 +286,7 @@ def attention_step(hp, w, query_in, processed_memory, prev_align, noise, lengths
 
 
 def process_memory(w, memory):
-    return memory @ w["decoder.attention.value.kernel"] + w["decoder.attention.value.bias"]     # Steps.py:123
+    return mm(memory, w["decoder.attention.value.kernel"]) + w["decoder.attention.value.bias"]  # Steps.py:123
 
 
 def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, return_states=False, token_lengths=None):
@@ -307,7 +326,7 @@ def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, r
             hs[i], cs[i] = lstm_cell(x, hs[i], cs[i], w[f"decoder.lstm{i}.kernel"],
                                      w[f"decoder.lstm{i}.recurrent_kernel"], w[f"decoder.lstm{i}.bias"])
             x = hs[i]
-        y = np.concatenate([x, ctx], -1) @ w["decoder.projection.kernel"] + w["decoder.projection.bias"]  # :112-113
+        y = mm(np.concatenate([x, ctx], -1), w["decoder.projection.kernel"]) + w["decoder.projection.bias"]  # :112-113
         pre[:, t * r:(t + 1) * r] = y[:, :mel * r].reshape(B, r, mel)        # :194-201
         stops[:, t] = y[:, mel * r]
         aligns[:, t] = align
@@ -341,8 +360,8 @@ def maxpool1d_same2(y):
 
 def highway(y, w_relu, b_relu, w_sig, b_sig):
     """One Highwaynet layer (reference Taco2.py:409-424): H*T + x*(1-T), H = relu dense, T = sigmoid dense."""
-    h = np.maximum(y @ w_relu + b_relu, 0)
-    t = sigmoid(y @ w_sig + b_sig)
+    h = np.maximum(mm(y, w_relu) + b_relu, 0)
+    t = sigmoid(mm(y, w_sig) + b_sig)
     return h * t + y * (1.0 - t)
 
 
@@ -363,10 +382,10 @@ def vocoder_taco1(hp, w, mels, dt):
         if i < n - 1:
             y = np.maximum(y, 0)
     if "vocoder.proj_dense.kernel" in w:                                      # :342-345
-        y = y @ w["vocoder.proj_dense.kernel"] + w["vocoder.proj_dense.bias"]
+        y = mm(y, w["vocoder.proj_dense.kernel"]) + w["vocoder.proj_dense.bias"]
     y = y + x                                                                 # residual :373
     if "vocoder.highway_in.kernel" in w:                                      # :348-351
-        y = y @ w["vocoder.highway_in.kernel"] + w["vocoder.highway_in.bias"]
+        y = mm(y, w["vocoder.highway_in.kernel"]) + w["vocoder.highway_in.bias"]
     for i in range(int(cb["Highwaynet"]["Count"])):                           # :409-424
         y = highway(y, w[f"vocoder.highway{i}.relu.kernel"], w[f"vocoder.highway{i}.relu.bias"],
                     w[f"vocoder.highway{i}.sigmoid.kernel"], w[f"vocoder.highway{i}.sigmoid.bias"])
@@ -374,14 +393,27 @@ def vocoder_taco1(hp, w, mels, dt):
     fwd = lstm_sequence(y, w[p + "fwd.kernel"], w[p + "fwd.recurrent_kernel"], w[p + "fwd.bias"])
     bwd = lstm_sequence(y, w[p + "bwd.kernel"], w[p + "bwd.recurrent_kernel"], w[p + "bwd.bias"], reverse=True)
     y = np.concatenate([fwd, bwd], -1)                                        # :357-361
-    return y @ w["vocoder.dense.kernel"] + w["vocoder.dense.bias"]            # :252-260
+    return mm(y, w["vocoder.dense.kernel"]) + w["vocoder.dense.bias"]        # :252-260
 
 
 def inference_step(hp, weights, tokens, mels_for_gst=None, mel_lengths_for_gst=None,
-                   prenet_masks=None, attn_noise=None, steps=None, dt=np.float64, token_lengths=None, with_vocoder=False):
-    """Reference Model.py:249-255 with the wiring of Model.py:108-129,145-156.
+                   prenet_masks=None, attn_noise=None, steps=None, dt=np.float64, token_lengths=None, with_vocoder=False,
+                   mixed=False):
+    """Reference Model.py:249-255 with the wiring of Model.py:108-129,145-156.  ``mixed`` emulates the HIP path's
+    Use_Mixed_Precision mode (bf16 GEMM operands, see `mm`).
     Returns (mels [B,S*r,mel] post-net, stops [B,S], None (vocoder out of scope), alignments [B,S,T_v])
     plus a dict of intermediates for per-module parity tests."""
+    global MIXED
+    prev_mixed, MIXED = MIXED, bool(mixed)
+    try:
+        return _inference_step(hp, weights, tokens, mels_for_gst, mel_lengths_for_gst, prenet_masks, attn_noise, steps, dt,
+                               token_lengths, with_vocoder)
+    finally:
+        MIXED = prev_mixed
+
+
+def _inference_step(hp, weights, tokens, mels_for_gst, mel_lengths_for_gst, prenet_masks, attn_noise, steps, dt,
+                    token_lengths, with_vocoder):
     w = cast_weights(weights, dt)
     enc = encoder(hp, w, tokens, dt, token_lengths)        # token_lengths=None: the reference's unmasked behaviour
     inter = {"encoder": enc}

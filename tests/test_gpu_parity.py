@@ -314,3 +314,102 @@ def test_config3_batch128_variable_length_with_padding_masks():
     torch.cuda.synchronize()
     assert np.abs(srt[0].cpu().numpy() - mel[order]).max() <= TOL
     assert np.abs(srt[1].cpu().numpy() - stop[order]).max() <= TOL
+
+
+# ------------------------------------------------------------------ mixed precision (BASELINE configs[4])
+# bf16 operands / fp32 accumulation in the MFMA GEMMs; the oracle emulates the same roundings (oracle_np.mm).  Where no
+# rounded activation feeds another rounded GEMM (one GEMM deep), or at the tiny dimensions, the HIP path reproduces the
+# emulation to fp32 noise (MIXED_EXACT).  Through deep stacks the comparison is ill-conditioned by construction: an fp32
+# activation that differs from the float64 emulation in its last bits occasionally rounds to the neighbouring bf16 value
+# (0.4 % of that element), and the synthetic-weight postnet amplifies such a flip ~10x per layer (measured: 1 layer
+# 9e-7, 2 layers 1e-4, 3 layers 1e-3, 5 layers 4e-3 max-abs; two CPU emulations in float64 / float32 differ by 1e-3 the
+# same way).  MIXED_TOL / MIXED_MEAN bound that; MIXED_VS_FP32 states how far the mode sits from fp32 on these inputs.
+MIXED_EXACT = 1e-5
+MIXED_TOL = 2e-2
+MIXED_MEAN = 2e-3
+MIXED_VS_FP32 = 0.25
+
+
+def _mixed_case(kind, seed=9):
+    from gst_tacotron_amd import synthetic, weights
+    if kind == "tiny":
+        hp = synthetic.tiny_hp("SMA", r=2, gst=True, max_step=24)
+        B, Tv, Tref, steps = 3, 12, 70, 12
+    else:
+        hp = synthetic.config_hp("cfg2")
+        B, Tv, Tref, steps = 5, 40, 90, 10
+    hp["Use_Mixed_Precision"] = True
+    w = weights.synthetic_weights(hp, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    tokens, tl = synthetic.make_tokens(rng, B, Tv)
+    mels, ml = synthetic.make_ref_mels(rng, B, Tref, mel=hp["Sound"]["Mel_Dim"])
+    masks, noise = synthetic.make_randomness(rng, steps, B, Tv, hp["Tacotron2"]["Decoder"]["Prenet"]["Size"])
+    return hp, w, tokens, tl, mels, ml, masks, noise, steps
+
+
+@pytest.mark.parametrize("kind", ["tiny", "full"])
+def test_mixed_precision_matches_the_bf16_emulating_oracle(kind):
+    import torch
+    from oracle import oracle_np
+    hp, w, tokens, tl, mels, ml, masks, noise, steps = _mixed_case(kind)
+    B, Tv = tokens.shape
+    m = _model(hp, w, B, Tv, mels.shape[1])
+    mel, stop, spec, align = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps,
+                                              with_vocoder=True)
+    torch.cuda.synchronize()
+    ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64, with_vocoder=True, mixed=True)
+    fp32 = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64, with_vocoder=True)
+    errs = {"mel": np.abs(mel.cpu().numpy() - ref[0]).max(), "stop": np.abs(stop.cpu().numpy() - ref[1]).max(),
+            "spec": np.abs(spec.cpu().numpy() - ref[2]).max(), "align": np.abs(align.cpu().numpy() - ref[3]).max()}
+    drift = np.abs(ref[0] - fp32[0]).max()
+    print(kind, "mixed vs emulating oracle", errs, " emulated-mixed vs fp32 oracle (mel)", drift)
+    if kind == "tiny":
+        assert max(errs.values()) <= MIXED_EXACT, errs
+    else:
+        assert max(errs.values()) <= MIXED_TOL, errs
+        assert np.abs(mel.cpu().numpy() - ref[0]).mean() <= MIXED_MEAN
+    assert 0.0 < drift <= MIXED_VS_FP32
+    hp32 = dict(hp); hp32["Use_Mixed_Precision"] = False
+    m32 = _model(hp32, w, B, Tv, mels.shape[1])
+    mel32 = m32.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps)[0]
+    torch.cuda.synchronize()
+    assert np.abs(mel32.cpu().numpy() - fp32[0]).max() <= TOL            # the flag off is still the fp32 parity path
+
+
+def test_mixed_precision_single_gemm_depth_is_exact_at_full_dimensions():
+    """Full-size kernels (128x128 bf16 conv tiles, 8- and 16-wave skinny GEMMs, co-scheduled workers) one GEMM deep:
+    a 1-layer postnet, the hoisted Value projection, and decoder step 0 from the oracle's memory."""
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    from oracle import oracle_np
+    hp, w, tokens, tl, mels, ml, masks, noise, steps = _mixed_case("full", seed=11)
+    B, Tv = tokens.shape
+    m = _model(hp, w, B, Tv, mels.shape[1])
+    w64 = oracle_np.cast_weights(w, np.float64)
+    oracle_np.MIXED = True
+    try:
+        enc_ref = oracle_np.encoder(hp, w64, tokens, np.float64)
+        gst_ref = oracle_np.style_token_layer(hp, w64, mels, ml, np.float64)
+        mem = oracle_np.gst_concat(enc_ref, gst_ref)
+        pre_ref, stop_ref, align_ref = oracle_np.decoder(hp, w64, mem, np.float64, masks.astype(np.float64),
+                                                         noise.astype(np.float64), steps=1)
+    finally:
+        oracle_np.MIXED = False
+    pre, stop, align = m.decode(enc_ref.astype(np.float32), gst_ref.astype(np.float32), masks, noise, steps=1)
+    torch.cuda.synchronize()
+    e = max(np.abs(pre.cpu().numpy() - pre_ref).max(), np.abs(align.cpu().numpy() - align_ref).max())
+    print("decoder step 0 (value projection, LSTM x2, projection)", e)
+    assert e <= 1e-4                      # three GEMMs deep (h1, h2 are rounded again): a flip is possible, rarely
+    hp1 = synthetic.config_hp("cfg2"); hp1["Use_Mixed_Precision"] = True
+    hp1["Tacotron2"]["Decoder"]["Conv"].update({"Filters": [], "Kernel_Size": [], "Strides": []})
+    w1 = weights.synthetic_weights(hp1, seed=12)
+    m1 = _model(hp1, w1, 5, 8, 4)
+    x = np.clip(np.random.default_rng(1).normal(0, 1.5, (5, 150, 80)), -4, 4).astype(np.float32)
+    post = m1.postnet(x).cpu().numpy()
+    oracle_np.MIXED = True
+    try:
+        ref = oracle_np.postnet(hp1, oracle_np.cast_weights(w1, np.float64), x.astype(np.float64), np.float64)
+    finally:
+        oracle_np.MIXED = False
+    print("1-layer postnet", np.abs(post - ref).max())
+    assert np.abs(post - ref).max() <= MIXED_EXACT

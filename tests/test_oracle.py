@@ -191,3 +191,27 @@ def test_vocoder_output_shape_and_no_time_leak_across_batch():
     assert spec.shape == (3, 10, 33)
     alone = oracle_np.vocoder_taco1(hp, w, mel[1:2], np.float64)
     np.testing.assert_allclose(spec[1:2], alone, atol=1e-12)
+
+
+def test_bf16_rounding_emulation():
+    """oracle_np.bf16_round = round-to-nearest-even on the top 16 bits (what v_cvt_pk_bf16_f32 does)."""
+    r = oracle_np.bf16_round
+    assert r(np.float32(1.0)) == 1.0 and r(np.float32(-2.5)) == -2.5
+    assert r(np.float32(1.0 + 2.0 ** -8)) == 1.0                      # tie -> even mantissa
+    assert r(np.float32(1.0 + 3 * 2.0 ** -8)) == 1.0 + 2.0 ** -6     # tie -> even (up)
+    assert r(np.float32(1.0 + 2.0 ** -8 + 2.0 ** -20)) == 1.0 + 2.0 ** -7
+    x = np.random.default_rng(0).normal(size=1000)
+    assert np.abs(r(x) - x).max() <= np.abs(x).max() * 2.0 ** -8 and r(x).dtype == x.dtype
+    a, b = np.random.default_rng(1).normal(size=(4, 8)), np.random.default_rng(2).normal(size=(8, 3))
+    assert np.array_equal(oracle_np.mm(a, b), a @ b)                 # off by default
+    hp = synthetic.tiny_hp()
+    w = weights.synthetic_weights(hp, seed=1)
+    rng = np.random.default_rng(3)
+    tok, _ = synthetic.make_tokens(rng, 2, 9)
+    mels, ml = synthetic.make_ref_mels(rng, 2, 64, mel=16)
+    masks, noise = synthetic.make_randomness(rng, 6, 2, 9, [32, 32])
+    f = oracle_np.inference_step(hp, w, tok, mels, ml, masks, noise, steps=6)
+    mx = oracle_np.inference_step(hp, w, tok, mels, ml, masks, noise, steps=6, mixed=True)
+    assert not oracle_np.MIXED
+    d = np.abs(f[0] - mx[0]).max()
+    assert 0 < d < 0.2
