@@ -91,7 +91,10 @@ __device__ __forceinline__ float front_wave_incl_scan(float x, int lane) {
     return x;
 }
 
-template <int L, int NP>
+// Z0: the projection launch of the previous step already produced this step's prenet-0 pre-activations (the projection and
+// the first prenet Dense are both linear: frame.W0 + b0 = [h2|ctx].(Wp_last.W0) + (bp_last.W0 + b0), DecFrontArgs::z0), so the
+// chain starts at prenet 1 and the query weights are requested at kernel start in place of prenet 0's.
+template <int L, int NP, bool Z0>
 __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     constexpr int A = 4 * L * NP;
     constexpr int ROWS = FT / L;            // memory rows per pass (one LDS tile)
@@ -161,14 +164,15 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     };
     // small operands first: loads return in issue order, so their LDS writes below wait only for themselves
     float in_x = 0.f, in_v = 0.f, in_p = 0.f;
-    if (tid < mel) in_x = P.frame[(size_t)b * P.ldframe + tid];                    // mel <= FT (checked on the host)
+    if (!Z0 && tid < mel) in_x = P.frame[(size_t)b * P.ldframe + tid];             // mel <= FT (checked on the host)
+    if (Z0 && tid < P0) in_x = P.z0[(size_t)b * P0 + tid];
     if (tid < A) in_v = P.v[tid];
     if (tid < Tv) in_p = P.prev ? P.prev[(size_t)b * P.ldprev + tid] : (tid == 0 ? 1.f : 0.f);
     const uint64_t seed = *P.seed_ptr;
     const float sbias = P.score_bias[0];
     // small vectors staged into LDS (see the carve): requested before the big loads, written after they are issued
     float t_b0 = 0.f, t_b1 = 0.f, t_bq = 0.f, t_k0 = 1.f, t_k1 = 1.f, t_nz = 0.f;
-    if (tid < P0) t_b0 = P.b0[tid];
+    if (!Z0 && tid < P0) t_b0 = P.b0[tid];
     if (tid < P1) t_b1 = P.b1[tid];
     if (tid < A) t_bq = P.bq[tid];
     if (P.drop_rate > 0.f && P.mask0 && tid < P0) t_k0 = P.mask0[(size_t)b * P0 + tid];
@@ -182,7 +186,8 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     const GemvPlan g2 = make_plan(P1, A, tid);
     // register budget (128 VGPRs at 16 waves/CU): three 8-row weight blocks + the memory rows in flight at t=0
     float4 r0a[8], r1a[8];
-    gemv_load<8>(P.w0, mel, P0, g0, 0, r0a);
+    if (Z0) gemv_load<8>(P.wq, P1, A, g2, 0, r0a);      // (r0a holds the query weights in this variant)
+    else gemv_load<8>(P.w0, mel, P0, g0, 0, r0a);
     gemv_load<8>(P.w1, P0, P1, g1, 0, r1a);
 
     // dropout keep-scales and sigmoid noise (Philox, ~100 VALU ops each) while the first loads are in flight
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     if (tid < Tv) snz[tid] = P.sigmoid_noise * t_nz;
     // (sizes beyond one pass of the workgroup: never at the reference's dimensions)
     for (int c = tid + FT; c < P0; c += FT) {
-        sb0[c] = P.b0[c];
+        if (!Z0) sb0[c] = P.b0[c];
         float keep = 1.f;
         if (P.drop_rate > 0.f) {
             keep = P.mask0 ? P.mask0[(size_t)b * P0 + c]
@@ -231,10 +236,14 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         }
         snz[t] = P.sigmoid_noise * nz;
     }
-    if (tid < P0) sb0[tid] = t_b0;
+    if (!Z0 && tid < P0) sb0[tid] = t_b0;
     if (tid < P1) sb1[tid] = t_b1;
     if (tid < A) sbq[tid] = t_bq;
-    if (tid < mel) xs[tid] = in_x;
+    if (!Z0 && tid < mel) xs[tid] = in_x;
+    if (Z0) {
+        if (tid < P0) y0[tid] = fmaxf(in_x, 0.f) * t_k0;
+        for (int c = tid + FT; c < P0; c += FT) y0[c] = fmaxf(P.z0[(size_t)b * P0 + c], 0.f) * sk0[c];
+    }
     if (tid < A) vs[tid] = in_v;
     if (tid < Tv) pv[tid] = in_p;
     for (int t = tid + FT; t < Tv; t += FT) pv[t] = P.prev ? P.prev[(size_t)b * P.ldprev + t] : 0.f;
@@ -247,17 +256,22 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     GT_STAMP(P.dbg, 1);
 
     // ---- prenet layer 0
-    {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        gemv_acc<8>(xs, mel, g0, 0, r0a, acc);
-        gemv_store(g0, P0, acc, partial);
-    }
-    asm volatile("" ::: "memory");                        // r0a is dead from here: its registers take the query weights
     float4 r2a[8];
-    gemv_load<8>(P.wq, P1, A, g2, 0, r2a);              // query weights: in flight while prenet0/1 compute
-    __syncthreads();
-    for (int c = tid; c < P0; c += FT) y0[c] = fmaxf(reduce_partial(partial, g0.kparts, P0, c) + sb0[c], 0.f) * sk0[c];
-    __syncthreads();
+    if (!Z0) {
+        {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            gemv_acc<8>(xs, mel, g0, 0, r0a, acc);
+            gemv_store(g0, P0, acc, partial);
+        }
+        asm volatile("" ::: "memory");                    // r0a is dead from here: its registers take the query weights
+        gemv_load<8>(P.wq, P1, A, g2, 0, r2a);          // query weights: in flight while prenet0/1 compute
+        __syncthreads();
+        for (int c = tid; c < P0; c += FT) y0[c] = fmaxf(reduce_partial(partial, g0.kparts, P0, c) + sb0[c], 0.f) * sk0[c];
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r2a[i] = r0a[i];
+    }
     GT_STAMP(P.dbg, 2);
     // ---- prenet layer 1
     {
@@ -417,7 +431,8 @@ bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv) {
 
 template <int L, int NP>
 static hipError_t front_launch(const DecFrontArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((gt_dec_front_kernel<L, NP>), dim3(a.B + a.n_workers), dim3(FT), front_lds_bytes(a), s, a);
+    if (a.z0) hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, true>), dim3(a.B + a.n_workers), dim3(FT), front_lds_bytes(a), s, a);
+    else hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, false>), dim3(a.B + a.n_workers), dim3(FT), front_lds_bytes(a), s, a);
     return hipGetLastError();
 }
 
@@ -435,7 +450,10 @@ hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t s) {
 hipError_t gt_dec_front_init() {
     hipError_t e;
 #define FRONT_ATTR(L, NP)                                                                         \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP>),          \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP, false>),   \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
+    if (e != hipSuccess) return e;                                                              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP, true>),    \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
     if (e != hipSuccess) return e;
     FRONT_ATTR(4, 1) FRONT_ATTR(8, 1) FRONT_ATTR(8, 2) FRONT_ATTR(8, 4) FRONT_ATTR(8, 8)

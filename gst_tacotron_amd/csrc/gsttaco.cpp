@@ -92,6 +92,10 @@ struct gsttaco_ctx {
 
     float *pw0 = nullptr, *pb0 = nullptr, *pw1 = nullptr, *pb1 = nullptr, *pwq = nullptr, *pbq = nullptr;  // plain layouts (fused front)
     bool fused_front = true;
+    bool fuse_prenet0 = true;   // prenet-0 pre-activations computed by the previous step's projection launch (GSTTACO_FUSE_PRENET0=0 off)
+    PackedLinear proj_z;        // projection columns | padding to a tile | (Wp_last . W0) columns
+    int z_col0 = 0;
+    float* w_z0 = nullptr;
     float *val_enc_w = nullptr, *val_bias = nullptr, *att_v = nullptr, *att_sb = nullptr;
     float *loc_cw = nullptr, *loc_cb = nullptr, *loc_dw = nullptr, *loc_db = nullptr, *att_bias = nullptr;   // LSA extension
     float* w_lsa_state = nullptr;
@@ -634,10 +638,12 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         // the fused front end implements BMA/SMA; the LSA extension runs on the four-kernel path
         const bool fused = c->fused_front && g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv);
         const bool split = fused && c->split_rec;
+        const bool use_z0 = split && c->proj_z.wp != nullptr;        // prenet-0 rides in the projection launch
         if (fused) {
             // 1-4 fused: prenet x2, query projection, score / alignment / context (dec_front.hip)
             DecFrontArgs f{};
             f.frame = frame_ptr; f.ldframe = frame_ld;
+            f.z0 = (use_z0 && t > 0) ? c->w_z0 : nullptr;
             f.w0 = c->pw0; f.b0 = c->pb0; f.w1 = c->pw1; f.b1 = c->pb1; f.wq = c->pwq; f.bq = c->pbq;
             f.mask0 = mask0; f.mask1 = mask1;
             f.drop_rate = g.prenet_rate; f.drop_scale = drop_scale; f.seed_ptr = c->w_seed; f.rng_step = (uint32_t)t;
@@ -743,10 +749,15 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         }
         // 7. projection [h2, ctx] -> r mel frames + stop logit, written in place (Taco2.py:112-118,194-205)
         memset(&k, 0, sizeof(k));
-        k.wp = c->proj.wp; k.bf16 = c->proj.bf16; k.bias = c->proj.bias;
+        const PackedLinear& PJ = (use_z0 && t + 1 < steps) ? c->proj_z : c->proj;
+        k.wp = PJ.wp; k.bf16 = PJ.bf16; k.bias = PJ.bias;
         k.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
         k.seg[1] = SkinnySeg{c->w_xa + (size_t)(P1 / 16) * BLK, 0, att / 16, 1};
-        k.nkb = c->proj.nkb; k.M = B; k.N = c->proj_out; k.n_split = mel * r; k.MT = MT;
+        k.nkb = PJ.nkb; k.M = B; k.N = c->proj_out; k.n_split = mel * r; k.MT = MT;
+        if (&PJ == &c->proj_z) {
+            k.N = c->z_col0 + P0; k.n_valid2 = c->proj_out; k.col3 = c->z_col0;
+            k.out3 = c->w_z0; k.ldo3 = P0;
+        }
         k.out = c->w_pre + (size_t)t * r * mel; k.ldo = ld_pre;
         k.out2 = c->w_stop + t; k.ldo2 = steps;
         if (prof) { int rce = prof_begin(3); if (rce) return rce; }
@@ -759,9 +770,9 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             rk.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
             rk.M = B; rk.N = H2; rk.MT = MT;
             rk.partial_out = c->w_part[1];
-            HIPCHECK(c, launch_skinny_co(c, k, c->proj.ntiles, rk, 0, co_tiles, s));
+            HIPCHECK(c, launch_skinny_co(c, k, PJ.ntiles, rk, 0, co_tiles, s));
         } else {
-            HIPCHECK(c, launch_skinny(c, EPI_LINEAR, k, nullptr, c->proj.ntiles, s));
+            HIPCHECK(c, launch_skinny(c, EPI_LINEAR, k, nullptr, PJ.ntiles, s));
         }
         if (prof) { int rce = prof_end(3); if (rce) return rce; }
         if (prof) {     // empty bracket
@@ -1105,6 +1116,8 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->fused_front = !(ef && ef[0] == '0');
     const char* er = getenv("GSTTACO_SPLIT_REC");
     c->split_rec = !(er && er[0] == '0');
+    const char* ez = getenv("GSTTACO_FUSE_PRENET0");
+    c->fuse_prenet0 = !(ez && ez[0] == '0');
     const char* ek = getenv("GSTTACO_KEEP_X");
     if (ek) c->keep_x_weights = atoi(ek);
     const char* es = getenv("GSTTACO_STAMPS");
@@ -1273,6 +1286,32 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         }
         const HostTensor &pk = T(c, "decoder.projection.kernel"), &pb = T(c, "decoder.projection.bias");
         if ((rc = pack_linear(c, &c->proj, {{pk.data.data(), (int)pk.shape[0]}}, c->proj_out, pb.data.data(), 0))) return rc;
+        if (c->fuse_prenet0 && !g.mixed_precision) {
+            // The projection and the first prenet Dense are both linear and nothing sits between them at inference
+            // (Taco2.py:186 feeds decodings[:, -1] straight into the prenet): frame.W0 + b0 = [h2|ctx].(Wp_last.W0) +
+            // (bp_last.W0 + b0), Wp_last = the projection columns of the last of the r frames.  The fused columns ride in the
+            // projection launch, so the next step's front kernel starts at prenet 1 with 80 KB less to pull.
+            const HostTensor &k0 = T(c, "decoder.prenet0.kernel"), &b0 = T(c, "decoder.prenet0.bias");
+            const int K = (int)pk.shape[0], N0 = c->proj_out, mel = g.mel_dim, P0 = c->P0, last = (c->r - 1) * mel;
+            c->z_col0 = (N0 + 15) / 16 * 16;
+            const int NE = c->z_col0 + P0;
+            std::vector<float> we((size_t)K * NE, 0.f), be(NE, 0.f);
+            for (int k = 0; k < K; ++k) {
+                for (int n = 0; n < N0; ++n) we[(size_t)k * NE + n] = pk.data[(size_t)k * N0 + n];
+                for (int cc = 0; cc < P0; ++cc) {
+                    double a = 0.0;
+                    for (int j = 0; j < mel; ++j) a += (double)pk.data[(size_t)k * N0 + last + j] * (double)k0.data[(size_t)j * P0 + cc];
+                    we[(size_t)k * NE + c->z_col0 + cc] = (float)a;
+                }
+            }
+            for (int n = 0; n < N0; ++n) be[n] = pb.data[n];
+            for (int cc = 0; cc < P0; ++cc) {
+                double a = b0.data[cc];
+                for (int j = 0; j < mel; ++j) a += (double)pb.data[last + j] * (double)k0.data[(size_t)j * P0 + cc];
+                be[c->z_col0 + cc] = (float)a;
+            }
+            if ((rc = pack_linear(c, &c->proj_z, {{we.data(), K}}, NE, be.data(), 0))) return rc;
+        }
     }
     // ---- postnet
     c->post_conv.resize(g.n_post);
@@ -1357,6 +1396,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         if ((rc = fa(&c->w_act[i], B * Tv * actc))) return rc;
     if ((rc = fa(&c->w_enc, B * Tv * c->enc_out))) return rc;
     if ((rc = fa(&c->w_cenc, 2 * B * g.enc_rnn))) return rc;
+    if ((rc = fa(&c->w_z0, B * (size_t)c->P0))) return rc;
     c->zero_floats = ((B + 15) / 16 * 16) * std::max<size_t>({(size_t)mel, (size_t)g.enc_rnn, (size_t)c->H1, (size_t)c->H2,
                                                                (size_t)(g.voc_use ? g.voc_rnn : 0)});
     if ((rc = fa(&c->w_zero, c->zero_floats))) return rc;

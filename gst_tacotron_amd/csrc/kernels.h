@@ -33,6 +33,8 @@ struct SkinnyArgs {
     int out_blocked;    // LINEAR: `out` is a blocked activation buffer; LSTM: `h` is
     float* out; int64_t ldo;
     float* out2; int64_t ldo2;
+    // LINEAR, optional third region: columns [col3, N) go to out3, [n_split, n_valid2) to out2, [n_valid2, col3) are padding
+    float* out3; int64_t ldo3; int col3, n_valid2;
     // EPI_RELU_DROP
     const float* mask; int64_t ldm;     // keep-mask [M, N] or NULL -> Philox
     float drop_rate, drop_scale;
@@ -124,6 +126,8 @@ size_t gt_attn_lds_bytes(int Tv, int A, int loc_f, int loc_k, int* rows_lds);
 // ---------------------------------------------------------------- dec_front.hip
 struct DecFrontArgs {
     const float* frame; int64_t ldframe;    // [B, mel] last emitted frame (zero rows, ld 0, at step 0)
+    const float* z0;                        // [B, P0] prenet-0 PRE-activations incl. bias, produced with the previous step's
+                                            // projection (NULL: compute them here from `frame`)
     const float* w0; const float* b0;       // prenet0 [mel, P0] (TF layout), [P0]
     const float* w1; const float* b1;       // prenet1 [P0, P1], [P1]
     const float* wq; const float* bq;       // attention Query [P1, A], [A]

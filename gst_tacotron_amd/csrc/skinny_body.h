@@ -234,11 +234,14 @@ __device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int ti
                         v = v * A.drop_scale * keep;      // tf.nn.dropout: x * scale * mask
                     }
                 }
-                if (gcol < A.n_split) {
+                if (A.out3 && gcol >= A.col3) {
+                    A.out3[(size_t)grow * A.ldo3 + (gcol - A.col3)] = v;       // third column region (fused prenet-0)
+                } else if (gcol < A.n_split) {
                     if (A.out_blocked) A.out[gt_blk_off(grow, gcol, MT)] = v;
                     else A.out[(size_t)grow * A.ldo + gcol] = v;
+                } else if (!A.out3 || gcol < A.n_valid2) {
+                    A.out2[(size_t)grow * A.ldo2 + (gcol - A.n_split)] = v;
                 }
-                else A.out2[(size_t)grow * A.ldo2 + (gcol - A.n_split)] = v;
             }
         }
     }
