@@ -18,9 +18,11 @@
 // processed memory is read from L2 exactly once per step); row reduction by DPP/shuffle, context
 // reduction by shuffle across the wave's rows and LDS across waves.
 #include "skinny_body.h"
+#include "lean_body.h"
 #include "../../include/gsttaco.h"
 
 #define FT 1024            // threads per workgroup
+#define WT 2               // recurrent-half tiles per worker job
 #define FMAXR 16           // max weight rows (float4 loads) per lane per GEMV phase (two register blocks of 8)
 
 struct GemvPlan {
@@ -94,7 +96,7 @@ __device__ __forceinline__ float front_wave_incl_scan(float x, int lane) {
 // Z0: the projection launch of the previous step already produced this step's prenet-0 pre-activations (the projection and
 // the first prenet Dense are both linear: frame.W0 + b0 = [h2|ctx].(Wp_last.W0) + (bp_last.W0 + b0), DecFrontArgs::z0), so the
 // chain starts at prenet 1 and the query weights are requested at kernel start in place of prenet 0's.
-template <int L, int NP, bool Z0>
+template <int L, int NP, bool Z0, bool LEAN>
 __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     constexpr int A = 4 * L * NP;
     constexpr int ROWS = FT / L;            // memory rows per pass (one LDS tile)
@@ -103,16 +105,20 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x >= P.B) {
         // ---- worker workgroup: recurrent half of an LSTM gate GEMM (see DecFrontArgs::rec)
-        const int n0 = P.rec_end[0] - P.rec_begin[0];
-        const int total = n0 + (P.rec_end[1] - P.rec_begin[1]);
+        // jobs are groups of up to WT adjacent tiles of one layer sharing one pass over that layer's state (skinny_body.h)
+        const int wt = P.worker_tiles == 1 ? 1 : WT;
+        const int j0 = (P.rec_end[0] - P.rec_begin[0] + wt - 1) / wt;
+        const int total = j0 + (P.rec_end[1] - P.rec_begin[1] + wt - 1) / wt;
         const int mchunks = (P.B + 31) / 32;
         const int wslot = (int)blockIdx.x == P.B ? 8 : ((int)blockIdx.x == (int)gridDim.x - 1 ? 10 : -1);   // diagnostics
         if (P.dbg && wslot >= 0 && threadIdx.x == 0) P.dbg[wslot] = __builtin_amdgcn_s_memrealtime();
         for (int job = (int)blockIdx.x - P.B; job < total; job += P.n_workers) {
-            const int layer = job < n0 ? 0 : 1;
-            const int tile = layer == 0 ? P.rec_begin[0] + job : P.rec_begin[1] + (job - n0);
+            const int layer = job < j0 ? 0 : 1;
+            const int tile = P.rec_begin[layer] + (layer == 0 ? job : job - j0) * wt;
+            const int ntile = min(wt, P.rec_end[layer] - tile);
             for (int mc = 0; mc < mchunks; ++mc) {
-                gt_skinny_body<EPI_PARTIAL, FT / 64, true>(P.rec[layer], tile, mc, smem);
+                if (LEAN) gt_lean_partial<FT / 64, 4, WT>(P.lrec[layer], tile, ntile, mc, smem);
+                else gt_skinny_partial_multi<FT / 64, WT, true>(P.rec[layer], tile, ntile, mc, smem);
                 __syncthreads();
             }
         }
@@ -409,7 +415,8 @@ static size_t front_lds_bytes(const DecFrontArgs& a) {
     size_t fl = ((mx + 3) & ~3) + a.P0 + a.P1 + 2 * (size_t)a.A + 3 * tv4 + FT + 4 * (size_t)FT;
     fl += 2 * (size_t)a.P0 + 2 * (size_t)a.P1 + a.A + tv4;      // staged biases, keep-scales, noise
     fl += (size_t)(FT / L) * (a.A + 4);             // processed-memory tile
-    const size_t worker = SkinnyLds<FT / 64>::kFloats;
+    size_t worker = SkinnyLds<FT / 64>::kFloats;
+    if ((size_t)SkinnyMultiLds<FT / 64, WT>::kFloats > worker) worker = SkinnyMultiLds<FT / 64, WT>::kFloats;
     if (fl < worker) fl = worker;
     return fl * sizeof(float);
 }
@@ -431,8 +438,15 @@ bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv) {
 
 template <int L, int NP>
 static hipError_t front_launch(const DecFrontArgs& a, hipStream_t s) {
-    if (a.z0) hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, true>), dim3(a.B + a.n_workers), dim3(FT), front_lds_bytes(a), s, a);
-    else hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, false>), dim3(a.B + a.n_workers), dim3(FT), front_lds_bytes(a), s, a);
+    const dim3 grid(a.B + a.n_workers), block(FT);
+    const size_t lds = front_lds_bytes(a);
+    if (a.z0) {
+        if (a.lean_rec) hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, true, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, true, false>), grid, block, lds, s, a);
+    } else {
+        if (a.lean_rec) hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, false, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, false, false>), grid, block, lds, s, a);
+    }
     return hipGetLastError();
 }
 
@@ -449,14 +463,13 @@ hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t s) {
 
 hipError_t gt_dec_front_init() {
     hipError_t e;
-#define FRONT_ATTR(L, NP)                                                                         \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP, false>),   \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
-    if (e != hipSuccess) return e;                                                              \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP, true>),    \
+#define FRONT_ATTR1(L, NP, Z, LN)                                                                 \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP, Z, LN>),   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
     if (e != hipSuccess) return e;
+#define FRONT_ATTR(L, NP) FRONT_ATTR1(L, NP, false, false) FRONT_ATTR1(L, NP, false, true) FRONT_ATTR1(L, NP, true, false) FRONT_ATTR1(L, NP, true, true)
     FRONT_ATTR(4, 1) FRONT_ATTR(8, 1) FRONT_ATTR(8, 2) FRONT_ATTR(8, 4) FRONT_ATTR(8, 8)
 #undef FRONT_ATTR
+#undef FRONT_ATTR1
     return hipSuccess;
 }

@@ -89,6 +89,10 @@ struct gsttaco_ctx {
     float* w_part[2] = {nullptr, nullptr};
     bool split_rec = true;
     int keep_x_weights = 1;
+    int co_tiles = 64;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
+    int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
+    int co_worker_tiles = 1;     // the same for the projection launch's workers
+    bool lean = true;            // lean_body.h kernels for the decode shapes they cover (GSTTACO_LEAN=0: general kernels only)
 
     float *pw0 = nullptr, *pb0 = nullptr, *pw1 = nullptr, *pb1 = nullptr, *pwq = nullptr, *pbq = nullptr;  // plain layouts (fused front)
     bool fused_front = true;
@@ -350,8 +354,7 @@ hipError_t launch_skinny(gsttaco_ctx* c, int epi, SkinnyArgs a0, const SkinnyArg
 }
 
 hipError_t launch_skinny_co(gsttaco_ctx* c, SkinnyArgs m, int ntiles, SkinnyArgs co, int co_begin, int co_end, hipStream_t s) {
-    (void)c;
-    return gt_launch_skinny_co(m, ntiles, co, co_begin, co_end, s);
+    return gt_launch_skinny_co(m, ntiles, co, co_begin, co_end, c->co_worker_tiles, s);
 }
 
 // Fold inference BatchNorm into y = x*scale + shift (Appendix A.4).
@@ -625,8 +628,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         return rce;
     };
     // layer-2 recurrent tiles co-scheduled with the (11-workgroup) projection kernel: one tile per otherwise idle CU
-    int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, 192));      // measured: 192 <= 245 <= 128 (flat optimum)
-    if (const char* ec = getenv("GSTTACO_CO_TILES")) co_tiles = std::max(0, std::min(co_tiles, atoi(ec)));
+    const int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, c->co_tiles));
     for (int t = 0; t < steps; ++t) {
         const int p = t & 1;
         SkinnyArgs k;
@@ -668,6 +670,10 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                     f.rec_begin[layer] = 0; f.rec_end[layer] = L.ntiles;
                 }
                 f.n_workers = B < 192 ? 256 - B : 64;
+                f.worker_tiles = c->worker_tiles;
+                f.lean_rec = c->lean && !f.rec[0].bf16 && !f.rec[1].bf16 && f.rec[0].nkb == 64 && f.rec[1].nkb == 64;
+                for (int layer = 0; layer < 2; ++layer)
+                    f.lrec[layer] = LeanPartialArgs{f.rec[layer].wp, f.rec[layer].bias, f.rec[layer].seg[0].ptr, f.rec[layer].partial_out, MT};
                 // from step 1 on, the projection kernel of the previous step already did layer-2 tiles [0, co_tiles)
                 if (t > 0 && c->proj.nkb >= 32) f.rec_begin[1] = co_tiles;
             }
@@ -744,6 +750,10 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             k.M = B; k.MT = MT;
             k.dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
             if (prof) { int rce = prof_begin(layer); if (rce) return rce; }
+            if (split && c->lean && !k.bf16 && c->keep_x_weights && gt_lstm_x_supported(k.nkb)) {
+                LstmXArgs la{k.wp, k.seg[0].ptr, k.partial_in, k.c, k.h, nullptr, k.dbg, B, MT, H, 0};
+                HIPCHECK(c, gt_launch_lstm_x(la, k.nkb, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2, s));
+            } else
             HIPCHECK(c, launch_skinny(c, EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));
             if (prof) { int rce = prof_end(layer); if (rce) return rce; }
         }
@@ -770,6 +780,12 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             rk.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
             rk.M = B; rk.N = H2; rk.MT = MT;
             rk.partial_out = c->w_part[1];
+            if (c->lean && !k.bf16 && !rk.bf16 && gt_proj_lean_supported(k.nkb, rk.nkb) && k.seg[0].nkb + k.seg[1].nkb == k.nkb) {
+                ProjArgs pa{k.wp, k.bias, k.seg[0].ptr, k.seg[1].ptr, k.seg[0].nkb, B, MT, k.N, k.n_split, k.n_valid2, k.col3,
+                            k.out, k.ldo, k.out2, k.ldo2, k.out3, k.ldo3};
+                HIPCHECK(c, gt_launch_proj_lean(pa, PJ.ntiles, rk.wp, rk.bias, rk.seg[0].ptr, rk.partial_out, 0, co_tiles,
+                                                c->co_worker_tiles, s));
+            } else
             HIPCHECK(c, launch_skinny_co(c, k, PJ.ntiles, rk, 0, co_tiles, s));
         } else {
             HIPCHECK(c, launch_skinny(c, EPI_LINEAR, k, nullptr, PJ.ntiles, s));
@@ -1120,6 +1136,10 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->fuse_prenet0 = !(ez && ez[0] == '0');
     const char* ek = getenv("GSTTACO_KEEP_X");
     if (ek) c->keep_x_weights = atoi(ek);
+    if (const char* e = getenv("GSTTACO_CO_TILES")) c->co_tiles = std::max(0, atoi(e));
+    if (const char* e = getenv("GSTTACO_WORKER_TILES")) c->worker_tiles = atoi(e);
+    if (const char* e = getenv("GSTTACO_CO_WORKER_TILES")) c->co_worker_tiles = atoi(e);
+    if (const char* e = getenv("GSTTACO_LEAN")) c->lean = e[0] != '0';
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);
@@ -1734,7 +1754,7 @@ int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int which, int B) {
     const bool fused = c->fused_front && c->split_rec;
     auto gemm = [&](int64_t K, int64_t N, int64_t extra_row_floats) { return 4 * (K * N + N) + 4 * (int64_t)B * (K + extra_row_floats); };
     const int64_t ntile2 = (H2 + 3) / 4;
-    int64_t co_tiles = std::max<int64_t>(0, std::min<int64_t>(ntile2, 192));       // same rule as enqueue_decode
+    int64_t co_tiles = std::max<int64_t>(0, std::min<int64_t>(ntile2, c->co_tiles));       // same rule as enqueue_decode
     if (c->proj.nkb < 32) co_tiles = 0;
     switch (which) {
         case 0:     // LSTM layer 1: x-half only when the recurrent half runs in the front launch

@@ -55,13 +55,53 @@ struct SkinnyArgs {
     unsigned long long* dbg;   // diagnostic phase stamps (s_memrealtime, 100 MHz) of block 0, or NULL
 };
 
+// Recurrent-half worker job (lean_body.h gt_lean_partial): tiles of  h . W_h + b  as pre-activation partial sums.
+struct LeanPartialArgs {
+    const float* wp;            // packed weights [tiles][NKB][64][4]
+    const float* bias;          // [tiles*16]
+    const float* x;             // blocked state [NKB][MT][64][4]
+    float* partial_out;         // [tile][MT*16 rows][16 cols]
+    int MT;
+};
+
 enum { TAG_GENERIC = 0, TAG_DEC_LSTM1 = 1, TAG_DEC_LSTM2 = 2, TAG_ENC_BILSTM = 3 };
 hipError_t gt_launch_skinny(int epi, const SkinnyArgs& a0, const SkinnyArgs* a1, int ntiles, hipStream_t stream,
                             int tag = TAG_GENERIC);
 // EPI_LINEAR main GEMM (tiles [0, ntiles)) plus co-scheduled worker workgroups in the same launch that compute tiles
 // [co_begin, co_end) of an independent EPI_PARTIAL GEMM `co` on CUs the small main grid leaves idle.
 hipError_t gt_launch_skinny_co(const SkinnyArgs& main_args, int ntiles, const SkinnyArgs& co, int co_begin, int co_end,
-                               hipStream_t stream);
+                               int tiles_per_worker, hipStream_t stream);
+
+// ---- lean decode-step kernels (lean_body.h): fp32, blocked operands, compile-time K; the host falls back to the
+// general kernels above for any other shape or precision.
+// Input half of a decode LSTM cell: z = x . W_x + partial_in (recurrent half + bias, from the workers), gates, cell update.
+struct LstmXArgs {
+    const float* wp;            // packed W_x [H/4 tiles][nkb][64][4]
+    const float* x;             // blocked input [nkb][MT][64][4]
+    const float* partial_in;    // [tiles][MT*16][16]
+    float* c;                   // [M, H] cell state, in place
+    float* h;                   // blocked output state
+    const int32_t* row_len;     // masked-mode extension (A12) or NULL
+    unsigned long long* dbg;
+    int M, MT, H, t_index;
+};
+bool gt_lstm_x_supported(int nkb);
+hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, hipStream_t stream);
+
+// Projection [h2 | ctx] -> mel frames | stop logit | (optional) next step's prenet-0 pre-activations, with co-scheduled
+// recurrent-half worker tiles of LSTM layer 2 for the next step in the same launch.
+struct ProjArgs {
+    const float* wp; const float* bias;
+    const float* xa; const float* xb; int nkb_a;    // blocked segments: k-blocks [0, nkb_a) from xa, the rest from xb
+    int M, MT, N;                                   // N: valid columns
+    int n_split, n_valid2, col3;                    // [0,n_split) -> out, [n_split,n_valid2) -> out2, [col3,N) -> out3 (NULL: none)
+    float* out; int64_t ldo;
+    float* out2; int64_t ldo2;
+    float* out3; int64_t ldo3;
+};
+bool gt_proj_lean_supported(int nkb_main, int nkb_co);
+hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp, const float* co_bias, const float* co_x,
+                               float* co_out, int co_begin, int co_end, int tiles_per_worker, hipStream_t stream);
 
 // ---------------------------------------------------------------- gemm_conv.hip
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
@@ -151,6 +191,9 @@ struct DecFrontArgs {
     SkinnyArgs rec[2];
     int rec_begin[2], rec_end[2];   // tile ranges [begin, end) of each layer handled by this launch's workers
     int n_workers;
+    int worker_tiles;               // tiles per worker job: 1, or 0/2 = pairs sharing one pass over the activations
+    LeanPartialArgs lrec[2];        // the same two GEMMs for the lean body (fp32, K = 1024); used when lean_rec != 0
+    int lean_rec;
 };
 bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv);
 hipError_t gt_dec_front_init();

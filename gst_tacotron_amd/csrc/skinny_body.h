@@ -21,6 +21,7 @@ __device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int ti
     float (*part)[32][17] = reinterpret_cast<float (*)[32][17]>(lds);
     float (*zs)[17] = reinterpret_cast<float (*)[17]>(lds + SkinnyLds<NW>::kPart);
 
+    GT_STAMP(A.dbg, 4);
     const int m0 = mchunk * 32;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -148,6 +149,7 @@ __device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int ti
                     x1[i] = *reinterpret_cast<const float4*>(p1 + (size_t)lk * st);
                 }
             }
+            GT_STAMP(A.dbg, 5);
 #pragma unroll
             for (int i = 0; i < MAXI; ++i) {
                 const int kb = base + i * NW;
@@ -246,4 +248,167 @@ __device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int ti
         }
     }
     GT_STAMP(A.dbg, 3);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Worker variant: EPI_PARTIAL only, NT adjacent tiles (16 columns each) per workgroup sharing ONE pass over the
+// activations.  A worker with a single tile pulls 64 KB of weights and 128 KB of (L2-served) batch activations per
+// K = 1024; two tiles per pass pull 128 + 128 KB, so twice the tiles cost 1.33x the bytes of one and the launch needs one
+// round of workers instead of two.  The operand is seg[0], blocked (the decode loop's h1 / h2).  The per-wave k-block
+// assignment and the summation order over waves equal gt_skinny_body's, so the partial sums are bitwise the same.
+template <int NW, int NT>
+struct SkinnyMultiLds {
+    static constexpr int kFloats = NT * NW * 32 * 17;
+};
+
+template <int NW, int NT, bool NT_WEIGHTS>
+__device__ __forceinline__ void gt_skinny_partial_multi(const SkinnyArgs& A, const int tile0, const int ntile, const int mchunk,
+                                                        float* lds) {
+    constexpr int MAXI = NW == 16 ? 4 : 8;
+    float (*part)[NW][32][17] = reinterpret_cast<float (*)[NW][32][17]>(lds);
+    const int m0 = mchunk * 32;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int MT = A.MT;
+    const int mt0 = mchunk * 2, mt1 = min(mt0 + 1, MT - 1);
+    const int nkb = A.nkb;
+    const float* sp0 = A.seg[0].ptr + (size_t)mt0 * 256 + lane * 4;
+    const float* sp1 = A.seg[0].ptr + (size_t)mt1 * 256 + lane * 4;
+    const size_t sstep = (size_t)MT * 256;
+
+    // epilogue mapping: thread e -> (tile j, row, col); bias requested before the K loop
+    constexpr int NE = (NT * 512 + NW * 64 - 1) / (NW * 64);
+    float bias_v[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + i * NW * 64;
+        const int j = e >> 9;
+        bias_v[i] = (e < NT * 512 && j < ntile) ? A.bias[(tile0 + j) * 16 + (e & 15)] : 0.f;
+    }
+
+    f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    if (A.bf16) {
+        constexpr int MAXB = MAXI / 2;
+        const int nkb32 = (nkb + 1) >> 1;
+        const uint4* wq = reinterpret_cast<const uint4*>(A.wp) + (size_t)tile0 * nkb32 * 64 + lane;
+        for (int base = wave; base < nkb32; base += NW * MAXB) {
+            uint4 b[MAXB][NT];
+            float4 x0[MAXB][2], x1[MAXB][2];
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int kb32 = base + i * NW;             // wave-uniform
+                if (kb32 < nkb32) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        b[i][j] = make_uint4(0u, 0u, 0u, 0u);
+                        if (j < ntile) {
+                            const uint4* src = wq + ((size_t)j * nkb32 + kb32) * 64;
+                            if (NT_WEIGHTS) {
+                                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+                                b[i][j] = make_uint4(t[0], t[1], t[2], t[3]);
+                            } else {
+                                b[i][j] = *src;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int kb = 2 * kb32 + hf;
+                        x0[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        x1[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (kb < nkb) {
+                            x0[i][hf] = *reinterpret_cast<const float4*>(sp0 + (size_t)kb * sstep);
+                            x1[i][hf] = *reinterpret_cast<const float4*>(sp1 + (size_t)kb * sstep);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) {
+                const int kb32 = base + i * NW;
+                if (kb32 < nkb32) {
+                    bf16x8 a0, a1;
+                    a0[0] = (__bf16)x0[i][0].x; a0[1] = (__bf16)x0[i][0].y; a0[2] = (__bf16)x0[i][0].z; a0[3] = (__bf16)x0[i][0].w;
+                    a0[4] = (__bf16)x0[i][1].x; a0[5] = (__bf16)x0[i][1].y; a0[6] = (__bf16)x0[i][1].z; a0[7] = (__bf16)x0[i][1].w;
+                    a1[0] = (__bf16)x1[i][0].x; a1[1] = (__bf16)x1[i][0].y; a1[2] = (__bf16)x1[i][0].z; a1[3] = (__bf16)x1[i][0].w;
+                    a1[4] = (__bf16)x1[i][1].x; a1[5] = (__bf16)x1[i][1].y; a1[6] = (__bf16)x1[i][1].z; a1[7] = (__bf16)x1[i][1].w;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        bf16x8 bw;
+                        __builtin_memcpy(&bw, &b[i][j], 16);
+                        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw, acc0[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw, acc1[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
+        const float4* wp = reinterpret_cast<const float4*>(A.wp) + (size_t)tile0 * nkb * 64 + lane;
+        for (int base = wave; base < nkb; base += NW * MAXI) {
+            float4 b[MAXI][NT], x0[MAXI], x1[MAXI];
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int kb = base + i * NW;               // wave-uniform
+                if (kb < nkb) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        b[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (j < ntile) {
+                            const float4* src = wp + ((size_t)j * nkb + kb) * 64;
+                            if (NT_WEIGHTS) {
+                                const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+                                b[i][j] = make_float4(t[0], t[1], t[2], t[3]);
+                            } else {
+                                b[i][j] = *src;
+                            }
+                        }
+                    }
+                    x0[i] = *reinterpret_cast<const float4*>(sp0 + (size_t)kb * sstep);
+                    x1[i] = *reinterpret_cast<const float4*>(sp1 + (size_t)kb * sstep);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXI; ++i) {
+                const int kb = base + i * NW;
+                if (kb < nkb) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, b[i][j].x, acc0[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, b[i][j].x, acc1[j], 0, 0, 0);
+                        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, b[i][j].y, acc0[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, b[i][j].y, acc1[j], 0, 0, 0);
+                        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, b[i][j].z, acc0[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, b[i][j].z, acc1[j], 0, 0, 0);
+                        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, b[i][j].w, acc0[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, b[i][j].w, acc1[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            part[j][wave][q * 4 + v][r] = acc0[j][v];
+            part[j][wave][16 + q * 4 + v][r] = acc1[j][v];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + i * NW * 64;
+        const int j = e >> 9, row = (e >> 4) & 31, col = e & 15;
+        if (e < NT * 512 && j < ntile && m0 + row < MT * 16) {
+            float z = bias_v[i];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) z += part[j][w][row][col];
+            A.partial_out[((size_t)(tile0 + j) * MT * 16 + m0 + row) * 16 + col] = z;
+        }
+    }
 }

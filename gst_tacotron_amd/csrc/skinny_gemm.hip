@@ -19,6 +19,7 @@
 // are 4 consecutive k of one batch row = one 16-byte load.  fp32 in / fp32 accumulate (exact fp32 FMA
 // chain), since the parity bar is 1e-3 through a 1000-frame recurrence.
 #include "skinny_body.h"
+#include "lean_body.h"
 
 // TAG only separates kernel symbols per call site (decode LSTM layer 1 / 2, encoder BiLSTM) so that
 // rocprofv3 --stats reports them on separate lines.
@@ -31,10 +32,12 @@ __global__ __launch_bounds__(NW * 64) void gt_skinny_kernel(SkinnyArgs a0, Skinn
     gt_skinny_body<EPI, NW, NT>(A, blockIdx.x, blockIdx.y, lds);
 }
 
-// Projection (EPI_LINEAR, 11 workgroups at 161 columns) co-scheduled with recurrent-half partial GEMM tiles.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void gt_skinny_co_kernel(SkinnyArgs main_args, SkinnyArgs co, int n_main, int co_begin) {
-    __shared__ __attribute__((aligned(16))) float lds[SkinnyLds<NW>::kFloats];
+// Projection (EPI_LINEAR, 11 workgroups at 161 columns) co-scheduled with recurrent-half partial GEMM tiles, CT tiles
+// per worker workgroup (CT = 2: one pass over the activations for both, gt_skinny_partial_multi).
+template <int NW, int CT>
+__global__ __launch_bounds__(NW * 64) void gt_skinny_co_kernel(SkinnyArgs main_args, SkinnyArgs co, int n_main, int co_begin, int co_end) {
+    constexpr int kLds = SkinnyLds<NW>::kFloats > SkinnyMultiLds<NW, CT>::kFloats ? SkinnyLds<NW>::kFloats : SkinnyMultiLds<NW, CT>::kFloats;
+    __shared__ __attribute__((aligned(16))) float lds[kLds];
     const int mchunks = (main_args.M + 31) / 32;
     if ((int)blockIdx.x < n_main) {
         for (int mc = 0; mc < mchunks; ++mc) {
@@ -42,18 +45,22 @@ __global__ __launch_bounds__(NW * 64) void gt_skinny_co_kernel(SkinnyArgs main_a
             __syncthreads();
         }
     } else {
-        const int tile = co_begin + (int)blockIdx.x - n_main;
+        const int tile = co_begin + ((int)blockIdx.x - n_main) * CT;
         for (int mc = 0; mc < mchunks; ++mc) {
-            gt_skinny_body<EPI_PARTIAL, NW, true>(co, tile, mc, lds);
+            if (CT == 1) gt_skinny_body<EPI_PARTIAL, NW, true>(co, tile, mc, lds);
+            else gt_skinny_partial_multi<NW, CT, true>(co, tile, min(CT, co_end - tile), mc, lds);
             __syncthreads();
         }
     }
 }
 
 hipError_t gt_launch_skinny_co(const SkinnyArgs& main_args, int ntiles, const SkinnyArgs& co, int co_begin, int co_end,
-                               hipStream_t stream) {
+                               int tiles_per_worker, hipStream_t stream) {
     const int nco = co_end > co_begin ? co_end - co_begin : 0;
-    hipLaunchKernelGGL((gt_skinny_co_kernel<8>), dim3(ntiles + nco), dim3(512), 0, stream, main_args, co, ntiles, co_begin);
+    if (tiles_per_worker == 2)
+        hipLaunchKernelGGL((gt_skinny_co_kernel<8, 2>), dim3(ntiles + (nco + 1) / 2), dim3(512), 0, stream, main_args, co, ntiles, co_begin, co_end);
+    else
+        hipLaunchKernelGGL((gt_skinny_co_kernel<8, 1>), dim3(ntiles + nco), dim3(512), 0, stream, main_args, co, ntiles, co_begin, co_end);
     return hipGetLastError();
 }
 
@@ -82,4 +89,125 @@ hipError_t gt_launch_skinny(int epi, const SkinnyArgs& a0, const SkinnyArgs* a1,
             }
     }
     return hipErrorInvalidValue;
+}
+
+// ======================================================================================================================
+// Lean decode-step kernels (see lean_body.h for why they exist)
+// ======================================================================================================================
+
+// z[32 rows x 16 gate columns] of tile `blockIdx.x` = x . W_x + partial_in; tile-local column g*4+u is gate g (i,f,c~,o)
+// of hidden unit tile*4+u (Appendix A.6; reference Taco2.py:79-85 via StackedRNNCells).  The 16 columns of a row sit in
+// 16 adjacent lanes, so the lanes with column < 4 collect their unit's four gates with three lane shifts -- no second LDS
+// round trip or barrier.
+template <int NW, int KPW, int TAG>
+__global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
+    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 1>::kFloats];
+    constexpr int NE = 512 / (NW * 64);
+    const int tile = blockIdx.x, mchunk = blockIdx.y;
+    const int m0 = mchunk * 32, MT = A.MT;
+    GT_STAMP(A.dbg, 4);
+    float pin[NE], c_prev[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + i * NW * 64;
+        const int row = e >> 4, col = e & 15;
+        const int grow = m0 + row, unit = tile * 4 + col;
+        pin[i] = (grow < MT * 16) ? A.partial_in[((size_t)tile * MT * 16 + grow) * 16 + col] : 0.f;
+        c_prev[i] = (col < 4 && grow < A.M && unit < A.H) ? A.c[(size_t)grow * A.H + unit] : 0.f;
+    }
+    GT_STAMP(A.dbg, 0);
+    f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    gt_lean_core<NW, KPW, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, NW * KPW}, MT, mchunk, acc0, acc1);
+    GT_STAMP(A.dbg, 1);
+    gt_lean_spill<NW, 1>(lds, acc0, acc1);
+    __syncthreads();
+    GT_STAMP(A.dbg, 2);
+    const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + i * NW * 64;
+        const int row = e >> 4, col = e & 15;
+        float z = pin[i];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) z += part[w][row][col];
+        const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+        const int grow = m0 + row, unit = tile * 4 + col;
+        if (col < 4 && grow < A.M && unit < A.H) {
+            if (A.row_len && A.t_index >= A.row_len[grow]) {
+                A.h[gt_blk_off(grow, unit, MT)] = 0.f;          // masked mode: this step does not exist for this utterance
+            } else {
+                const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
+                const float c2 = gf * c_prev[i] + gi * gg;
+                A.c[(size_t)grow * A.H + unit] = c2;
+                A.h[gt_blk_off(grow, unit, MT)] = go * gt_tanh(c2);
+            }
+        }
+    }
+    GT_STAMP(A.dbg, 3);
+}
+
+bool gt_lstm_x_supported(int nkb) { return nkb == 24 || nkb == 64; }
+
+hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, hipStream_t stream) {
+    const dim3 grid((a.H + 3) / 4, (a.M + 31) / 32);
+    if (nkb == 24) {
+        if (tag == TAG_DEC_LSTM1) hipLaunchKernelGGL((gt_lstm_x_kernel<4, 6, TAG_DEC_LSTM1>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((gt_lstm_x_kernel<4, 6, TAG_DEC_LSTM2>), grid, dim3(256), 0, stream, a);
+    } else if (nkb == 64) {
+        if (tag == TAG_DEC_LSTM1) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG_DEC_LSTM1>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG_DEC_LSTM2>), grid, dim3(512), 0, stream, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// Projection (K = 1152 = 8 waves x 9 k-blocks) + co-scheduled layer-2 recurrent tiles (K = 1024 = 8 x 8), CT per worker.
+template <int CT>
+__global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanPartialArgs co, int n_main, int co_begin, int co_end) {
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, CT>::kFloats];
+    const int mchunks = (P.M + 31) / 32;
+    if ((int)blockIdx.x >= n_main) {
+        const int tile = co_begin + ((int)blockIdx.x - n_main) * CT;
+        for (int mc = 0; mc < mchunks; ++mc) {
+            gt_lean_partial<NW, 8, CT>(co, tile, min(CT, co_end - tile), mc, lds);
+            if (mc + 1 < mchunks) __syncthreads();
+        }
+        return;
+    }
+    const int tile = blockIdx.x;
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const int gcol = tile * 16 + col;
+    const float bias = P.bias[gcol];
+    for (int mc = 0; mc < mchunks; ++mc) {
+        f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+        gt_lean_core<NW, 9, 1, false>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mc, acc0, acc1);
+        gt_lean_spill<NW, 1>(lds, acc0, acc1);
+        __syncthreads();
+        const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
+        float v = bias;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += part[w][row][col];
+        const int grow = mc * 32 + row;
+        if (grow < P.M && gcol < P.N) {
+            if (P.out3 && gcol >= P.col3) P.out3[(size_t)grow * P.ldo3 + (gcol - P.col3)] = v;
+            else if (gcol < P.n_split) P.out[(size_t)grow * P.ldo + gcol] = v;
+            else if (!P.out3 || gcol < P.n_valid2) P.out2[(size_t)grow * P.ldo2 + (gcol - P.n_split)] = v;
+        }
+        if (mc + 1 < mchunks) __syncthreads();
+    }
+}
+
+bool gt_proj_lean_supported(int nkb_main, int nkb_co) { return nkb_main == 72 && (nkb_co == 64 || nkb_co == 0); }
+
+hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp, const float* co_bias, const float* co_x,
+                               float* co_out, int co_begin, int co_end, int tiles_per_worker, hipStream_t stream) {
+    const int nco = co_end > co_begin ? co_end - co_begin : 0;
+    LeanPartialArgs co{co_wp, co_bias, co_x, co_out, m.MT};
+    if (tiles_per_worker == 2)
+        hipLaunchKernelGGL((gt_proj_lean_kernel<2>), dim3(ntiles + (nco + 1) / 2), dim3(512), 0, stream, m, co, ntiles, co_begin, co_end);
+    else
+        hipLaunchKernelGGL((gt_proj_lean_kernel<1>), dim3(ntiles + nco), dim3(512), 0, stream, m, co, ntiles, co_begin, co_end);
+    return hipGetLastError();
 }

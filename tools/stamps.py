@@ -16,9 +16,12 @@ buf = (ctypes.c_uint64 * 48)()
 m.ctx.check(m.ctx.lib.gsttaco_debug_stamps(m.ctx.handle, buf))
 names = {0: "front", 1: "lstm1", 2: "lstm2"}
 for k in range(3):
-    st = [buf[k * 16 + i] for i in range(8)]
+    st = [buf[k * 16 + i] for i in range(4 if k else 8)]
     st = [x for x in st if x]
     print(names[k], "phase deltas (us):", [round((b - a) / 100.0, 2) for a, b in zip(st[:-1], st[1:])], "total", round((st[-1] - st[0]) / 100.0, 2))
+for k in (1, 2):
+    b0 = buf[k * 16]
+    print(names[k], "entry -> stamp0 (us):", (b0 - buf[k * 16 + 4]) / 100.0, " stamp0 -> loads issued:", (buf[k * 16 + 5] - b0) / 100.0)
 f = [buf[i] for i in range(16)]
 t0 = f[0]
 print("front raw (us since stamp0):", {i: round((f[i]-t0)/100.0, 2) for i in range(16) if f[i]})
