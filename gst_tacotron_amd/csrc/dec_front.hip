@@ -20,6 +20,7 @@
 #include "skinny_body.h"
 #include "lean_body.h"
 #include "../../include/gsttaco.h"
+#include <stdlib.h>
 
 #define FT 1024            // threads per workgroup
 #define WT 2               // recurrent-half tiles per worker job
@@ -40,9 +41,19 @@ __device__ __forceinline__ GemvPlan make_plan(int K, int N, int tid) {
     return p;
 }
 
-// loads rows [i0, i0+MAXR) of this lane's k range
-template <int MAXR>
+// loads rows [i0, i0+MAXR) of this lane's k range.  EXACT: the plan divides evenly (every lane has exactly i0+MAXR or more
+// rows, all inside K) -- true for the prenet-1 and query layers at the reference's dimensions -- so the loads carry no
+// predicates: with them each load costs ~30 instructions of exec-mask bookkeeping, ~1 us over the prologue's 24 loads.
+template <int MAXR, bool EXACT = false>
 __device__ __forceinline__ void gemv_load(const float* __restrict__ W, int K, int N, const GemvPlan& p, int i0, float4 (&r)[MAXR]) {
+    if (EXACT) {
+        // uniform (SGPR) base per row + ONE per-lane 32-bit byte offset: no per-load address registers
+        const uint32_t off = (uint32_t)(((p.kp * p.rows + i0) * N + p.cg * 4) * 4);
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i)
+            r[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(W) + (size_t)i * N * 4 + off);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const int k = p.kp * p.rows + i0 + i;
@@ -52,12 +63,12 @@ __device__ __forceinline__ void gemv_load(const float* __restrict__ W, int K, in
     }
 }
 
-template <int MAXR>
+template <int MAXR, bool EXACT = false>
 __device__ __forceinline__ void gemv_acc(const float* xs, int K, const GemvPlan& p, int i0, const float4 (&r)[MAXR], float4& acc) {
 #pragma unroll
     for (int i = 0; i < MAXR; ++i) {
         const int k = p.kp * p.rows + i0 + i;
-        if (i0 + i < p.rows && p.kp < p.kparts && k < K) {
+        if (EXACT || (i0 + i < p.rows && p.kp < p.kparts && k < K)) {
             const float x = xs[k];
             acc.x += x * r[i].x; acc.y += x * r[i].y; acc.z += x * r[i].z; acc.w += x * r[i].w;
         }
@@ -96,7 +107,7 @@ __device__ __forceinline__ float front_wave_incl_scan(float x, int lane) {
 // Z0: the projection launch of the previous step already produced this step's prenet-0 pre-activations (the projection and
 // the first prenet Dense are both linear: frame.W0 + b0 = [h2|ctx].(Wp_last.W0) + (bp_last.W0 + b0), DecFrontArgs::z0), so the
 // chain starts at prenet 1 and the query weights are requested at kernel start in place of prenet 0's.
-template <int L, int NP, bool Z0, bool LEAN>
+template <int L, int NP, bool Z0, bool LEAN, bool EXACT>
 __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     constexpr int A = 4 * L * NP;
     constexpr int ROWS = FT / L;            // memory rows per pass (one LDS tile)
@@ -168,22 +179,25 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) *reinterpret_cast<float4*>(tile + row * LD + 4 * (li + L * j)) = v[j];
     };
-    // small operands first: loads return in issue order, so their LDS writes below wait only for themselves
-    float in_x = 0.f, in_v = 0.f, in_p = 0.f;
-    if (!Z0 && tid < mel) in_x = P.frame[(size_t)b * P.ldframe + tid];             // mel <= FT (checked on the host)
-    if (Z0 && tid < P0) in_x = P.z0[(size_t)b * P0 + tid];
-    if (tid < A) in_v = P.v[tid];
-    if (tid < Tv) in_p = P.prev ? P.prev[(size_t)b * P.ldprev + tid] : (tid == 0 ? 1.f : 0.f);
-    const uint64_t seed = *P.seed_ptr;
+    // small operands first: loads return in issue order, so their LDS writes below wait only for themselves.  They are
+    // BRANCH-FREE (clamped index + select): inside an exec-masked block the compiler sinks the first use (the ReLU of the
+    // z0 row) next to the load and waits for it there -- a full memory latency before any other load is even requested.
+    // The Philox seed is read only by the branches that draw random numbers, for the same reason.
+    const float x_raw = Z0 ? P.z0[(size_t)b * P0 + min(tid, P0 - 1)] : P.frame[(size_t)b * P.ldframe + min(tid, mel - 1)];
+    const float in_x = tid < (Z0 ? P0 : mel) ? x_raw : 0.f;                         // mel <= FT (checked on the host)
+    const float v_raw = P.v[min(tid, A - 1)];
+    const float in_v = tid < A ? v_raw : 0.f;
+    float in_p = tid == 0 ? 1.f : 0.f;
+    if (P.prev) in_p = P.prev[(size_t)b * P.ldprev + min(tid, Tv - 1)];
     const float sbias = P.score_bias[0];
     // small vectors staged into LDS (see the carve): requested before the big loads, written after they are issued
-    float t_b0 = 0.f, t_b1 = 0.f, t_bq = 0.f, t_k0 = 1.f, t_k1 = 1.f, t_nz = 0.f;
-    if (!Z0 && tid < P0) t_b0 = P.b0[tid];
-    if (tid < P1) t_b1 = P.b1[tid];
-    if (tid < A) t_bq = P.bq[tid];
-    if (P.drop_rate > 0.f && P.mask0 && tid < P0) t_k0 = P.mask0[(size_t)b * P0 + tid];
-    if (P.drop_rate > 0.f && P.mask1 && tid < P1) t_k1 = P.mask1[(size_t)b * P1 + tid];
-    if (P.sigmoid_noise > 0.f && P.noise && tid < Tv) t_nz = P.noise[(size_t)b * P.ldnoise + tid];
+    float t_b0 = 0.f, t_k0 = 1.f, t_k1 = 1.f, t_nz = 0.f;
+    if (!Z0) t_b0 = P.b0[min(tid, P0 - 1)];
+    const float t_b1 = P.b1[min(tid, P1 - 1)];
+    const float t_bq = P.bq[min(tid, A - 1)];
+    if (P.drop_rate > 0.f && P.mask0) t_k0 = P.mask0[(size_t)b * P0 + min(tid, P0 - 1)];
+    if (P.drop_rate > 0.f && P.mask1) t_k1 = P.mask1[(size_t)b * P1 + min(tid, P1 - 1)];
+    if (P.sigmoid_noise > 0.f && P.noise) t_nz = P.noise[(size_t)b * P.ldnoise + min(tid, Tv - 1)];
     float4 v0[NP];
     load_rows(v0, 0);                                   // processed-memory rows of chunk 0 (64 KiB at 128x128)
 
@@ -192,18 +206,18 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     const GemvPlan g2 = make_plan(P1, A, tid);
     // register budget (128 VGPRs at 16 waves/CU): three 8-row weight blocks + the memory rows in flight at t=0
     float4 r0a[8], r1a[8];
-    if (Z0) gemv_load<8>(P.wq, P1, A, g2, 0, r0a);      // (r0a holds the query weights in this variant)
+    if (Z0) gemv_load<8, EXACT>(P.wq, P1, A, g2, 0, r0a);      // (r0a holds the query weights in this variant)
     else gemv_load<8>(P.w0, mel, P0, g0, 0, r0a);
-    gemv_load<8>(P.w1, P0, P1, g1, 0, r1a);
+    gemv_load<8, EXACT>(P.w1, P0, P1, g1, 0, r1a);
 
     // dropout keep-scales and sigmoid noise (Philox, ~100 VALU ops each) while the first loads are in flight
     if (P.drop_rate > 0.f) {
-        if (!P.mask0 && tid < P0) t_k0 = (gt_u01(gt_philox(seed, (uint32_t)(b * P0 + tid), P.rng_step, 0u, 0x1000u).x) > P.drop_rate) ? 1.f : 0.f;
-        if (!P.mask1 && tid < P1) t_k1 = (gt_u01(gt_philox(seed, (uint32_t)(b * P1 + tid), P.rng_step, 0u, 0x1001u).x) > P.drop_rate) ? 1.f : 0.f;
+        if (!P.mask0 && tid < P0) t_k0 = (gt_u01(gt_philox(*P.seed_ptr, (uint32_t)(b * P0 + tid), P.rng_step, 0u, 0x1000u).x) > P.drop_rate) ? 1.f : 0.f;
+        if (!P.mask1 && tid < P1) t_k1 = (gt_u01(gt_philox(*P.seed_ptr, (uint32_t)(b * P1 + tid), P.rng_step, 0u, 0x1001u).x) > P.drop_rate) ? 1.f : 0.f;
         t_k0 *= P.drop_scale; t_k1 *= P.drop_scale;
     }
     if (P.sigmoid_noise > 0.f && !P.noise && tid < Tv) {
-        const Philox4 r = gt_philox(seed, (uint32_t)(b * TvFull + tid), P.rng_step, 0u, GT_RNG_NOISE);
+        const Philox4 r = gt_philox(*P.seed_ptr, (uint32_t)(b * TvFull + tid), P.rng_step, 0u, GT_RNG_NOISE);
         t_nz = gt_normal(r.x, r.y);
     }
     if (tid < P0) sk0[tid] = t_k0;
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         float keep = 1.f;
         if (P.drop_rate > 0.f) {
             keep = P.mask0 ? P.mask0[(size_t)b * P0 + c]
-                           : ((gt_u01(gt_philox(seed, (uint32_t)(b * P0 + c), P.rng_step, 0u, 0x1000u).x) > P.drop_rate) ? 1.f : 0.f);
+                           : ((gt_u01(gt_philox(*P.seed_ptr, (uint32_t)(b * P0 + c), P.rng_step, 0u, 0x1000u).x) > P.drop_rate) ? 1.f : 0.f);
             keep *= P.drop_scale;
         }
         sk0[c] = keep;
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         float keep = 1.f;
         if (P.drop_rate > 0.f) {
             keep = P.mask1 ? P.mask1[(size_t)b * P1 + c]
-                           : ((gt_u01(gt_philox(seed, (uint32_t)(b * P1 + c), P.rng_step, 0u, 0x1001u).x) > P.drop_rate) ? 1.f : 0.f);
+                           : ((gt_u01(gt_philox(*P.seed_ptr, (uint32_t)(b * P1 + c), P.rng_step, 0u, 0x1001u).x) > P.drop_rate) ? 1.f : 0.f);
             keep *= P.drop_scale;
         }
         sk1[c] = keep;
@@ -236,7 +250,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         if (P.sigmoid_noise > 0.f) {
             if (P.noise) nz = P.noise[(size_t)b * P.ldnoise + t];
             else {
-                const Philox4 r = gt_philox(seed, (uint32_t)(b * TvFull + t), P.rng_step, 0u, GT_RNG_NOISE);
+                const Philox4 r = gt_philox(*P.seed_ptr, (uint32_t)(b * TvFull + t), P.rng_step, 0u, GT_RNG_NOISE);
                 nz = gt_normal(r.x, r.y);
             }
         }
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     store_rows(v0);                                     // the rows were requested first, so they are back first
     asm volatile("" ::: "memory");                        // keep the next request BEHIND the tile write (register budget)
     float4 r1b[8];
-    gemv_load<8>(P.w1, P0, P1, g1, 8, r1b);             // second half of prenet1 takes the registers the rows freed
+    gemv_load<8, EXACT>(P.w1, P0, P1, g1, 8, r1b);             // second half of prenet1 takes the registers the rows freed
     __syncthreads();
     GT_STAMP(P.dbg, 1);
 
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
             gemv_store(g0, P0, acc, partial);
         }
         asm volatile("" ::: "memory");                    // r0a is dead from here: its registers take the query weights
-        gemv_load<8>(P.wq, P1, A, g2, 0, r2a);          // query weights: in flight while prenet0/1 compute
+        gemv_load<8, EXACT>(P.wq, P1, A, g2, 0, r2a);          // query weights: in flight while prenet0/1 compute
         __syncthreads();
         for (int c = tid; c < P0; c += FT) y0[c] = fmaxf(reduce_partial(partial, g0.kparts, P0, c) + sb0[c], 0.f) * sk0[c];
         __syncthreads();
@@ -282,8 +296,8 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     // ---- prenet layer 1
     {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        gemv_acc<8>(y0, P0, g1, 0, r1a, acc);
-        gemv_acc<8>(y0, P0, g1, 8, r1b, acc);
+        gemv_acc<8, EXACT>(y0, P0, g1, 0, r1a, acc);
+        gemv_acc<8, EXACT>(y0, P0, g1, 8, r1b, acc);
         gemv_store(g1, P1, acc, partial);
     }
     __syncthreads();
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     // ---- query projection
     {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        gemv_acc<8>(y1, P1, g2, 0, r2a, acc);
+        gemv_acc<8, EXACT>(y1, P1, g2, 0, r2a, acc);
         gemv_store(g2, A, acc, partial);
     }
     __syncthreads();
@@ -436,16 +450,33 @@ bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv) {
     return front_lds_bytes(t) <= 150 * 1024;
 }
 
-template <int L, int NP>
-static hipError_t front_launch(const DecFrontArgs& a, hipStream_t s) {
+// prenet-1 and query plans divide evenly: 16 resp. 8 rows for every lane (gemv_load EXACT)
+static bool front_exact(const DecFrontArgs& a) {
+    auto rows = [](int K, int N) {
+        if (N % 4 || N / 4 > FT || FT % (N / 4)) return -1;
+        const int kparts = FT / (N / 4);
+        return (kparts <= K && K % kparts == 0) ? K / kparts : -1;
+    };
+    static const bool on = getenv("GSTTACO_FRONT_EXACT") && getenv("GSTTACO_FRONT_EXACT")[0] == '1';
+    return on && rows(a.P0, a.P1) == 16 && rows(a.P1, a.A) == 8;
+}
+
+template <int L, int NP, bool Z0, bool LEAN>
+static void front_launch2(const DecFrontArgs& a, hipStream_t s) {
     const dim3 grid(a.B + a.n_workers), block(FT);
     const size_t lds = front_lds_bytes(a);
+    if (front_exact(a)) hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, Z0, LEAN, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, Z0, LEAN, false>), grid, block, lds, s, a);
+}
+
+template <int L, int NP>
+static hipError_t front_launch(const DecFrontArgs& a, hipStream_t s) {
     if (a.z0) {
-        if (a.lean_rec) hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, true, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, true, false>), grid, block, lds, s, a);
+        if (a.lean_rec) front_launch2<L, NP, true, true>(a, s);
+        else front_launch2<L, NP, true, false>(a, s);
     } else {
-        if (a.lean_rec) hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, false, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, false, false>), grid, block, lds, s, a);
+        if (a.lean_rec) front_launch2<L, NP, false, true>(a, s);
+        else front_launch2<L, NP, false, false>(a, s);
     }
     return hipGetLastError();
 }
@@ -463,13 +494,15 @@ hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t s) {
 
 hipError_t gt_dec_front_init() {
     hipError_t e;
-#define FRONT_ATTR1(L, NP, Z, LN)                                                                 \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP, Z, LN>),   \
+#define FRONT_ATTR1(L, NP, Z, LN, EX)                                                                 \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP, Z, LN, EX>),   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
     if (e != hipSuccess) return e;
-#define FRONT_ATTR(L, NP) FRONT_ATTR1(L, NP, false, false) FRONT_ATTR1(L, NP, false, true) FRONT_ATTR1(L, NP, true, false) FRONT_ATTR1(L, NP, true, true)
+#define FRONT_ATTR2(L, NP, EX) FRONT_ATTR1(L, NP, false, false, EX) FRONT_ATTR1(L, NP, false, true, EX) FRONT_ATTR1(L, NP, true, false, EX) FRONT_ATTR1(L, NP, true, true, EX)
+#define FRONT_ATTR(L, NP) FRONT_ATTR2(L, NP, false) FRONT_ATTR2(L, NP, true)
     FRONT_ATTR(4, 1) FRONT_ATTR(8, 1) FRONT_ATTR(8, 2) FRONT_ATTR(8, 4) FRONT_ATTR(8, 8)
 #undef FRONT_ATTR
 #undef FRONT_ATTR1
+#undef FRONT_ATTR2
     return hipSuccess;
 }
