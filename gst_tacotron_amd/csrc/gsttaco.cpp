@@ -89,7 +89,7 @@ struct gsttaco_ctx {
     float* w_part[2] = {nullptr, nullptr};
     bool split_rec = true;
     int keep_x_weights = 1;
-    int co_tiles = 64;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
+    int co_tiles = 128;          // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
     bool lean = true;            // lean_body.h kernels for the decode shapes they cover (GSTTACO_LEAN=0: general kernels only)

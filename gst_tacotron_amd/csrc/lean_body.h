@@ -28,13 +28,15 @@ struct LeanX {
 };
 
 // acc0[j] / acc1[j]: rows m0..m0+15 / m0+16..m0+31 of tile (tile0 + j).  All NW*64 threads must call.
-template <int NW, int KPW, int NT, bool NTW>
+// ONE_M: `mchunk` counts 16-row M-tiles and only acc0 (rows mchunk*16 .. +15) is computed -- for GEMMs with fewer tiles
+// than CUs (the projection), where a second workgroup per tile halves each one's activation pull and MFMA chain.
+template <int NW, int KPW, int NT, bool NTW, bool ONE_M = false>
 __device__ __forceinline__ void gt_lean_core(const float* __restrict__ wp, const int tile0, const int ntile, const LeanX X, const int MT,
                                              const int mchunk, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]) {
     constexpr int NKB = NW * KPW;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mt0 = mchunk * 2, mt1 = min(mt0 + 1, MT - 1);
+    const int mt0 = ONE_M ? mchunk : mchunk * 2, mt1 = min(mt0 + 1, MT - 1);
     const float4* wl = reinterpret_cast<const float4*>(wp) + ((size_t)tile0 * NKB + wave) * 64 + lane;
     float4 b[KPW][NT], x0[KPW], x1[KPW];
 #pragma unroll
@@ -55,7 +57,7 @@ __device__ __forceinline__ void gt_lean_core(const float* __restrict__ wp, const
         }
         const float* xs = kb < X.nkb_a ? X.xa + (size_t)kb * MT * 256 : X.xb + (size_t)(kb - X.nkb_a) * MT * 256;
         x0[i] = *reinterpret_cast<const float4*>(xs + mt0 * 256 + lane * 4);
-        x1[i] = *reinterpret_cast<const float4*>(xs + mt1 * 256 + lane * 4);
+        if (!ONE_M) x1[i] = *reinterpret_cast<const float4*>(xs + mt1 * 256 + lane * 4);
     }
     // every load above is requested before the first MFMA (without this the scheduler sinks each load next to its use
     // to save registers, and the wave pays one memory latency per k-block instead of one in all)
@@ -66,13 +68,13 @@ __device__ __forceinline__ void gt_lean_core(const float* __restrict__ wp, const
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, b[i][j].x, acc0[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, b[i][j].x, acc1[j], 0, 0, 0);
+            if (!ONE_M) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, b[i][j].x, acc1[j], 0, 0, 0);
             acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, b[i][j].y, acc0[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, b[i][j].y, acc1[j], 0, 0, 0);
+            if (!ONE_M) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, b[i][j].y, acc1[j], 0, 0, 0);
             acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, b[i][j].z, acc0[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, b[i][j].z, acc1[j], 0, 0, 0);
+            if (!ONE_M) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, b[i][j].z, acc1[j], 0, 0, 0);
             acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, b[i][j].w, acc0[j], 0, 0, 0);
-            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, b[i][j].w, acc1[j], 0, 0, 0);
+            if (!ONE_M) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, b[i][j].w, acc1[j], 0, 0, 0);
         }
     }
 }

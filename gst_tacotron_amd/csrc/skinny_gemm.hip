@@ -176,26 +176,26 @@ __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanParti
         }
         return;
     }
-    const int tile = blockIdx.x;
-    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    // main tiles: one workgroup per (tile, 16-row M-tile) -- 27 tiles would leave most CUs idle, so the rows are split
+    const int tile = (int)blockIdx.x / P.MT, mt = (int)blockIdx.x % P.MT;
+    const int row = (threadIdx.x >> 4) & 15, col = threadIdx.x & 15, half = threadIdx.x >> 8;   // waves 0-3 / 4-7 reduce half the partials each
     const int gcol = tile * 16 + col;
     const float bias = P.bias[gcol];
-    for (int mc = 0; mc < mchunks; ++mc) {
-        f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-        gt_lean_core<NW, 9, 1, false>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mc, acc0, acc1);
-        gt_lean_spill<NW, 1>(lds, acc0, acc1);
-        __syncthreads();
-        const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
+    f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    gt_lean_core<NW, 9, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, acc0, acc1);
+    gt_lean_spill<NW, 1>(lds, acc0, acc1);          // (rows 16..31 of the slab are unused zeros)
+    __syncthreads();
+    const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
+    if (half == 0) {
         float v = bias;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += part[w][row][col];
-        const int grow = mc * 32 + row;
+        const int grow = mt * 16 + row;
         if (grow < P.M && gcol < P.N) {
             if (P.out3 && gcol >= P.col3) P.out3[(size_t)grow * P.ldo3 + (gcol - P.col3)] = v;
             else if (gcol < P.n_split) P.out[(size_t)grow * P.ldo + gcol] = v;
             else if (!P.out3 || gcol < P.n_valid2) P.out2[(size_t)grow * P.ldo2 + (gcol - P.n_split)] = v;
         }
-        if (mc + 1 < mchunks) __syncthreads();
     }
 }
 
@@ -206,8 +206,8 @@ hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp
     const int nco = co_end > co_begin ? co_end - co_begin : 0;
     LeanPartialArgs co{co_wp, co_bias, co_x, co_out, m.MT};
     if (tiles_per_worker == 2)
-        hipLaunchKernelGGL((gt_proj_lean_kernel<2>), dim3(ntiles + (nco + 1) / 2), dim3(512), 0, stream, m, co, ntiles, co_begin, co_end);
+        hipLaunchKernelGGL((gt_proj_lean_kernel<2>), dim3(ntiles * m.MT + (nco + 1) / 2), dim3(512), 0, stream, m, co, ntiles * m.MT, co_begin, co_end);
     else
-        hipLaunchKernelGGL((gt_proj_lean_kernel<1>), dim3(ntiles + nco), dim3(512), 0, stream, m, co, ntiles, co_begin, co_end);
+        hipLaunchKernelGGL((gt_proj_lean_kernel<1>), dim3(ntiles * m.MT + nco), dim3(512), 0, stream, m, co, ntiles * m.MT, co_begin, co_end);
     return hipGetLastError();
 }
