@@ -88,6 +88,27 @@ struct LstmXArgs {
 bool gt_lstm_x_supported(int nkb);
 hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, hipStream_t stream);
 
+// One time step of a Bidirectional LSTM (reference Taco2.py:39-43, 394-398) whose input halves x_t . W_x + b were hoisted
+// into ONE GEMM over all time steps (columns in tile order: tile*16 + gate*4 + unit%4): z = zx + h_{t-1} . W_h, gates, cell
+// update.  grid = (H/4 tiles, ceil(M/32), 2 directions).
+struct BiLstmDir {
+    const float* wp;        // packed W_h [H/4 tiles][H/16][64][4]
+    const float* hprev;     // blocked state [H/16][MT][64][4]
+    float* hnext;
+    float* c;               // [M, H]
+    const float* zx;        // hoisted input half of THIS time step: element (row, tile, col) at zx[row*ldz + tile*16 + col]
+    float* out;             // row-major output of this time step: (row, unit) at out[row*ldo + unit]
+    int t_index;            // masked-mode extension (A12): rows with t_index >= row_len[row] write h = 0 and keep c
+};
+struct BiLstmArgs {
+    BiLstmDir d[2];
+    const int32_t* row_len;
+    int64_t ldz, ldo;
+    int M, MT, H;
+};
+bool gt_bilstm_lean_supported(int nkb_h);
+hipError_t gt_launch_bilstm_lean(const BiLstmArgs& a, hipStream_t stream);
+
 // Projection [h2 | ctx] -> mel frames | stop logit | (optional) next step's prenet-0 pre-activations, with co-scheduled
 // recurrent-half worker tiles of LSTM layer 2 for the next step in the same launch.
 struct ProjArgs {

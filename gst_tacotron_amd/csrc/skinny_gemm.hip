@@ -211,3 +211,56 @@ hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp
         hipLaunchKernelGGL((gt_proj_lean_kernel<1>), dim3(ntiles * m.MT + nco), dim3(512), 0, stream, m, co, ntiles * m.MT, co_begin, co_end);
     return hipGetLastError();
 }
+
+// Bidirectional LSTM time step on the hoisted input halves (see BiLstmArgs): K = H = 256 -> 4 waves x 4 k-blocks.
+template <int NW, int KPW>
+__global__ __launch_bounds__(NW * 64) void gt_bilstm_lean_kernel(BiLstmArgs A) {
+    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 1>::kFloats];
+    constexpr int NE = 512 / (NW * 64);
+    const BiLstmDir& D = A.d[blockIdx.z];
+    const int tile = blockIdx.x, mchunk = blockIdx.y;
+    const int m0 = mchunk * 32, MT = A.MT;
+    float pin[NE], c_prev[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + i * NW * 64;
+        const int row = e >> 4, col = e & 15;
+        const int grow = m0 + row, unit = tile * 4 + col;
+        pin[i] = (grow < A.M) ? D.zx[(size_t)grow * A.ldz + tile * 16 + col] : 0.f;
+        c_prev[i] = (col < 4 && grow < A.M && unit < A.H) ? D.c[(size_t)grow * A.H + unit] : 0.f;
+    }
+    f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    gt_lean_core<NW, KPW, 1, false>(D.wp, tile, 1, LeanX{D.hprev, D.hprev, NW * KPW}, MT, mchunk, acc0, acc1);
+    gt_lean_spill<NW, 1>(lds, acc0, acc1);
+    __syncthreads();
+    const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + i * NW * 64;
+        const int row = e >> 4, col = e & 15;
+        float z = pin[i];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) z += part[w][row][col];
+        const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+        const int grow = m0 + row, unit = tile * 4 + col;
+        if (col < 4 && grow < A.M && unit < A.H) {
+            float hv = 0.f;
+            if (!(A.row_len && D.t_index >= A.row_len[grow])) {
+                const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
+                const float c2 = gf * c_prev[i] + gi * gg;
+                D.c[(size_t)grow * A.H + unit] = c2;
+                hv = go * gt_tanh(c2);
+            }
+            D.hnext[gt_blk_off(grow, unit, MT)] = hv;
+            D.out[(size_t)grow * A.ldo + unit] = hv;
+        }
+    }
+}
+
+bool gt_bilstm_lean_supported(int nkb_h) { return nkb_h == 16; }
+
+hipError_t gt_launch_bilstm_lean(const BiLstmArgs& a, hipStream_t stream) {
+    const dim3 grid((a.H + 3) / 4, (a.M + 31) / 32, 2);
+    hipLaunchKernelGGL((gt_bilstm_lean_kernel<4, 4>), grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
