@@ -198,17 +198,23 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     if (P.drop_rate > 0.f && P.mask0) t_k0 = P.mask0[(size_t)b * P0 + min(tid, P0 - 1)];
     if (P.drop_rate > 0.f && P.mask1) t_k1 = P.mask1[(size_t)b * P1 + min(tid, P1 - 1)];
     if (P.sigmoid_noise > 0.f && P.noise) t_nz = P.noise[(size_t)b * P.ldnoise + min(tid, Tv - 1)];
-    float4 v0[NP];
-    load_rows(v0, 0);                                   // processed-memory rows of chunk 0 (64 KiB at 128x128)
-
     const GemvPlan g0 = make_plan(mel, P0, tid);
     const GemvPlan g1 = make_plan(P0, P1, tid);
     const GemvPlan g2 = make_plan(P1, A, tid);
-    // register budget (128 VGPRs at 16 waves/CU): three 8-row weight blocks + the memory rows in flight at t=0
-    float4 r0a[8], r1a[8];
-    if (Z0) gemv_load<8, EXACT>(P.wq, P1, A, g2, 0, r0a);      // (r0a holds the query weights in this variant)
-    else gemv_load<8>(P.w0, mel, P0, g0, 0, r0a);
-    gemv_load<8, EXACT>(P.w1, P0, P1, g1, 0, r1a);
+    // Request order = need order (loads return in issue order): with the prenet-0 pre-activations already there (Z0) the
+    // chain starts at prenet 1, so ALL of W1 goes first, then the query weights; the processed-memory rows, needed three
+    // phases later, are requested once prenet 1 has consumed W1 and take its registers (128 VGPRs at 16 waves/CU: three
+    // 8-row weight blocks is what fits).  Without Z0 (step 0) prenet 0 comes first and the rows ride along early.
+    float4 v0[NP];
+    float4 r0a[8], r1a[8], r1b[8], r2a[8];
+    if (Z0) {
+        gemv_load<8, EXACT>(P.w1, P0, P1, g1, 0, r1a);
+        gemv_load<8, EXACT>(P.w1, P0, P1, g1, 8, r1b);
+    } else {
+        load_rows(v0, 0);                               // processed-memory rows of chunk 0 (64 KiB at 128x128)
+        gemv_load<8>(P.w0, mel, P0, g0, 0, r0a);
+        gemv_load<8, EXACT>(P.w1, P0, P1, g1, 0, r1a);
+    }
 
     // dropout keep-scales and sigmoid noise (Philox, ~100 VALU ops each) while the first loads are in flight
     if (P.drop_rate > 0.f) {
@@ -268,15 +274,15 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     if (tid < Tv) pv[tid] = in_p;
     for (int t = tid + FT; t < Tv; t += FT) pv[t] = P.prev ? P.prev[(size_t)b * P.ldprev + t] : 0.f;
     GT_STAMP(P.dbg, 0);
-    store_rows(v0);                                     // the rows were requested first, so they are back first
-    asm volatile("" ::: "memory");                        // keep the next request BEHIND the tile write (register budget)
-    float4 r1b[8];
-    gemv_load<8, EXACT>(P.w1, P0, P1, g1, 8, r1b);             // second half of prenet1 takes the registers the rows freed
+    if (!Z0) {
+        store_rows(v0);                                 // the rows were requested first, so they are back first
+        asm volatile("" ::: "memory");                    // keep the next request BEHIND the tile write (register budget)
+        gemv_load<8, EXACT>(P.w1, P0, P1, g1, 8, r1b);         // second half of prenet1 takes the registers the rows freed
+    }
     __syncthreads();
     GT_STAMP(P.dbg, 1);
 
     // ---- prenet layer 0
-    float4 r2a[8];
     if (!Z0) {
         {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -288,9 +294,6 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         __syncthreads();
         for (int c = tid; c < P0; c += FT) y0[c] = fmaxf(reduce_partial(partial, g0.kparts, P0, c) + sb0[c], 0.f) * sk0[c];
         __syncthreads();
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r2a[i] = r0a[i];
     }
     GT_STAMP(P.dbg, 2);
     // ---- prenet layer 1
@@ -299,6 +302,11 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         gemv_acc<8, EXACT>(y0, P0, g1, 0, r1a, acc);
         gemv_acc<8, EXACT>(y0, P0, g1, 8, r1b, acc);
         gemv_store(g1, P1, acc, partial);
+    }
+    if (Z0) {
+        asm volatile("" ::: "memory");                    // W1 is consumed: its registers take the query weights and the rows
+        gemv_load<8, EXACT>(P.wq, P1, A, g2, 0, r2a);
+        load_rows(v0, 0);
     }
     __syncthreads();
     for (int c = tid; c < P1; c += FT) {
@@ -316,6 +324,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     }
     __syncthreads();
     for (int c = tid; c < A; c += FT) qs[c] = reduce_partial(partial, g2.kparts, A, c) + sbq[c];
+    if (Z0) store_rows(v0);
     __syncthreads();
     GT_STAMP(P.dbg, 4);
 
@@ -457,7 +466,7 @@ static bool front_exact(const DecFrontArgs& a) {
         const int kparts = FT / (N / 4);
         return (kparts <= K && K % kparts == 0) ? K / kparts : -1;
     };
-    static const bool on = getenv("GSTTACO_FRONT_EXACT") && getenv("GSTTACO_FRONT_EXACT")[0] == '1';
+    static const bool on = !(getenv("GSTTACO_FRONT_EXACT") && getenv("GSTTACO_FRONT_EXACT")[0] == '0');
     return on && rows(a.P0, a.P1) == 16 && rows(a.P1, a.A) == 8;
 }
 

@@ -6,6 +6,9 @@ import torch
 from gst_tacotron_amd import synthetic, weights
 from gst_tacotron_amd.model import GST_Tacotron
 hp, inputs = synthetic.config_inputs("cfg2", batch=32)
+if os.environ.get("STAMPS_NO_RANDOM") == "1":
+    hp["Tacotron2"]["Decoder"]["Prenet"]["Dropout_Rate"] = 0.0
+    hp["Tacotron2"]["Decoder"]["Attention"]["Sigmoid_Noise"] = 0.0
 w = weights.synthetic_weights(hp, seed=0)
 m = GST_Tacotron(hyper_parameters=hp, max_batch=32, max_tokens=128, max_ref_frames=257)
 m.Restore(weights=w)
