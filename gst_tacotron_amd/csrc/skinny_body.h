@@ -210,7 +210,7 @@ __device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int ti
                 const float gf = gt_sigmoid(zs[row][4 + u]);
                 const float gg = gt_tanh(zs[row][8 + u]);
                 const float go = gt_sigmoid(zs[row][12 + u]);
-                const float c2 = gf * c_prev + gi * gg;
+                const float c2 = __builtin_fmaf(gf, c_prev, gi * gg);     // (explicit: the same contraction in every body)
                 A.c[(size_t)grow * A.N + unit] = c2;
                 const float hv = go * gt_tanh(c2);
                 if (A.out_blocked) A.h[gt_blk_off(grow, unit, MT)] = hv;

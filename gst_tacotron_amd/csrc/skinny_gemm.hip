@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
                 A.h[gt_blk_off(grow, unit, MT)] = 0.f;          // masked mode: this step does not exist for this utterance
             } else {
                 const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
-                const float c2 = gf * c_prev[i] + gi * gg;
+                const float c2 = __builtin_fmaf(gf, c_prev[i], gi * gg);
                 A.c[(size_t)grow * A.H + unit] = c2;
                 A.h[gt_blk_off(grow, unit, MT)] = go * gt_tanh(c2);
             }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void gt_bilstm_lean_kernel(BiLstmArgs A) {
             float hv = 0.f;
             if (!(A.row_len && D.t_index >= A.row_len[grow])) {
                 const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
-                const float c2 = gf * c_prev[i] + gi * gg;
+                const float c2 = __builtin_fmaf(gf, c_prev[i], gi * gg);
                 D.c[(size_t)grow * A.H + unit] = c2;
                 hv = go * gt_tanh(c2);
             }

@@ -162,6 +162,32 @@ def test_eager_graph_and_unfused_paths_agree(monkeypatch):
     assert np.abs(outs[0][0] - outs[2][0]).max() <= TOL and np.abs(outs[0][1] - outs[2][1]).max() <= TOL
 
 
+def test_lean_and_general_decode_kernels_are_the_same_arithmetic(monkeypatch):
+    """csrc/lean_body.h restates the general skinny GEMM body for the decode shapes with K fixed at compile time: same
+    k-block-to-wave assignment, same summation order, so the decode loop (LSTM input halves, projection, recurrent-half
+    workers) is BITWISE the general kernels' result at full dimensions; the lean encoder BiLSTM hoists its input halves
+    into one GEMM (different summation order) and agrees within the parity tolerance."""
+    import torch
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(5, 40, 90, 12, seed=9)
+    w64 = None
+    outs = []
+    for lean in ("1", "0"):
+        monkeypatch.setenv("GSTTACO_LEAN", lean)
+        m = _model(hp, w, 5, 40, 91)
+        enc = m.encode(tokens)
+        gst = m.Inference_GST_Step(mels, ml)
+        torch.cuda.synchronize()
+        if w64 is None:
+            w64 = (enc.cpu().numpy().copy(), gst.cpu().numpy().copy())     # decode both variants from the SAME memory
+        pre, stop, align = m.decode(w64[0], w64[1], masks, noise, steps=12)
+        torch.cuda.synchronize()
+        outs.append((enc.cpu().numpy(), pre.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy()))
+    monkeypatch.delenv("GSTTACO_LEAN")
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= TOL                      # encoder: hoisted vs fused input half
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert np.array_equal(a, b)                                          # decode loop: bitwise
+
+
 def test_on_device_randomness_is_seeded():
     """Throughput mode (no injected tensors): Philox dropout / SMA noise are a pure function of the seed."""
     import torch
