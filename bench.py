@@ -164,9 +164,10 @@ def main():
 
     # per-kernel timing of the decode step: HIP event-record nodes inside the replayed graph (on the stream the
     # kernels run on), every PROFILE_EVERY-th decode step of the last timed replay
-    KNAMES = {0: "gt_skinny_kernel<EPI_LSTM> layer 1 (x-half)", 1: "gt_skinny_kernel<EPI_LSTM> layer 2 (x-half)",
-              2: "gt_dec_front_kernel (prenet x2 + query + attention per utterance; workers: recurrent halves W_h.h+b)",
-              3: "gt_skinny_co_kernel (projection; workers: layer-2 recurrent half)"}
+    KNAMES = {0: "gt_lstm_x_kernel<4,6> LSTM layer 1 (input half + gates)", 1: "gt_lstm_x_kernel<8,8> LSTM layer 2 (input half + gates)",
+              2: "gt_dec_front_kernel (prenet + query + attention per utterance; workers: recurrent halves W_h.h+b)",
+              3: "gt_proj_lean_kernel (projection + next prenet-0; workers: layer-2 recurrent half)"}
+    KPMC = {0: "gt_lstm_x_kernel<4, 6, 1>", 1: "gt_lstm_x_kernel<8, 8, 2>", 2: "gt_dec_front_kernel<8, 4, true", 3: "gt_proj_lean_kernel"}
     prof = {}
     for which in range(4):
         ms, cnt = ctypes.c_float(), ctypes.c_int()
@@ -186,8 +187,7 @@ def main():
         dom = max(prof, key=lambda k: prof[k][0])          # dominant = largest share of the decode step
         ms1, cnt1, bytes1 = prof[dom]
         achieved = (bytes1 / (ms1 * 1e-3)) / 1e9 if ms1 > 0 else 0.0
-        traffic, traffic_src = pmc_traffic("gt_dec_front_kernel" if dom == 2 else
-                                           ("gt_skinny_co_kernel" if dom == 3 else "gt_skinny_kernel<2, 8, %d>" % (dom + 1)))
+        traffic, traffic_src = pmc_traffic(KPMC[dom])
         step_us = sum(v[0] for v in prof.values()) * 1e3
         step_bytes = sum(v[2] for v in prof.values())
         line = {

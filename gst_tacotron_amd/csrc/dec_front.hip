@@ -107,7 +107,7 @@ __device__ __forceinline__ float front_wave_incl_scan(float x, int lane) {
 // Z0: the projection launch of the previous step already produced this step's prenet-0 pre-activations (the projection and
 // the first prenet Dense are both linear: frame.W0 + b0 = [h2|ctx].(Wp_last.W0) + (bp_last.W0 + b0), DecFrontArgs::z0), so the
 // chain starts at prenet 1 and the query weights are requested at kernel start in place of prenet 0's.
-template <int L, int NP, bool Z0, bool LEAN, bool EXACT>
+template <int L, int NP, bool Z0, int LEAN, bool EXACT>
 __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     constexpr int A = 4 * L * NP;
     constexpr int ROWS = FT / L;            // memory rows per pass (one LDS tile)
@@ -128,7 +128,8 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
             const int tile = P.rec_begin[layer] + (layer == 0 ? job : job - j0) * wt;
             const int ntile = min(wt, P.rec_end[layer] - tile);
             for (int mc = 0; mc < mchunks; ++mc) {
-                if (LEAN) gt_lean_partial<FT / 64, 4, WT>(P.lrec[layer], tile, ntile, mc, smem);
+                if (LEAN == 2) gt_lean_partial<FT / 64, 2, WT, true>(P.lrec[layer], tile, ntile, mc, smem);
+                else if (LEAN == 1) gt_lean_partial<FT / 64, 4, WT>(P.lrec[layer], tile, ntile, mc, smem);
                 else gt_skinny_partial_multi<FT / 64, WT, true>(P.rec[layer], tile, ntile, mc, smem);
                 __syncthreads();
             }
@@ -470,22 +471,26 @@ static bool front_exact(const DecFrontArgs& a) {
     return on && rows(a.P0, a.P1) == 16 && rows(a.P1, a.A) == 8;
 }
 
-template <int L, int NP, bool Z0, bool LEAN>
+template <int L, int NP, bool Z0, int LEAN>
 static void front_launch2(const DecFrontArgs& a, hipStream_t s) {
     const dim3 grid(a.B + a.n_workers), block(FT);
     const size_t lds = front_lds_bytes(a);
-    if (front_exact(a)) hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, Z0, LEAN, true>), grid, block, lds, s, a);
+    // (without Z0 -- step 0, or prenet-0 fusion off -- the old request order keeps more rows in flight and the
+    // unpredicated variant spills: predicated loads there)
+    if (Z0 && front_exact(a)) hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, Z0, LEAN, true>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((gt_dec_front_kernel<L, NP, Z0, LEAN, false>), grid, block, lds, s, a);
 }
 
 template <int L, int NP>
 static hipError_t front_launch(const DecFrontArgs& a, hipStream_t s) {
     if (a.z0) {
-        if (a.lean_rec) front_launch2<L, NP, true, true>(a, s);
-        else front_launch2<L, NP, true, false>(a, s);
+        if (a.lean_rec == 2) front_launch2<L, NP, true, 2>(a, s);
+        else if (a.lean_rec == 1) front_launch2<L, NP, true, 1>(a, s);
+        else front_launch2<L, NP, true, 0>(a, s);
     } else {
-        if (a.lean_rec) front_launch2<L, NP, false, true>(a, s);
-        else front_launch2<L, NP, false, false>(a, s);
+        if (a.lean_rec == 2) front_launch2<L, NP, false, 2>(a, s);
+        else if (a.lean_rec == 1) front_launch2<L, NP, false, 1>(a, s);
+        else front_launch2<L, NP, false, 0>(a, s);
     }
     return hipGetLastError();
 }
@@ -507,7 +512,7 @@ hipError_t gt_dec_front_init() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_front_kernel<L, NP, Z, LN, EX>),   \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);            \
     if (e != hipSuccess) return e;
-#define FRONT_ATTR2(L, NP, EX) FRONT_ATTR1(L, NP, false, false, EX) FRONT_ATTR1(L, NP, false, true, EX) FRONT_ATTR1(L, NP, true, false, EX) FRONT_ATTR1(L, NP, true, true, EX)
+#define FRONT_ATTR2(L, NP, EX) FRONT_ATTR1(L, NP, false, 0, EX) FRONT_ATTR1(L, NP, false, 1, EX) FRONT_ATTR1(L, NP, false, 2, EX) FRONT_ATTR1(L, NP, true, 0, EX) FRONT_ATTR1(L, NP, true, 1, EX) FRONT_ATTR1(L, NP, true, 2, EX)
 #define FRONT_ATTR(L, NP) FRONT_ATTR2(L, NP, false) FRONT_ATTR2(L, NP, true)
     FRONT_ATTR(4, 1) FRONT_ATTR(8, 1) FRONT_ATTR(8, 2) FRONT_ATTR(8, 4) FRONT_ATTR(8, 8)
 #undef FRONT_ATTR

@@ -697,7 +697,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 }
                 f.n_workers = B < 192 ? 256 - B : 64;
                 f.worker_tiles = c->worker_tiles;
-                f.lean_rec = c->lean && !f.rec[0].bf16 && !f.rec[1].bf16 && f.rec[0].nkb == 64 && f.rec[1].nkb == 64;
+                f.lean_rec = (c->lean && f.rec[0].bf16 == f.rec[1].bf16 && f.rec[0].nkb == 64 && f.rec[1].nkb == 64) ? (f.rec[0].bf16 ? 2 : 1) : 0;
                 for (int layer = 0; layer < 2; ++layer)
                     f.lrec[layer] = LeanPartialArgs{f.rec[layer].wp, f.rec[layer].bias, f.rec[layer].seg[0].ptr, f.rec[layer].partial_out, MT};
                 // from step 1 on, the projection kernel of the previous step already did layer-2 tiles [0, co_tiles)
@@ -776,9 +776,9 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             k.M = B; k.MT = MT;
             k.dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
             if (prof) { int rce = prof_begin(layer); if (rce) return rce; }
-            if (split && c->lean && !k.bf16 && c->keep_x_weights && gt_lstm_x_supported(k.nkb)) {
+            if (split && c->lean && c->keep_x_weights && gt_lstm_x_supported(k.nkb)) {
                 LstmXArgs la{k.wp, k.seg[0].ptr, k.partial_in, k.c, k.h, nullptr, k.dbg, B, MT, H, 0};
-                HIPCHECK(c, gt_launch_lstm_x(la, k.nkb, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2, s));
+                HIPCHECK(c, gt_launch_lstm_x(la, k.nkb, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2, k.bf16 != 0, s));
             } else
             HIPCHECK(c, launch_skinny(c, EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));
             if (prof) { int rce = prof_end(layer); if (rce) return rce; }
@@ -806,11 +806,12 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             rk.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
             rk.M = B; rk.N = H2; rk.MT = MT;
             rk.partial_out = c->w_part[1];
-            if (c->lean && !k.bf16 && !rk.bf16 && gt_proj_lean_supported(k.nkb, rk.nkb) && k.seg[0].nkb + k.seg[1].nkb == k.nkb) {
+            if (c->lean && k.bf16 == rk.bf16 && gt_proj_lean_supported(k.nkb, rk.nkb) && k.seg[0].nkb + k.seg[1].nkb == k.nkb &&
+                k.seg[0].nkb % 2 == 0) {
                 ProjArgs pa{k.wp, k.bias, k.seg[0].ptr, k.seg[1].ptr, k.seg[0].nkb, B, MT, k.N, k.n_split, k.n_valid2, k.col3,
                             k.out, k.ldo, k.out2, k.ldo2, k.out3, k.ldo3};
                 HIPCHECK(c, gt_launch_proj_lean(pa, PJ.ntiles, rk.wp, rk.bias, rk.seg[0].ptr, rk.partial_out, 0, co_tiles,
-                                                c->co_worker_tiles, s));
+                                                c->co_worker_tiles, k.bf16 != 0, s));
             } else
             HIPCHECK(c, launch_skinny_co(c, k, PJ.ntiles, rk, 0, co_tiles, s));
         } else {

@@ -86,7 +86,7 @@ struct LstmXArgs {
     int M, MT, H, t_index;
 };
 bool gt_lstm_x_supported(int nkb);
-hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, hipStream_t stream);
+hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, bool bf16, hipStream_t stream);
 
 // One time step of a Bidirectional LSTM (reference Taco2.py:39-43, 394-398) whose input halves x_t . W_x + b were hoisted
 // into ONE GEMM over all time steps (columns in tile order: tile*16 + gate*4 + unit%4): z = zx + h_{t-1} . W_h, gates, cell
@@ -122,7 +122,7 @@ struct ProjArgs {
 };
 bool gt_proj_lean_supported(int nkb_main, int nkb_co);
 hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp, const float* co_bias, const float* co_x,
-                               float* co_out, int co_begin, int co_end, int tiles_per_worker, hipStream_t stream);
+                               float* co_out, int co_begin, int co_end, int tiles_per_worker, bool bf16, hipStream_t stream);
 
 // ---------------------------------------------------------------- gemm_conv.hip
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_TANH = 2 };
@@ -214,7 +214,7 @@ struct DecFrontArgs {
     int n_workers;
     int worker_tiles;               // tiles per worker job: 1, or 0/2 = pairs sharing one pass over the activations
     LeanPartialArgs lrec[2];        // the same two GEMMs for the lean body (fp32, K = 1024); used when lean_rec != 0
-    int lean_rec;
+    int lean_rec;                   // 0: general body, 1: lean fp32, 2: lean bf16
 };
 bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv);
 hipError_t gt_dec_front_init();

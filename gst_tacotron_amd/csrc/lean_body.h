@@ -79,6 +79,72 @@ __device__ __forceinline__ void gt_lean_core(const float* __restrict__ wp, const
     }
 }
 
+// Mixed precision (Use_Mixed_Precision): the same core on v_mfma_f32_16x16x32_bf16.  Weights are the bf16 pack
+// [tile][32-k block][lane][8] (one 16-byte load per lane per 32 k, slot i <-> k = 32 j + 16 (i>>2) + 4 q + (i&3)); the fp32
+// activations of the two 16-blocks (2j, 2j+1) are rounded to bf16 (RNE) on their way into the MFMA -- exactly what the
+// general body does, in the same order, so the results are bitwise the same.  KPW32 = 32-k blocks per wave (guarded by
+// nkb32, so 36 blocks on 8 waves is fine); nkb_a (in 16-blocks) must be even.
+template <int NW, int KPW32, int NT, bool NTW, bool ONE_M = false>
+__device__ __forceinline__ void gt_lean_core_bf16(const float* __restrict__ wp, const int tile0, const int ntile, const LeanX X, const int MT,
+                                                  const int mchunk, const int nkb32, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mt0 = ONE_M ? mchunk : mchunk * 2, mt1 = min(mt0 + 1, MT - 1);
+    const uint4* wl = reinterpret_cast<const uint4*>(wp) + ((size_t)tile0 * nkb32 + wave) * 64 + lane;
+    uint4 b[KPW32][NT];
+    float4 x0[KPW32][2], x1[KPW32][2];
+#pragma unroll
+    for (int i = 0; i < KPW32; ++i) {
+        const int kb32 = wave + i * NW;                     // wave-uniform
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b[i][j] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) { x0[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f); x1[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (kb32 < nkb32) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (NT == 1 || j < ntile) {
+                    const uint4* src = wl + ((size_t)j * nkb32 + i * NW) * 64;
+                    if (NTW) {
+                        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+                        b[i][j] = make_uint4(t[0], t[1], t[2], t[3]);
+                    } else {
+                        b[i][j] = *src;
+                    }
+                }
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int kb = 2 * kb32 + hf;
+                const float* xs = kb < X.nkb_a ? X.xa + (size_t)kb * MT * 256 : X.xb + (size_t)(kb - X.nkb_a) * MT * 256;
+                x0[i][hf] = *reinterpret_cast<const float4*>(xs + mt0 * 256 + lane * 4);
+                if (!ONE_M) x1[i][hf] = *reinterpret_cast<const float4*>(xs + mt1 * 256 + lane * 4);
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < KPW32; ++i) {
+        if (wave + i * NW < nkb32) {
+            bf16x8 a0, a1;
+            a0[0] = (__bf16)x0[i][0].x; a0[1] = (__bf16)x0[i][0].y; a0[2] = (__bf16)x0[i][0].z; a0[3] = (__bf16)x0[i][0].w;
+            a0[4] = (__bf16)x0[i][1].x; a0[5] = (__bf16)x0[i][1].y; a0[6] = (__bf16)x0[i][1].z; a0[7] = (__bf16)x0[i][1].w;
+            if (!ONE_M) {
+                a1[0] = (__bf16)x1[i][0].x; a1[1] = (__bf16)x1[i][0].y; a1[2] = (__bf16)x1[i][0].z; a1[3] = (__bf16)x1[i][0].w;
+                a1[4] = (__bf16)x1[i][1].x; a1[5] = (__bf16)x1[i][1].y; a1[6] = (__bf16)x1[i][1].z; a1[7] = (__bf16)x1[i][1].w;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bf16x8 bw;
+                __builtin_memcpy(&bw, &b[i][j], 16);
+                acc0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw, acc0[j], 0, 0, 0);
+                if (!ONE_M) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw, acc1[j], 0, 0, 0);
+            }
+        }
+    }
+}
+
 // accumulators -> LDS part[j][wave][32 rows][17] (C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg)
 template <int NW, int NT>
 __device__ __forceinline__ void gt_lean_spill(float* lds, const f32x4 (&acc0)[NT], const f32x4 (&acc1)[NT]) {
@@ -98,7 +164,7 @@ __device__ __forceinline__ void gt_lean_spill(float* lds, const f32x4 (&acc0)[NT
 
 // Recurrent-half worker job: NT adjacent tiles of  h . W_h + b  written as pre-activation partial sums in tile order
 // [tile][MT*16 rows][16 cols] (the consumer is gt_lstm_x_kernel).  One pass over the activations for all NT tiles.
-template <int NW, int KPW, int NT>
+template <int NW, int KPW, int NT, bool BF16 = false>
 __device__ __forceinline__ void gt_lean_partial(const LeanPartialArgs& A, const int tile0, const int ntile, const int mchunk, float* lds) {
     constexpr int NE = (NT * 512 + NW * 64 - 1) / (NW * 64);
     const int m0 = mchunk * 32;
@@ -112,7 +178,8 @@ __device__ __forceinline__ void gt_lean_partial(const LeanPartialArgs& A, const 
     f32x4 acc0[NT], acc1[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    gt_lean_core<NW, KPW, NT, true>(A.wp, tile0, ntile, LeanX{A.x, A.x, NW * KPW}, A.MT, mchunk, acc0, acc1);
+    if (BF16) gt_lean_core_bf16<NW, KPW, NT, true>(A.wp, tile0, ntile, LeanX{A.x, A.x, 2 * NW * KPW}, A.MT, mchunk, NW * KPW, acc0, acc1);
+    else gt_lean_core<NW, KPW, NT, true>(A.wp, tile0, ntile, LeanX{A.x, A.x, NW * KPW}, A.MT, mchunk, acc0, acc1);
     gt_lean_spill<NW, NT>(lds, acc0, acc1);
     __syncthreads();
     const float (*part)[NW][32][17] = reinterpret_cast<const float (*)[NW][32][17]>(lds);

@@ -99,7 +99,7 @@ hipError_t gt_launch_skinny(int epi, const SkinnyArgs& a0, const SkinnyArgs* a1,
 // of hidden unit tile*4+u (Appendix A.6; reference Taco2.py:79-85 via StackedRNNCells).  The 16 columns of a row sit in
 // 16 adjacent lanes, so the lanes with column < 4 collect their unit's four gates with three lane shifts -- no second LDS
 // round trip or barrier.
-template <int NW, int KPW, int TAG>
+template <int NW, int KPW, int TAG, bool BF16>
 __global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
     __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 1>::kFloats];
     constexpr int NE = 512 / (NW * 64);
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
     }
     GT_STAMP(A.dbg, 0);
     f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-    gt_lean_core<NW, KPW, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, NW * KPW}, MT, mchunk, acc0, acc1);
+    if (BF16) gt_lean_core_bf16<NW, KPW, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, 2 * NW * KPW}, MT, mchunk, NW * KPW, acc0, acc1);
+    else gt_lean_core<NW, KPW, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, NW * KPW}, MT, mchunk, acc0, acc1);
     GT_STAMP(A.dbg, 1);
     gt_lean_spill<NW, 1>(lds, acc0, acc1);
     __syncthreads();
@@ -148,22 +149,27 @@ __global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
 
 bool gt_lstm_x_supported(int nkb) { return nkb == 24 || nkb == 64; }
 
-hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, hipStream_t stream) {
+template <int TAG>
+static void launch_lstm_x(const LstmXArgs& a, int nkb, bool bf16, hipStream_t stream) {
     const dim3 grid((a.H + 3) / 4, (a.M + 31) / 32);
     if (nkb == 24) {
-        if (tag == TAG_DEC_LSTM1) hipLaunchKernelGGL((gt_lstm_x_kernel<4, 6, TAG_DEC_LSTM1>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((gt_lstm_x_kernel<4, 6, TAG_DEC_LSTM2>), grid, dim3(256), 0, stream, a);
-    } else if (nkb == 64) {
-        if (tag == TAG_DEC_LSTM1) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG_DEC_LSTM1>), grid, dim3(512), 0, stream, a);
-        else hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG_DEC_LSTM2>), grid, dim3(512), 0, stream, a);
+        if (bf16) hipLaunchKernelGGL((gt_lstm_x_kernel<4, 3, TAG, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((gt_lstm_x_kernel<4, 6, TAG, false>), grid, dim3(256), 0, stream, a);
     } else {
-        return hipErrorInvalidValue;
+        if (bf16) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 4, TAG, true>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG, false>), grid, dim3(512), 0, stream, a);
     }
+}
+
+hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, bool bf16, hipStream_t stream) {
+    if (!gt_lstm_x_supported(nkb)) return hipErrorInvalidValue;
+    if (tag == TAG_DEC_LSTM1) launch_lstm_x<TAG_DEC_LSTM1>(a, nkb, bf16, stream);
+    else launch_lstm_x<TAG_DEC_LSTM2>(a, nkb, bf16, stream);
     return hipGetLastError();
 }
 
 // Projection (K = 1152 = 8 waves x 9 k-blocks) + co-scheduled layer-2 recurrent tiles (K = 1024 = 8 x 8), CT per worker.
-template <int CT>
+template <int CT, bool BF16>
 __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanPartialArgs co, int n_main, int co_begin, int co_end) {
     constexpr int NW = 8;
     __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, CT>::kFloats];
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanParti
     if ((int)blockIdx.x >= n_main) {
         const int tile = co_begin + ((int)blockIdx.x - n_main) * CT;
         for (int mc = 0; mc < mchunks; ++mc) {
-            gt_lean_partial<NW, 8, CT>(co, tile, min(CT, co_end - tile), mc, lds);
+            gt_lean_partial<NW, BF16 ? 4 : 8, CT, BF16>(co, tile, min(CT, co_end - tile), mc, lds);
             if (mc + 1 < mchunks) __syncthreads();
         }
         return;
@@ -182,7 +188,8 @@ __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanParti
     const int gcol = tile * 16 + col;
     const float bias = P.bias[gcol];
     f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-    gt_lean_core<NW, 9, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, acc0, acc1);
+    if (BF16) gt_lean_core_bf16<NW, 5, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, 36, acc0, acc1);
+    else gt_lean_core<NW, 9, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, acc0, acc1);
     gt_lean_spill<NW, 1>(lds, acc0, acc1);          // (rows 16..31 of the slab are unused zeros)
     __syncthreads();
     const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
@@ -202,13 +209,18 @@ __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanParti
 bool gt_proj_lean_supported(int nkb_main, int nkb_co) { return nkb_main == 72 && (nkb_co == 64 || nkb_co == 0); }
 
 hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp, const float* co_bias, const float* co_x,
-                               float* co_out, int co_begin, int co_end, int tiles_per_worker, hipStream_t stream) {
+                               float* co_out, int co_begin, int co_end, int tiles_per_worker, bool bf16, hipStream_t stream) {
     const int nco = co_end > co_begin ? co_end - co_begin : 0;
     LeanPartialArgs co{co_wp, co_bias, co_x, co_out, m.MT};
-    if (tiles_per_worker == 2)
-        hipLaunchKernelGGL((gt_proj_lean_kernel<2>), dim3(ntiles * m.MT + (nco + 1) / 2), dim3(512), 0, stream, m, co, ntiles * m.MT, co_begin, co_end);
-    else
-        hipLaunchKernelGGL((gt_proj_lean_kernel<1>), dim3(ntiles * m.MT + nco), dim3(512), 0, stream, m, co, ntiles * m.MT, co_begin, co_end);
+    const int n_main = ntiles * m.MT;
+    const dim3 g2(n_main + (nco + 1) / 2), g1(n_main + nco);
+    if (tiles_per_worker == 2) {
+        if (bf16) hipLaunchKernelGGL((gt_proj_lean_kernel<2, true>), g2, dim3(512), 0, stream, m, co, n_main, co_begin, co_end);
+        else hipLaunchKernelGGL((gt_proj_lean_kernel<2, false>), g2, dim3(512), 0, stream, m, co, n_main, co_begin, co_end);
+    } else {
+        if (bf16) hipLaunchKernelGGL((gt_proj_lean_kernel<1, true>), g1, dim3(512), 0, stream, m, co, n_main, co_begin, co_end);
+        else hipLaunchKernelGGL((gt_proj_lean_kernel<1, false>), g1, dim3(512), 0, stream, m, co, n_main, co_begin, co_end);
+    }
     return hipGetLastError();
 }
 

@@ -162,13 +162,15 @@ def test_eager_graph_and_unfused_paths_agree(monkeypatch):
     assert np.abs(outs[0][0] - outs[2][0]).max() <= TOL and np.abs(outs[0][1] - outs[2][1]).max() <= TOL
 
 
-def test_lean_and_general_decode_kernels_are_the_same_arithmetic(monkeypatch):
+@pytest.mark.parametrize("mixed", [False, True])
+def test_lean_and_general_decode_kernels_are_the_same_arithmetic(monkeypatch, mixed):
     """csrc/lean_body.h restates the general skinny GEMM body for the decode shapes with K fixed at compile time: same
     k-block-to-wave assignment, same summation order, so the decode loop (LSTM input halves, projection, recurrent-half
     workers) is BITWISE the general kernels' result at full dimensions; the lean encoder BiLSTM hoists its input halves
     into one GEMM (different summation order) and agrees within the parity tolerance."""
     import torch
     hp, w, tokens, tl, mels, ml, masks, noise = _full_case(5, 40, 90, 12, seed=9)
+    hp = dict(hp); hp["Use_Mixed_Precision"] = bool(mixed)        # bf16 operands: the lean bf16 bodies, same claim
     w64 = None
     outs = []
     for lean in ("1", "0"):
