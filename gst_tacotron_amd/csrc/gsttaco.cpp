@@ -93,7 +93,7 @@ struct gsttaco_ctx {
     float* w_part[2] = {nullptr, nullptr};
     bool split_rec = true;
     int keep_x_weights = 1;
-    int co_tiles = 128;          // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
+    int co_tiles = 64;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
     bool lean = true;            // lean_body.h kernels for the decode shapes they cover (GSTTACO_LEAN=0: general kernels only)
@@ -809,7 +809,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             if (c->lean && k.bf16 == rk.bf16 && gt_proj_lean_supported(k.nkb, rk.nkb) && k.seg[0].nkb + k.seg[1].nkb == k.nkb &&
                 k.seg[0].nkb % 2 == 0) {
                 ProjArgs pa{k.wp, k.bias, k.seg[0].ptr, k.seg[1].ptr, k.seg[0].nkb, B, MT, k.N, k.n_split, k.n_valid2, k.col3,
-                            k.out, k.ldo, k.out2, k.ldo2, k.out3, k.ldo3};
+                            k.out, k.ldo, k.out2, k.ldo2, k.out3, k.ldo3,
+                            (c->stamps && t == steps / 2) ? c->w_dbg + 40 : nullptr};
                 HIPCHECK(c, gt_launch_proj_lean(pa, PJ.ntiles, rk.wp, rk.bias, rk.seg[0].ptr, rk.partial_out, 0, co_tiles,
                                                 c->co_worker_tiles, k.bf16 != 0, s));
             } else

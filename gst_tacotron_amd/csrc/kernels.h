@@ -119,6 +119,7 @@ struct ProjArgs {
     float* out; int64_t ldo;
     float* out2; int64_t ldo2;
     float* out3; int64_t ldo3;
+    unsigned long long* dbg;                        // diagnostic stamps (8 slots) or NULL
 };
 bool gt_proj_lean_supported(int nkb_main, int nkb_co);
 hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp, const float* co_bias, const float* co_x,

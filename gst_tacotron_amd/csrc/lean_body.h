@@ -164,30 +164,33 @@ __device__ __forceinline__ void gt_lean_spill(float* lds, const f32x4 (&acc0)[NT
 
 // Recurrent-half worker job: NT adjacent tiles of  h . W_h + b  written as pre-activation partial sums in tile order
 // [tile][MT*16 rows][16 cols] (the consumer is gt_lstm_x_kernel).  One pass over the activations for all NT tiles.
-template <int NW, int KPW, int NT, bool BF16 = false>
+template <int NW, int KPW, int NT, bool BF16 = false, bool ONE_M = false>
 __device__ __forceinline__ void gt_lean_partial(const LeanPartialArgs& A, const int tile0, const int ntile, const int mchunk, float* lds) {
-    constexpr int NE = (NT * 512 + NW * 64 - 1) / (NW * 64);
-    const int m0 = mchunk * 32;
+    // ONE_M: `mchunk` is a 16-row M-tile and the job covers those 16 rows only (half the state pull; for launches with
+    // spare CUs, where two lighter workgroups per tile finish sooner than one)
+    constexpr int ROWS = ONE_M ? 16 : 32;
+    constexpr int NE = (NT * ROWS * 16 + NW * 64 - 1) / (NW * 64);
+    const int m0 = mchunk * ROWS;
     float bias_v[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = threadIdx.x + i * NW * 64;
-        const int j = e >> 9;
-        bias_v[i] = (e < NT * 512 && j < ntile) ? A.bias[(tile0 + j) * 16 + (e & 15)] : 0.f;
+        const int j = e / (ROWS * 16);
+        bias_v[i] = (e < NT * ROWS * 16 && j < ntile) ? A.bias[(tile0 + j) * 16 + (e & 15)] : 0.f;
     }
     f32x4 acc0[NT], acc1[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    if (BF16) gt_lean_core_bf16<NW, KPW, NT, true>(A.wp, tile0, ntile, LeanX{A.x, A.x, 2 * NW * KPW}, A.MT, mchunk, NW * KPW, acc0, acc1);
-    else gt_lean_core<NW, KPW, NT, true>(A.wp, tile0, ntile, LeanX{A.x, A.x, NW * KPW}, A.MT, mchunk, acc0, acc1);
+    if (BF16) gt_lean_core_bf16<NW, KPW, NT, true, ONE_M>(A.wp, tile0, ntile, LeanX{A.x, A.x, 2 * NW * KPW}, A.MT, mchunk, NW * KPW, acc0, acc1);
+    else gt_lean_core<NW, KPW, NT, true, ONE_M>(A.wp, tile0, ntile, LeanX{A.x, A.x, NW * KPW}, A.MT, mchunk, acc0, acc1);
     gt_lean_spill<NW, NT>(lds, acc0, acc1);
     __syncthreads();
     const float (*part)[NW][32][17] = reinterpret_cast<const float (*)[NW][32][17]>(lds);
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = threadIdx.x + i * NW * 64;
-        const int j = e >> 9, row = (e >> 4) & 31, col = e & 15;
-        if (e < NT * 512 && j < ntile && m0 + row < A.MT * 16) {
+        const int j = e / (ROWS * 16), row = (e >> 4) & (ROWS - 1), col = e & 15;
+        if (e < NT * ROWS * 16 && j < ntile && m0 + row < A.MT * 16) {
             float z = bias_v[i];
 #pragma unroll
             for (int w = 0; w < NW; ++w) z += part[j][w][row][col];

@@ -175,13 +175,22 @@ __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanParti
     __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, CT>::kFloats];
     const int mchunks = (P.M + 31) / 32;
     if ((int)blockIdx.x >= n_main) {
-        const int tile = co_begin + ((int)blockIdx.x - n_main) * CT;
-        for (int mc = 0; mc < mchunks; ++mc) {
-            gt_lean_partial<NW, BF16 ? 4 : 8, CT, BF16>(co, tile, min(CT, co_end - tile), mc, lds);
-            if (mc + 1 < mchunks) __syncthreads();
+        const bool st = P.dbg && (int)blockIdx.x == n_main && threadIdx.x == 0;
+        if (st) P.dbg[4] = __builtin_amdgcn_s_memrealtime();
+        if (CT == 1) {          // one workgroup per (tile, 16-row M-tile): lighter jobs that end with the projection's own
+            const int w = (int)blockIdx.x - n_main;
+            gt_lean_partial<NW, BF16 ? 4 : 8, 1, BF16, true>(co, co_begin + w / P.MT, 1, w % P.MT, lds);
+        } else {
+            const int tile = co_begin + ((int)blockIdx.x - n_main) * CT;
+            for (int mc = 0; mc < mchunks; ++mc) {
+                gt_lean_partial<NW, BF16 ? 4 : 8, CT, BF16>(co, tile, min(CT, co_end - tile), mc, lds);
+                if (mc + 1 < mchunks) __syncthreads();
+            }
         }
+        if (st) P.dbg[5] = __builtin_amdgcn_s_memrealtime();
         return;
     }
+    GT_STAMP(P.dbg, 0);
     // main tiles: one workgroup per (tile, 16-row M-tile) -- 27 tiles would leave most CUs idle, so the rows are split
     const int tile = (int)blockIdx.x / P.MT, mt = (int)blockIdx.x % P.MT;
     const int row = (threadIdx.x >> 4) & 15, col = threadIdx.x & 15, half = threadIdx.x >> 8;   // waves 0-3 / 4-7 reduce half the partials each
@@ -190,8 +199,10 @@ __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanParti
     f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
     if (BF16) gt_lean_core_bf16<NW, 5, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, 36, acc0, acc1);
     else gt_lean_core<NW, 9, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, acc0, acc1);
+    GT_STAMP(P.dbg, 1);
     gt_lean_spill<NW, 1>(lds, acc0, acc1);          // (rows 16..31 of the slab are unused zeros)
     __syncthreads();
+    GT_STAMP(P.dbg, 2);
     const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
     if (half == 0) {
         float v = bias;
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanParti
             else if (!P.out3 || gcol < P.n_valid2) P.out2[(size_t)grow * P.ldo2 + (gcol - P.n_split)] = v;
         }
     }
+    GT_STAMP(P.dbg, 3);
 }
 
 bool gt_proj_lean_supported(int nkb_main, int nkb_co) { return nkb_main == 72 && (nkb_co == 64 || nkb_co == 0); }
@@ -213,7 +225,7 @@ hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp
     const int nco = co_end > co_begin ? co_end - co_begin : 0;
     LeanPartialArgs co{co_wp, co_bias, co_x, co_out, m.MT};
     const int n_main = ntiles * m.MT;
-    const dim3 g2(n_main + (nco + 1) / 2), g1(n_main + nco);
+    const dim3 g2(n_main + (nco + 1) / 2), g1(n_main + nco * m.MT);
     if (tiles_per_worker == 2) {
         if (bf16) hipLaunchKernelGGL((gt_proj_lean_kernel<2, true>), g2, dim3(512), 0, stream, m, co, n_main, co_begin, co_end);
         else hipLaunchKernelGGL((gt_proj_lean_kernel<2, false>), g2, dim3(512), 0, stream, m, co, n_main, co_begin, co_end);

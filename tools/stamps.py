@@ -31,3 +31,7 @@ print("front raw (us since stamp0):", {i: round((f[i]-t0)/100.0, 2) for i in ran
 print("front -> lstm1 start gap (us):", (buf[16] - buf[7]) / 100.0, " lstm1 end -> lstm2 start:", (buf[32] - buf[19]) / 100.0)
 w = {i: round((f[i]-t0)/100.0, 2) for i in (8, 9, 10, 11) if f[i]}
 print("front workers (us since utterance-WG0 stamp0): first worker start/end", w.get(8), w.get(9), " last worker start/end", w.get(10), w.get(11))
+pj = [buf[40 + i] for i in range(6)]
+if pj[0]:
+    print("proj main WG0 (us since its entry): core done", (pj[1]-pj[0])/100.0, "after barrier", (pj[2]-pj[0])/100.0, "end", (pj[3]-pj[0])/100.0,
+          "| lstm2 end -> proj entry", (pj[0]-buf[35])/100.0, "| first worker entry/end", (pj[4]-pj[0])/100.0, (pj[5]-pj[0])/100.0)
