@@ -18,7 +18,7 @@
 
 #define BK 32
 
-template <int WAVES_M, int WAVES_N, int RM, int RN>
+template <int WAVES_M, int WAVES_N, int RM, int RN, bool C2D = false>
 __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
     constexpr int BM = WAVES_M * RM * 32;
     constexpr int BN = WAVES_N * RN * 32;
@@ -68,7 +68,17 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
             const int f = tid + i * 256;
             const int kk = k0 + (f & 7) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_ok[i] && kk < K) {
+            if (C2D) {                                           // 2-D taps, stride, NHWC input (ConvGemmArgs::conv2d)
+                if (a_ok[i] && kk < K) {
+                    const int tap = kk / A.Cin;
+                    const int c = kk - tap * A.Cin;
+                    const int ti = tap / A.kw, tj = tap - ti * A.kw;
+                    const int ho = a_t[i] / A.Wo, wo = a_t[i] - ho * A.Wo;
+                    const int hi = ho * A.stride + ti - A.pad_h, wi = wo * A.stride + tj - A.pad_w;
+                    if (hi >= 0 && hi < A.H && wi >= 0 && wi < A.W)
+                        v = *reinterpret_cast<const float4*>(A.x + (int64_t)a_b[i] * A.xb + ((int64_t)hi * A.W + wi) * A.Cin + c);
+                }
+            } else if (a_ok[i] && kk < K) {
                 const int tap = kk / A.Cin;
                 const int c = kk - tap * A.Cin;
                 const int ts = a_t[i] + tap - A.pad_before;
@@ -312,6 +322,12 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         } else {
             hipLaunchKernelGGL((gt_conv_gemm_bf16_kernel<1>), dim3((M + 63) / 64, nb), dim3(256), 0, stream, a);
         }
+        return hipGetLastError();
+    }
+    if (a.conv2d) {
+        if (a.N > 64) hipLaunchKernelGGL((gt_conv_gemm_kernel<2, 2, 1, 2, true>), dim3((M + 63) / 64, (a.N + 127) / 128), dim3(256), 0, stream, a);
+        else if (a.N > 32) hipLaunchKernelGGL((gt_conv_gemm_kernel<4, 1, 1, 2, true>), dim3((M + 127) / 128, 1), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((gt_conv_gemm_kernel<4, 1, 1, 1, true>), dim3((M + 127) / 128, 1), dim3(256), 0, stream, a);
         return hipGetLastError();
     }
     if (a.N > 96) {

@@ -573,6 +573,16 @@ int enqueue_gst(gsttaco_ctx* c, hipStream_t s, int B, int Tref1) {
         a.k = c->ref_conv[i].k; a.stride = c->ref_conv[i].stride;
         a.pad_h = same_pad_before(H, a.k, a.stride, &a.Ho);
         a.pad_w = same_pad_before(W, a.k, a.stride, &a.Wo);
+        if (a.Cin % 4 == 0 && a.Cin >= 16 && !g.mixed_precision) {
+            // implicit GEMM on the fp32 MFMA path (M = B*Ho*Wo rows, K = 9*Cin): the direct kernel's late layers have a
+            // few thousand threads with K = 576..1152 serial loads each (124 us for the last one)
+            ConvGemmArgs ga{};
+            ga.x = a.x; ga.xb = a.xb; ga.w = a.w; ga.scale = a.scale; ga.shift = a.shift;
+            ga.out = a.out; ga.ldo = a.Cout;
+            ga.B = B; ga.T = a.Ho * a.Wo; ga.Cin = a.Cin; ga.N = a.Cout; ga.taps = a.k * a.k; ga.act = ACT_RELU;
+            ga.conv2d = 1; ga.H = H; ga.W = W; ga.Wo = a.Wo; ga.kw = a.k; ga.stride = a.stride; ga.pad_h = a.pad_h; ga.pad_w = a.pad_w;
+            HIPCHECK(c, gt_launch_conv_gemm(ga, s));
+        } else
         HIPCHECK(c, gt_launch_conv2d_bn_relu(a, s));
         x = a.out; H = a.Ho; W = a.Wo; xb = (int64_t)H * W * a.Cout; cur ^= 1;
     }

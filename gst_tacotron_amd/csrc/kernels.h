@@ -147,6 +147,10 @@ struct ConvGemmArgs {
     float* out;             // [B*T, ldo]
     int64_t ldo;
     int B, T, Cin, N, taps, pad_before, act;
+    // 2-D mode (GST reference encoder, GST.py:23-31): rows are (b, ho, wo) with T = Ho*Wo, k = (i*kw + j)*Cin + c reads
+    // x[b][ho*stride + i - pad_h][wo*stride + j - pad_w][c] of an NHWC input with batch stride xb floats; taps = kh*kw.
+    int conv2d, H, W, Wo, kw, stride, pad_h, pad_w;
+    int64_t xb;
 };
 
 hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
