@@ -1366,7 +1366,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         }
         const HostTensor &pk = T(c, "decoder.projection.kernel"), &pb = T(c, "decoder.projection.bias");
         if ((rc = pack_linear(c, &c->proj, {{pk.data.data(), (int)pk.shape[0]}}, c->proj_out, pb.data.data(), 0))) return rc;
-        if (c->fuse_prenet0 && !g.mixed_precision) {
+        if (c->fuse_prenet0) {
             // The projection and the first prenet Dense are both linear and nothing sits between them at inference
             // (Taco2.py:186 feeds decodings[:, -1] straight into the prenet): frame.W0 + b0 = [h2|ctx].(Wp_last.W0) +
             // (bp_last.W0 + b0), Wp_last = the projection columns of the last of the r frames.  The fused columns ride in the
@@ -1810,6 +1810,17 @@ uint32_t gsttaco_crc32c(const void* data, size_t n, uint32_t crc) {
     }
     while (n--) c = tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
     return c ^ 0xffffffffu;
+}
+
+int gsttaco_decode_plan(const gsttaco_ctx* c, int Tv, int32_t plan[3]) {
+    if (!c || !plan || Tv < 1) return GSTTACO_E_INVALID;
+    const gsttaco_config& g = c->cfg;
+    const bool fused = c->fused_front && g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(g.mel_dim, c->P0, c->P1, c->att, Tv);
+    const bool split = fused && c->split_rec;
+    plan[0] = fused ? 1 : 0;
+    plan[1] = (split && c->proj_z.wp != nullptr) ? 1 : 0;
+    plan[2] = (split && c->lean && c->keep_x_weights && gt_lstm_x_supported(c->lstm_x[0].nkb) && gt_lstm_x_supported(c->lstm_x[1].nkb)) ? 1 : 0;
+    return 0;
 }
 
 int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int which, int B) {

@@ -293,6 +293,14 @@ class GST_Tacotron:
         return path
 
     # ------------------------------------------------------------------ per-phase entry points (tests / profiling)
+    def decode_plan(self, Tv):
+        """(fused_front, fused_prenet0, lean) -- which variant of the decode step a Tv-token batch runs on
+        (``gsttaco_decode_plan``).  The mixed-precision parity oracle needs ``fused_prenet0``."""
+        self._require_ready()
+        plan = (ctypes.c_int32 * 3)()
+        self.ctx.check(self.ctx.lib.gsttaco_decode_plan(self.ctx.handle, int(Tv), plan))
+        return bool(plan[0]), bool(plan[1]), bool(plan[2])
+
     def encode(self, tokens, token_lengths=None):
         self._require_ready()
         tok = self._dev(tokens, torch.int32)

