@@ -81,10 +81,14 @@ struct gsttaco_ctx {
     float* d_emb = nullptr;
     std::vector<ConvLayer> enc_conv, post_conv;
     PackedLinear bilstm[2];
-    // lean encoder BiLSTM (fp32): input halves of both directions hoisted into one GEMM (columns in tile order), recurrent packs
-    PackedLinear bilstm_h[2];
-    float *enc_xw = nullptr, *enc_xb = nullptr;     // [C, 2*4H], [2*4H]
-    float *w_encz = nullptr, *w_ehb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    // lean BiLSTMs (fp32; encoder and vocoder): input halves of both directions hoisted into one GEMM (columns in tile
+    // order), recurrent-only packs, hoisted-GEMM output and ping-pong blocked state in the workspace
+    struct LeanBiLstm {
+        PackedLinear h[2];
+        float *xw = nullptr, *xb = nullptr;         // [C, 2*4H], [2*4H]
+        float *z = nullptr, *hb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        int H = 0, C = 0;
+    } enc_lean, voc_lean;
     struct { float *w, *scale, *shift; int k, cin, cout, stride; } ref_conv[GSTTACO_MAX_LAYERS]{};
     float *gru_w = nullptr, *gru_u = nullptr, *gru_b = nullptr, *dense_w = nullptr, *dense_b = nullptr;
     float *mq_w = nullptr, *mq_b = nullptr, *v_tok = nullptr, *ln_g = nullptr, *ln_b = nullptr;
@@ -493,6 +497,66 @@ int record_event(gsttaco_ctx* c, hipEvent_t ev, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ lean BiLSTM
+// x_t . W_x + b of both directions for all time steps in one GEMM, output columns already in the recurrent kernel's tile
+// order (direction d, tile, gate*4 + unit%4), and recurrent-only packs for gt_bilstm_lean_kernel.
+int build_lean_bilstm(gsttaco_ctx* c, gsttaco_ctx::LeanBiLstm* L, const std::string& prefix, int H) {
+    if (!c->lean || c->cfg.mixed_precision || H % 16 || !gt_bilstm_lean_supported(H / 16)) return 0;
+    const int C = (int)T(c, prefix + ".fwd.kernel").shape[0];
+    std::vector<float> xw((size_t)C * 8 * H), xb((size_t)8 * H);
+    int d = 0, rc = 0;
+    for (const char* dir : {"fwd", "bwd"}) {
+        const std::string p = prefix + "." + dir;
+        const HostTensor &k = T(c, p + ".kernel"), &u = T(c, p + ".recurrent_kernel"), &b = T(c, p + ".bias");
+        for (int tile = 0; tile < H / 4; ++tile)
+            for (int cl = 0; cl < 16; ++cl) {
+                const int src = (cl >> 2) * H + tile * 4 + (cl & 3), dst = d * 4 * H + tile * 16 + cl;
+                xb[dst] = b.data[src];
+                for (int kk = 0; kk < C; ++kk) xw[(size_t)kk * 8 * H + dst] = k.data[(size_t)kk * 4 * H + src];
+            }
+        if ((rc = pack_linear(c, &L->h[d], {{u.data.data(), (int)u.shape[0]}}, 4 * H, nullptr, H, false))) return rc;
+        ++d;
+    }
+    if ((rc = upload(c, &L->xw, xw.data(), xw.size()))) return rc;
+    if ((rc = upload(c, &L->xb, xb.data(), xb.size()))) return rc;
+    L->H = H; L->C = C;
+    return 0;
+}
+
+int alloc_lean_bilstm(gsttaco_ctx* c, gsttaco_ctx::LeanBiLstm* L, size_t B, size_t Tmax) {
+    if (!L->xw) return 0;
+    int rc = 0;
+    if ((rc = dev_alloc(c, (void**)&L->z, B * Tmax * 8 * L->H * sizeof(float)))) return rc;
+    for (int d = 0; d < 2; ++d)
+        for (int q = 0; q < 2; ++q)
+            if ((rc = dev_alloc(c, (void**)&L->hb[d][q], ((B + 15) / 16) * 16 * L->H * sizeof(float)))) return rc;
+    return 0;
+}
+
+// x: [B*T, C] rows; cstate: [2, B, H] (zeroed by the caller); out: [B, T, 2H]
+int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBiLstm& L, const float* x, int B, int Tn, float* cstate,
+                        float* out, const int32_t* row_len) {
+    const int H = L.H, EO = 2 * H, MT = (B + 15) / 16;
+    ConvGemmArgs a{};
+    a.x = x; a.w = L.xw; a.shift = L.xb;
+    a.out = L.z; a.ldo = 8 * H;
+    a.B = B; a.T = Tn; a.Cin = L.C; a.N = 8 * H; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
+    HIPCHECK(c, launch_conv(c, a, s));
+    for (int d = 0; d < 2; ++d) HIPCHECK(c, gt_launch_zero(L.hb[d][1], (size_t)MT * 16 * H, s));
+    for (int t = 0; t < Tn; ++t) {
+        BiLstmArgs k{};
+        for (int d = 0; d < 2; ++d) {
+            const int tt = d == 0 ? t : Tn - 1 - t;
+            k.d[d] = BiLstmDir{L.h[d].wp, L.hb[d][(t & 1) ^ 1], L.hb[d][t & 1], cstate + (size_t)d * B * H,
+                               L.z + (size_t)tt * 8 * H + (size_t)d * 4 * H, out + (size_t)tt * EO + d * H, tt};
+        }
+        k.row_len = row_len; k.ldz = (int64_t)Tn * 8 * H; k.ldo = (int64_t)Tn * EO;
+        k.M = B; k.MT = MT; k.H = H;
+        HIPCHECK(c, gt_launch_bilstm_lean(k, s));
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ enqueue
 int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked) {
     const int32_t* tlen = masked ? c->w_tok_len : nullptr;      // masked-mode extension
@@ -515,28 +579,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked) {
     // BiLSTM: one launch per time step, both directions in grid.z; h is written straight into enc_out.
     const int H = g.enc_rnn, C = c->conv_c, EO = c->enc_out;
     HIPCHECK(c, gt_launch_zero(c->w_cenc, (size_t)2 * B * H, s));
-    if (c->enc_xw) {
-        // lean path (fp32): the input halves of every time step and both directions in one GEMM, then K = H per step
-        const int MT = (B + 15) / 16;
-        ConvGemmArgs a{};
-        a.x = x; a.w = c->enc_xw; a.shift = c->enc_xb;
-        a.out = c->w_encz; a.ldo = 8 * H;
-        a.B = B; a.T = Tv; a.Cin = C; a.N = 8 * H; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
-        HIPCHECK(c, launch_conv(c, a, s));
-        for (int d = 0; d < 2; ++d) HIPCHECK(c, gt_launch_zero(c->w_ehb[d][1], (size_t)MT * 16 * H, s));
-        for (int t = 0; t < Tv; ++t) {
-            BiLstmArgs k{};
-            for (int d = 0; d < 2; ++d) {
-                const int tt = d == 0 ? t : Tv - 1 - t;
-                k.d[d] = BiLstmDir{c->bilstm_h[d].wp, c->w_ehb[d][(t & 1) ^ 1], c->w_ehb[d][t & 1], c->w_cenc + (size_t)d * B * H,
-                                   c->w_encz + (size_t)tt * 8 * H + (size_t)d * 4 * H, c->w_enc + (size_t)tt * EO + d * H, tt};
-            }
-            k.row_len = tlen; k.ldz = (int64_t)Tv * 8 * H; k.ldo = (int64_t)Tv * EO;
-            k.M = B; k.MT = MT; k.H = H;
-            HIPCHECK(c, gt_launch_bilstm_lean(k, s));
-        }
-        return 0;
-    }
+    if (c->enc_lean.xw) return enqueue_lean_bilstm(c, s, c->enc_lean, x, B, Tv, c->w_cenc, c->w_enc, tlen);
     for (int t = 0; t < Tv; ++t) {
         SkinnyArgs a[2];
         for (int d = 0; d < 2; ++d) {
@@ -1018,6 +1061,10 @@ int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* m
     // Bidirectional LSTM over the Tf frames: one launch per time step, both directions in grid.z (:353-361)
     const int H = g.voc_rnn, EO = 2 * H;
     HIPCHECK(c, gt_launch_zero(c->w_vc, (size_t)2 * B * H, s));
+    if (c->voc_lean.xw) {
+        int rl = enqueue_lean_bilstm(c, s, c->voc_lean, x, B, Tf, c->w_vc, c->w_vrnn, nullptr);
+        if (rl) return rl;
+    } else
     for (int t = 0; t < Tf; ++t) {
         SkinnyArgs a[2];
         for (int d = 0; d < 2; ++d) {
@@ -1256,28 +1303,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
                                   4 * g.enc_rnn, b.data.data(), g.enc_rnn))) return rc;
             ++d;
         }
-        // lean path: x_t . W_x + b of both directions for all time steps in one GEMM, output columns already in the
-        // recurrent kernel's tile order (direction d, tile, gate*4 + unit%4), and recurrent-only packs for the step kernel
-        const int H = g.enc_rnn;
-        if (c->lean && !g.mixed_precision && H % 16 == 0 && gt_bilstm_lean_supported(H / 16)) {
-            const int C = (int)T(c, "encoder.bilstm.fwd.kernel").shape[0];
-            std::vector<float> xw((size_t)C * 8 * H), xb((size_t)8 * H);
-            d = 0;
-            for (const char* dir : {"fwd", "bwd"}) {
-                std::string p = std::string("encoder.bilstm.") + dir;
-                const HostTensor &k = T(c, p + ".kernel"), &u = T(c, p + ".recurrent_kernel"), &b = T(c, p + ".bias");
-                for (int tile = 0; tile < H / 4; ++tile)
-                    for (int cl = 0; cl < 16; ++cl) {
-                        const int src = (cl >> 2) * H + tile * 4 + (cl & 3), dst = d * 4 * H + tile * 16 + cl;
-                        xb[dst] = b.data[src];
-                        for (int kk = 0; kk < C; ++kk) xw[(size_t)kk * 8 * H + dst] = k.data[(size_t)kk * 4 * H + src];
-                    }
-                if ((rc = pack_linear(c, &c->bilstm_h[d], {{u.data.data(), (int)u.shape[0]}}, 4 * H, nullptr, H, false))) return rc;
-                ++d;
-            }
-            if ((rc = upload(c, &c->enc_xw, xw.data(), xw.size()))) return rc;
-            if ((rc = upload(c, &c->enc_xb, xb.data(), xb.size()))) return rc;
-        }
+        if ((rc = build_lean_bilstm(c, &c->enc_lean, "encoder.bilstm", g.enc_rnn))) return rc;
     }
     // ---- GST
     if (g.gst_use) {
@@ -1447,6 +1473,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
                                   4 * g.voc_rnn, b.data.data(), g.voc_rnn))) return rc;
             ++d;
         }
+        if ((rc = build_lean_bilstm(c, &c->voc_lean, "vocoder.bilstm", g.voc_rnn))) return rc;
         {   // final Dense: rows padded to a multiple of 4 columns so the GEMM can load 16 bytes per lane
             const HostTensor &k = T(c, "vocoder.dense.kernel"), &b = T(c, "vocoder.dense.bias");
             const int K = (int)k.shape[0], N = g.spec_dim, ldw = (N + 3) / 4 * 4;
@@ -1476,12 +1503,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         if ((rc = fa(&c->w_act[i], B * Tv * actc))) return rc;
     if ((rc = fa(&c->w_enc, B * Tv * c->enc_out))) return rc;
     if ((rc = fa(&c->w_cenc, 2 * B * g.enc_rnn))) return rc;
-    if (c->enc_xw) {
-        if ((rc = fa(&c->w_encz, (size_t)B * Tv * 8 * g.enc_rnn))) return rc;
-        for (int d = 0; d < 2; ++d)
-            for (int q = 0; q < 2; ++q)
-                if ((rc = fa(&c->w_ehb[d][q], (size_t)((B + 15) / 16) * 16 * g.enc_rnn))) return rc;
-    }
+    if ((rc = alloc_lean_bilstm(c, &c->enc_lean, B, Tv))) return rc;
     if ((rc = fa(&c->w_z0, B * (size_t)c->P0))) return rc;
     c->zero_floats = ((B + 15) / 16 * 16) * std::max<size_t>({(size_t)mel, (size_t)g.enc_rnn, (size_t)c->H1, (size_t)c->H2,
                                                                (size_t)(g.voc_use ? g.voc_rnn : 0)});
@@ -1535,6 +1557,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         if ((rc = fa(&c->w_vz, B * Tf * 2 * g.highway_size))) return rc;
         if ((rc = fa(&c->w_vrnn, B * Tf * 2 * g.voc_rnn))) return rc;
         if ((rc = fa(&c->w_vc, 2 * B * g.voc_rnn))) return rc;
+        if ((rc = alloc_lean_bilstm(c, &c->voc_lean, B, Tf))) return rc;
         if ((rc = fa(&c->w_spec, B * Tf * g.spec_dim))) return rc;
     }
     HIPCHECK(c, gt_attn_init());
