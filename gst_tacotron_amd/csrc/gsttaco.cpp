@@ -1562,6 +1562,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     }
     HIPCHECK(c, gt_attn_init());
     HIPCHECK(c, gt_dec_front_init());
+    HIPCHECK(c, gt_gst_init());
     HIPCHECK(c, hipDeviceSynchronize());
     // host copies are no longer needed
     for (auto& t : c->tensors) std::vector<float>().swap(t.data);

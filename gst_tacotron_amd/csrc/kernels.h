@@ -254,6 +254,7 @@ struct GstTailArgs {
     int B, T2, gru_in, u, D, A, ntok, heads, stride_prod;
 };
 hipError_t gt_launch_gst_tail(const GstTailArgs& a, hipStream_t stream);
+hipError_t gt_gst_init();      // opt in to >64 KiB dynamic LDS; call once outside stream capture
 
 // ---------------------------------------------------------------- audio.hip
 struct AudioFrontArgs {
