@@ -325,7 +325,7 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         return hipGetLastError();
     }
     if (a.conv2d) {
-        if (a.N > 64) hipLaunchKernelGGL((gt_conv_gemm_kernel<2, 2, 1, 2, true>), dim3((M + 63) / 64, (a.N + 127) / 128), dim3(256), 0, stream, a);
+        if (a.N > 64) hipLaunchKernelGGL((gt_conv_gemm_kernel<1, 4, 1, 1, true>), dim3((M + 31) / 32, (a.N + 127) / 128), dim3(256), 0, stream, a);
         else if (a.N > 32) hipLaunchKernelGGL((gt_conv_gemm_kernel<4, 1, 1, 2, true>), dim3((M + 127) / 128, 1), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((gt_conv_gemm_kernel<4, 1, 1, 1, true>), dim3((M + 127) / 128, 1), dim3(256), 0, stream, a);
         return hipGetLastError();
@@ -335,6 +335,10 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         if (wg128 >= 256) {
             dim3 grid((M + 127) / 128, (a.N + 127) / 128);
             hipLaunchKernelGGL((gt_conv_gemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, stream, a);
+        } else if (((M + 63) / 64) * ((a.N + 127) / 128) <= 256) {
+            // few rows (the 4096-row encoder convs): 32 x 128 tiles give two workgroups per CU instead of one wave per SIMD
+            dim3 grid((M + 31) / 32, (a.N + 127) / 128);
+            hipLaunchKernelGGL((gt_conv_gemm_kernel<1, 4, 1, 1>), grid, dim3(256), 0, stream, a);
         } else {
             dim3 grid((M + 63) / 64, (a.N + 127) / 128);
             hipLaunchKernelGGL((gt_conv_gemm_kernel<2, 2, 1, 2>), grid, dim3(256), 0, stream, a);
