@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight", "gsttaco_finalize_weights",
     "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder", "gsttaco_inference_step",
     "gsttaco_mel_frontend", "gsttaco_mel_basis", "gsttaco_griffin_lim", "gsttaco_crc32c",
-    "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_lstm_launch_bytes", "gsttaco_debug_stamps", "gsttaco_decode_plan",
+    "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_lstm_launch_bytes", "gsttaco_debug_stamps", "gsttaco_decode_plan", "gsttaco_debug_randomness",
 )
 
 _I32A = ctypes.c_int32 * MAX_LAYERS
@@ -109,6 +109,8 @@ def load_library(path=None):
     lib.gsttaco_debug_stamps.restype = ctypes.c_int
     lib.gsttaco_decode_plan.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_int32)]
     lib.gsttaco_decode_plan.restype = ctypes.c_int
+    lib.gsttaco_debug_randomness.argtypes = [vp, vp, vp, i32, i32, i32]
+    lib.gsttaco_debug_randomness.restype = ctypes.c_int
     for fn in ("gsttaco_create", "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight",
                "gsttaco_finalize_weights", "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder",
                "gsttaco_inference_step", "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_mel_frontend",

@@ -275,8 +275,8 @@ __global__ __launch_bounds__(256) void gt_rng_fill_kernel(const uint64_t* seed_p
             const int64_t e = i - (int64_t)t * per_step;
             const bool second = e >= (int64_t)B * P0;
             const uint32_t idx = (uint32_t)(second ? e - (int64_t)B * P0 : e);         // b * P + column
-            const Philox4 ph = gt_philox(seed, idx, (uint32_t)t, 0u, second ? 0x1001u : 0x1000u);
-            masks[i] = (gt_u01(ph.x) > drop_rate) ? 1.f : 0.f;
+            const uint32_t P = (uint32_t)(second ? P1 : P0);
+            masks[i] = gt_drop_keep(seed, (uint32_t)t, second ? 1u : 0u, idx / P, idx % P, P, drop_rate);
         } else {
             const int64_t j = i - nmask;
             const int t = (int)(j / ((int64_t)B * Tv));

@@ -45,13 +45,17 @@ __device__ __forceinline__ GemvPlan make_plan(int K, int N, int tid) {
 // rows, all inside K) -- true for the prenet-1 and query layers at the reference's dimensions -- so the loads carry no
 // predicates: with them each load costs ~30 instructions of exec-mask bookkeeping, ~1 us over the prologue's 24 loads.
 template <int MAXR, bool EXACT = false>
-__device__ __forceinline__ void gemv_load(const float* __restrict__ W, int K, int N, const GemvPlan& p, int i0, float4 (&r)[MAXR]) {
+__device__ __forceinline__ void gemv_load(const float* __restrict__ W, int K, int N, const GemvPlan& p, int i0, float4 (&r)[MAXR],
+                                          uint32_t bits = 0xFFFFFFFFu) {
     if (EXACT) {
-        // uniform (SGPR) base per row + ONE per-lane 32-bit byte offset: no per-load address registers
+        // uniform (SGPR) base per row + ONE per-lane 32-bit byte offset: no per-load address registers.
+        // `bits`: bit i clear <=> row i0 + i multiplies an exact zero (dropped by the prenet's dropout) and is not requested
         const uint32_t off = (uint32_t)(((p.kp * p.rows + i0) * N + p.cg * 4) * 4);
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i)
-            r[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(W) + (size_t)i * N * 4 + off);
+        for (int i = 0; i < MAXR; ++i) {
+            r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((bits >> i) & 1u) r[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(W) + (size_t)i * N * 4 + off);
+        }
         return;
     }
 #pragma unroll
@@ -208,9 +212,23 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     // 8-row weight blocks is what fits).  Without Z0 (step 0) prenet 0 comes first and the rows ride along early.
     float4 v0[NP];
     float4 r0a[8], r1a[8], r1b[8], r2a[8];
+    // Throughput mode at rate 0.5 (keep_hash): the keep decisions are words of a counter hash of the seed (gt_keep_word), so
+    // each wave knows after one scalar load and ~25 scalar instructions which of ITS weight rows meet an exact zero: wave w
+    // owns prenet-1 rows 16w..16w+15 (mask 0) and query rows 16w..16w+15 (mask 1, 8 per lane half).
+    uint64_t kseed = 0;
+    uint32_t rb1 = 0xFFFFu, rbq = 0xFFu;
+    if (P.drop_rate > 0.f && (!P.mask0 || !P.mask1)) {
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kseed) : "s"(P.seed_ptr) : "memory");
+        if (EXACT && Z0 && P.keep_hash) {
+            const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            rb1 = (gt_keep_word(kseed, P.rng_step, 0u, (uint32_t)b, wave >> 1) >> ((wave & 1u) * 16u)) & 0xFFFFu;
+            const uint32_t q16 = (gt_keep_word(kseed, P.rng_step, 1u, (uint32_t)b, wave >> 1) >> ((wave & 1u) * 16u)) & 0xFFFFu;
+            rbq = (q16 >> ((lane >> 5) * 8)) & 0xFFu;
+        }
+    }
     if (Z0) {
-        gemv_load<8, EXACT>(P.w1, P0, P1, g1, 0, r1a);
-        gemv_load<8, EXACT>(P.w1, P0, P1, g1, 8, r1b);
+        gemv_load<8, EXACT>(P.w1, P0, P1, g1, 0, r1a, rb1);
+        gemv_load<8, EXACT>(P.w1, P0, P1, g1, 8, r1b, rb1 >> 8);
     } else {
         load_rows(v0, 0);                               // processed-memory rows of chunk 0 (64 KiB at 128x128)
         gemv_load<8>(P.w0, mel, P0, g0, 0, r0a);
@@ -219,8 +237,8 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
 
     // dropout keep-scales and sigmoid noise (Philox, ~100 VALU ops each) while the first loads are in flight
     if (P.drop_rate > 0.f) {
-        if (!P.mask0 && tid < P0) t_k0 = (gt_u01(gt_philox(*P.seed_ptr, (uint32_t)(b * P0 + tid), P.rng_step, 0u, 0x1000u).x) > P.drop_rate) ? 1.f : 0.f;
-        if (!P.mask1 && tid < P1) t_k1 = (gt_u01(gt_philox(*P.seed_ptr, (uint32_t)(b * P1 + tid), P.rng_step, 0u, 0x1001u).x) > P.drop_rate) ? 1.f : 0.f;
+        if (!P.mask0 && tid < P0) t_k0 = gt_drop_keep(kseed, P.rng_step, 0u, (uint32_t)b, (uint32_t)tid, (uint32_t)P0, P.drop_rate);
+        if (!P.mask1 && tid < P1) t_k1 = gt_drop_keep(kseed, P.rng_step, 1u, (uint32_t)b, (uint32_t)tid, (uint32_t)P1, P.drop_rate);
         t_k0 *= P.drop_scale; t_k1 *= P.drop_scale;
     }
     if (P.sigmoid_noise > 0.f && !P.noise && tid < Tv) {
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         float keep = 1.f;
         if (P.drop_rate > 0.f) {
             keep = P.mask0 ? P.mask0[(size_t)b * P0 + c]
-                           : ((gt_u01(gt_philox(*P.seed_ptr, (uint32_t)(b * P0 + c), P.rng_step, 0u, 0x1000u).x) > P.drop_rate) ? 1.f : 0.f);
+                           : gt_drop_keep(kseed, P.rng_step, 0u, (uint32_t)b, (uint32_t)c, (uint32_t)P0, P.drop_rate);
             keep *= P.drop_scale;
         }
         sk0[c] = keep;
@@ -246,7 +264,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         float keep = 1.f;
         if (P.drop_rate > 0.f) {
             keep = P.mask1 ? P.mask1[(size_t)b * P1 + c]
-                           : ((gt_u01(gt_philox(*P.seed_ptr, (uint32_t)(b * P1 + c), P.rng_step, 0u, 0x1001u).x) > P.drop_rate) ? 1.f : 0.f);
+                           : gt_drop_keep(kseed, P.rng_step, 1u, (uint32_t)b, (uint32_t)c, (uint32_t)P1, P.drop_rate);
             keep *= P.drop_scale;
         }
         sk1[c] = keep;
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     }
     if (Z0) {
         asm volatile("" ::: "memory");                    // W1 is consumed: its registers take the query weights and the rows
-        gemv_load<8, EXACT>(P.wq, P1, A, g2, 0, r2a);
+        gemv_load<8, EXACT>(P.wq, P1, A, g2, 0, r2a, rbq);
         load_rows(v0, 0);
     }
     __syncthreads();

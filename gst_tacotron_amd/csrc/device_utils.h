@@ -52,9 +52,36 @@ __device__ __forceinline__ float gt_normal(uint32_t r0, uint32_t r1) {   // Box-
     return sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530718f * u2);
 }
 
+// Prenet dropout keep decisions in throughput mode (the reference draws them unseeded and always on, Taco2.py:283).
+// At the reference's rate 0.5 a decision is ONE bit, and 32 of them -- columns [32 w, 32 w + 32) of one row of one layer at
+// one step -- are one word of a counter hash of the seed: cheap enough for the front kernel to know, a few scalar
+// instructions after it starts, which rows of the next Dense's weights will multiply an exact zero, BEFORE it requests
+// them (dec_front.hip: the dropped half of its 384 KB weight pull is never loaded).  Other rates: Philox, one call per
+// decision, no such shortcut.  Every consumer (front kernel, general prenet kernels, gt_rng_fill_kernel) goes through
+// gt_drop_keep so they all see the same masks.
+__device__ __forceinline__ uint32_t gt_mix32(uint32_t h) {      // murmur3 finaliser
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t gt_keep_word(uint64_t seed, uint32_t step, uint32_t layer, uint32_t row, uint32_t word) {
+    uint32_t h = gt_mix32((uint32_t)seed ^ (step * 0x9E3779B1u + layer));
+    h = gt_mix32(h ^ (uint32_t)(seed >> 32) ^ (row * 0x85EBCA77u));
+    return gt_mix32(h ^ (word * 0xC2B2AE3Du + 0x27D4EB2Fu));
+}
+__device__ __forceinline__ bool gt_keep_is_hashed(float rate) { return rate == 0.5f; }
+// keep (1) / drop (0) of column `col` of row `row` of prenet layer `layer` (0 / 1) at decode step `step`
+__device__ __forceinline__ float gt_drop_keep(uint64_t seed, uint32_t step, uint32_t layer, uint32_t row, uint32_t col, uint32_t ncols,
+                                             float rate);
+
 // stream ids for the Philox counter's 4th word
 #define GT_RNG_PRENET0 0x1000u
 #define GT_RNG_NOISE   0x2000u
+
+__device__ __forceinline__ float gt_drop_keep(uint64_t seed, uint32_t step, uint32_t layer, uint32_t row, uint32_t col, uint32_t ncols,
+                                             float rate) {
+    if (gt_keep_is_hashed(rate)) return (float)((gt_keep_word(seed, step, layer, row, col >> 5) >> (col & 31)) & 1u);
+    return (gt_u01(gt_philox(seed, row * ncols + col, step, 0u, GT_RNG_PRENET0 + layer).x) > rate) ? 1.f : 0.f;
+}
 
 // diagnostic: phase stamp (constant 100 MHz counter) written by thread 0 of block 0 when dbg != NULL
 #define GT_STAMP(dbg, slot)                                                                    \

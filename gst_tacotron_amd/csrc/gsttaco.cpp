@@ -100,6 +100,7 @@ struct gsttaco_ctx {
     int co_tiles = 64;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
+    bool keep_hash = true;       // GSTTACO_KEEP_HASH=0: the front kernel reads the generated masks from HBM like injected ones
     bool lean = true;            // lean_body.h kernels for the decode shapes they cover (GSTTACO_LEAN=0: general kernels only)
 
     float *pw0 = nullptr, *pb0 = nullptr, *pw1 = nullptr, *pb1 = nullptr, *pwq = nullptr, *pbq = nullptr;  // plain layouts (fused front)
@@ -684,6 +685,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     const size_t mask_step = (size_t)B * (P0 + P1);
     // throughput mode: the whole decode's dropout masks and sigmoid noise are generated up front (same Philox streams the
     // step kernels would draw) into the buffers injected tensors use, so no step spends time on random numbers
+    const bool injected_mask = has_mask;
     {
         float* fm = (!has_mask && g.prenet_rate > 0.f) ? c->w_masks : nullptr;
         float* fn = (!has_noise && g.sigmoid_noise > 0.f && g.att_type != GSTTACO_ATT_LSA) ? c->w_noise : nullptr;
@@ -727,6 +729,12 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             f.z0 = (use_z0 && t > 0) ? c->w_z0 : nullptr;
             f.w0 = c->pw0; f.b0 = c->pb0; f.w1 = c->pw1; f.b1 = c->pb1; f.wq = c->pwq; f.bq = c->pbq;
             f.mask0 = mask0; f.mask1 = mask1;
+            if (!injected_mask && g.prenet_rate == 0.5f && c->keep_hash) {
+                // throughput mode: the kernel derives the same decisions gt_rng_fill_kernel wrote to w_masks from the seed
+                // itself (gt_keep_word) and, at the reference's sizes, skips the weight rows they zero
+                f.mask0 = f.mask1 = nullptr;
+                f.keep_hash = (P0 == 256 && P1 == 256 && att == 128) ? 1 : 0;
+            }
             f.drop_rate = g.prenet_rate; f.drop_scale = drop_scale; f.seed_ptr = c->w_seed; f.rng_step = (uint32_t)t;
             f.pm = c->w_pm; f.v = c->att_v; f.score_bias = c->att_sb;
             f.prev = t == 0 ? nullptr : c->w_align + (size_t)(t - 1) * Tv; f.ldprev = (int64_t)steps * Tv;
@@ -1225,6 +1233,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     if (const char* e = getenv("GSTTACO_WORKER_TILES")) c->worker_tiles = atoi(e);
     if (const char* e = getenv("GSTTACO_CO_WORKER_TILES")) c->co_worker_tiles = atoi(e);
     if (const char* e = getenv("GSTTACO_LEAN")) c->lean = e[0] != '0';
+    if (const char* e = getenv("GSTTACO_KEEP_HASH")) c->keep_hash = e[0] != '0';
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);
@@ -1834,6 +1843,16 @@ uint32_t gsttaco_crc32c(const void* data, size_t n, uint32_t crc) {
     }
     while (n--) c = tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
     return c ^ 0xffffffffu;
+}
+
+int gsttaco_debug_randomness(gsttaco_ctx* c, float* host_masks, float* host_noise, int steps, int B, int Tv) {
+    if (!c || steps < 1 || B < 1 || Tv < 1 || steps > c->steps_max || B > c->cfg.max_batch || Tv > c->cfg.max_tokens)
+        return GSTTACO_E_INVALID;
+    HIPCHECK(c, hipDeviceSynchronize());
+    if (host_masks)
+        HIPCHECK(c, hipMemcpy(host_masks, c->w_masks, (size_t)steps * B * (c->P0 + c->P1) * 4, hipMemcpyDeviceToHost));
+    if (host_noise) HIPCHECK(c, hipMemcpy(host_noise, c->w_noise, (size_t)steps * B * Tv * 4, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int gsttaco_decode_plan(const gsttaco_ctx* c, int Tv, int32_t plan[3]) {

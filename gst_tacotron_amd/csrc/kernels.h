@@ -220,6 +220,8 @@ struct DecFrontArgs {
     int worker_tiles;               // tiles per worker job: 1, or 0/2 = pairs sharing one pass over the activations
     LeanPartialArgs lrec[2];        // the same two GEMMs for the lean body (fp32, K = 1024); used when lean_rec != 0
     int lean_rec;                   // 0: general body, 1: lean fp32, 2: lean bf16
+    int keep_hash;                  // throughput mode at dropout rate 0.5 and the reference's prenet / attention sizes: rows of
+                                    // the prenet-1 / query weights that the (hashed) keep decisions zero are not requested
 };
 bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv);
 hipError_t gt_dec_front_init();

@@ -230,8 +230,8 @@ __device__ __forceinline__ void gt_skinny_body(const SkinnyArgs& A, const int ti
                         if (A.mask) {
                             keep = A.mask[(size_t)grow * A.ldm + gcol];
                         } else {
-                            Philox4 p = gt_philox(*A.seed_ptr, (uint32_t)(grow * A.N + gcol), A.rng_step, 0u, A.rng_stream);
-                            keep = (gt_u01(p.x) > A.drop_rate) ? 1.f : 0.f;
+                            keep = gt_drop_keep(*A.seed_ptr, A.rng_step, A.rng_stream - GT_RNG_PRENET0, (uint32_t)grow, (uint32_t)gcol,
+                                                (uint32_t)A.N, A.drop_rate);
                         }
                         v = v * A.drop_scale * keep;      // tf.nn.dropout: x * scale * mask
                     }

@@ -301,6 +301,22 @@ class GST_Tacotron:
         self.ctx.check(self.ctx.lib.gsttaco_decode_plan(self.ctx.handle, int(Tv), plan))
         return bool(plan[0]), bool(plan[1]), bool(plan[2])
 
+    def debug_randomness(self, steps, B, Tv):
+        """(prenet_masks [steps, 2, B, P], attn_noise [steps, B, Tv]) the last decode of that shape used, as NumPy arrays in
+        the layout ``Inference_Step(prenet_masks=, attn_noise=)`` takes -- in throughput mode the tensors generated from the
+        seed (``gsttaco_debug_randomness``; test support)."""
+        import numpy as np
+        self._require_ready()
+        d = self.dims
+        P0, P1 = d.prenet[0], d.prenet[1]
+        if P0 != P1:
+            raise ValueError("debug_randomness returns a stacked mask tensor: equal prenet sizes only")
+        masks = np.empty((steps, B * (P0 + P1)), np.float32)
+        noise = np.empty((steps, B, Tv), np.float32)
+        self.ctx.check(self.ctx.lib.gsttaco_debug_randomness(self.ctx.handle, masks.ctypes.data_as(ctypes.c_void_p),
+                                                             noise.ctypes.data_as(ctypes.c_void_p), int(steps), int(B), int(Tv)))
+        return masks.reshape(steps, 2, B, P0), noise
+
     def encode(self, tokens, token_lengths=None):
         self._require_ready()
         tok = self._dev(tokens, torch.int32)

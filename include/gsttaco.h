@@ -232,6 +232,10 @@ int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
 /* Diagnostic (GSTTACO_STAMPS=1): 3 x 16 phase stamps (100 MHz ticks) of workgroup 0 of the fused front kernel
  * and the two decode LSTM kernels at the middle decode step of the last replay.  Synchronises the device. */
 int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
+/* Test support: the prenet keep-masks [steps][mask0 B*P0 | mask1 B*P1] (0/1) and SMA noise [steps][B][Tv] the LAST
+ * gsttaco_inference_step / gsttaco_decode of that shape used -- generated from the seed in throughput mode, or the
+ * injected tensors -- copied to HOST buffers (either may be NULL).  Synchronises the device. */
+int gsttaco_debug_randomness(gsttaco_ctx* ctx, float* host_masks, float* host_noise, int steps, int B, int Tv);
 /* Which variant of the decode step a (Tv)-token batch runs on (finalized context).  plan[0]: 1 = fused per-utterance
  * front kernel (prenet + query + attention), 0 = the four-kernel front end (LSA, or a shape the fused kernel does not
  * cover); plan[1]: 1 = prenet layer 0's pre-activations ride in the previous step's projection launch (a composed

@@ -201,6 +201,39 @@ def test_on_device_randomness_is_seeded():
     assert np.isfinite(a).all() and np.array_equal(a, b) and not np.array_equal(a, c)
 
 
+@pytest.mark.parametrize("att,rate", [("SMA", 0.5), ("BMA", 0.5), ("SMA", 0.25)])
+def test_throughput_mode_randomness_matches_oracle(att, rate, monkeypatch):
+    """Throughput mode (nothing injected): the prenet keep decisions and the SMA noise come from the seed on the device.  The
+    front kernel derives the decisions itself (a counter hash at rate 0.5, Philox otherwise) and -- at rate 0.5 and the
+    reference's sizes -- never requests the prenet-1 / query weight rows they zero.  The tensors it used are read back
+    (gsttaco_debug_randomness) and fed to the oracle: same mels, and the same result with the row skipping switched off."""
+    import torch
+    from oracle import oracle_np
+    B, Tv, Tref, steps = 3, 24, 70, 9
+    hp, w, tokens, tl, mels, ml, _, _ = _full_case(B, Tv, Tref, steps, seed=31, att=att, rate=rate)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GSTTACO_KEEP_HASH", flag)
+        m = _model(hp, w, B, Tv, Tref + 1)
+        mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, seed=1234, steps=steps)
+        torch.cuda.synchronize()
+        masks, noise = m.debug_randomness(steps, B, Tv)
+        outs.append((mel.cpu().numpy(), align.cpu().numpy(), masks, noise))
+    monkeypatch.delenv("GSTTACO_KEEP_HASH")
+    mel, align, masks, noise = outs[0]
+    assert set(np.unique(masks)) <= {0.0, 1.0} and abs(masks.mean() - (1.0 - rate)) < 0.03
+    from gst_tacotron_amd import hparams
+    if hparams.attention_sigmoid_noise(hp) > 0:             # SMA draws N(0,1) noise (Steps.py:212,220-221), BMA none
+        assert abs(noise.mean()) < 0.1 and abs(noise.std() - 1.0) < 0.1 and np.array_equal(noise, outs[1][3])
+    else:
+        noise = None
+    assert np.array_equal(masks, outs[1][2])
+    assert np.abs(mel - outs[1][0]).max() <= TOL and np.abs(align - outs[1][1]).max() <= TOL
+    ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
+    assert np.abs(mel - ref[0]).max() <= TOL
+    assert np.abs(align - ref[3]).max() <= TOL
+
+
 def test_full_size_batch_independence_and_invariants():
     """BASELINE configs[1] at full size (batch 32 x 128 tokens x 500 steps), too big for the oracle in seconds, through
     size-independent properties: (1) utterances are independent -- utterance b decoded inside the batch of 32 equals the
