@@ -91,6 +91,23 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
+def rocprof_avg_us(kernel_substr):
+    """Average duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary (tools/profile.sh), for
+    cross-reference with the live HIP-event figure (which includes ~2.5 us of event-node overhead); None if absent."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")))
+    if not files:
+        return None, None
+    try:
+        for r in csv.DictReader(open(files[-1])):
+            if kernel_substr in r["Name"]:
+                return float(r["AverageNs"]) * 1e-3, os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,6 +205,7 @@ def main():
         ms1, cnt1, bytes1 = prof[dom]
         achieved = (bytes1 / (ms1 * 1e-3)) / 1e9 if ms1 > 0 else 0.0
         traffic, traffic_src = pmc_traffic(KPMC[dom])
+        rp_us, rp_src = rocprof_avg_us(KPMC[dom])
         step_us = sum(v[0] for v in prof.values()) * 1e3
         step_bytes = sum(v[2] for v in prof.values())
         line = {
@@ -204,6 +222,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes1,
                          "avg_launch_us": ms1 * 1e3, "launches_timed": cnt1, "empty_event_bracket_us": bracket_ms * 1e3,
+                         "avg_launch_us_rocprofv3": rp_us, "rocprofv3_source": rp_src,
                          "decode_step": {"us": step_us, "algorithmic_bytes": step_bytes,
                                          "GB/s": step_bytes / step_us / 1e3 if step_us > 0 else 0.0,
                                          "kernels": {str(k): {"name": KNAMES[k], "avg_us": prof[k][0] * 1e3, "bytes": prof[k][2]}
