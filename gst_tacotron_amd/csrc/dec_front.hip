@@ -4,19 +4,24 @@
 //   score / SMA|BMA alignment / context          (Steps.py:126-166, 168-199, 215-229)
 // on the hoisted processed memory (Steps.py:123 is loop-invariant).
 //
-// Why one kernel: on MI355X a dependent kernel boundary costs ~1.5 us and a tiny kernel ~3-5 us of pure
+// Why one kernel: on MI355X a dependent kernel boundary costs ~2 us and a tiny kernel ~3-5 us of pure
 // latency; the four separate launches of v1 (prenet0, prenet1, query, attention) cost ~31 us per decoder
 // step.  Everything here is per-utterance, so one workgroup can run the whole chain with only
-// workgroup barriers in between.  The price is that each workgroup pulls the prenet/query weights
-// (475 KB fp32) from L2 itself; to hide that, EVERY weight load of prenet0/prenet1 and the utterance's
-// processed-memory rows are issued before the first dependent instruction (~25 x 16-byte loads in flight
-// per lane, 16 waves per CU), and the query weights are requested while prenet0 computes.
+// workgroup barriers in between.  The price is that each workgroup pulls the prenet / query weights and its
+// processed-memory rows (448 KB fp32) itself, at a CU's ~130 GB/s L1 fill rate -- a third of the chain.  So:
+//   * requests go out in NEED order (loads return in issue order): small operands, all of prenet 1's weights, and --
+//     once prenet 1 has consumed them and freed their registers -- the query weights and the memory rows;
+//   * prenet 0's pre-activations arrive from the previous step's projection launch (Z0; both layers are linear);
+//   * in throughput mode the dropout keep decisions are a counter hash of the seed (device_utils.h gt_keep_word), known a
+//     few scalar instructions after the kernel starts: weight rows that will meet an exact zero are never requested;
+//   * the prologue is branch-free and, where the GEMV plans divide evenly (EXACT), its loads are unpredicated
+//     SGPR-base + one-VGPR-offset loads (a predicated load costs ~30 instructions of exec-mask bookkeeping).
+// The other ~224 CUs of the launch run worker workgroups: recurrent halves of the LSTM gate GEMMs (see DecFrontArgs).
 //
 // GEMV mapping: lane = 4 consecutive output columns (one coalesced 16-byte load per k row), the K range
-// is split over the remaining lanes and reduced through LDS.  Attention mapping: L lanes per memory row,
-// each holding NP float4 pieces of the row in REGISTERS for both the score and the context pass (the
-// processed memory is read from L2 exactly once per step); row reduction by DPP/shuffle, context
-// reduction by shuffle across the wave's rows and LDS across waves.
+// is split over the remaining lanes and reduced through LDS.  Attention mapping: the utterance's processed memory is
+// staged once into a padded LDS tile, read row-wise for the scores (L lanes per row, shuffle reduction) and
+// column-wise for the context.
 #include "skinny_body.h"
 #include "lean_body.h"
 #include "../../include/gsttaco.h"
