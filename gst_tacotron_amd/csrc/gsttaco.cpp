@@ -838,7 +838,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             k.dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
             if (prof) { int rce = prof_begin(layer); if (rce) return rce; }
             if (split && c->lean && c->keep_x_weights && gt_lstm_x_supported(k.nkb)) {
-                LstmXArgs la{k.wp, k.seg[0].ptr, k.partial_in, k.c, k.h, nullptr, k.dbg, B, MT, H, 0};
+                LstmXArgs la{k.wp, k.seg[0].ptr, k.partial_in, k.c, k.h, nullptr, k.dbg, B, MT, H, 0, k.nkb};
                 HIPCHECK(c, gt_launch_lstm_x(la, k.nkb, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2, k.bf16 != 0, s));
             } else
             HIPCHECK(c, launch_skinny(c, EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));

@@ -84,6 +84,7 @@ struct LstmXArgs {
     const int32_t* row_len;     // masked-mode extension (A12) or NULL
     unsigned long long* dbg;
     int M, MT, H, t_index;
+    int nkb;                    // K / 16 (the bf16 variant's 32-k blocks need not fill NW x KPW)
 };
 bool gt_lstm_x_supported(int nkb);
 hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, bool bf16, hipStream_t stream);

@@ -68,8 +68,9 @@ template <int EPI, int TAG>
 static hipError_t launch_epi(const SkinnyArgs& a0, const SkinnyArgs* a1, int ntiles, hipStream_t stream) {
     dim3 grid(ntiles, (a0.M + 31) / 32, a1 ? 2 : 1);
     const SkinnyArgs& b = a1 ? *a1 : a0;
-    // K-split width: 8 waves when the K loop is long enough to feed them
-    if (a0.nkb >= 32) {
+    // K-split width: 8 waves when the K loop is long enough to feed them (24: the decode LSTM-1 input half, same split as
+    // its lean kernel so the two stay bitwise equal)
+    if (a0.nkb >= 24) {
         hipLaunchKernelGGL((gt_skinny_kernel<EPI, 8, TAG>), grid, dim3(512), 0, stream, a0, b);
     } else {
         hipLaunchKernelGGL((gt_skinny_kernel<EPI, 4, TAG>), grid, dim3(256), 0, stream, a0, b);
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
     }
     GT_STAMP(A.dbg, 0);
     f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (BF16) gt_lean_core_bf16<NW, KPW, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, 2 * NW * KPW}, MT, mchunk, NW * KPW, acc0, acc1);
+    if (BF16) gt_lean_core_bf16<NW, KPW, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, A.nkb}, MT, mchunk, (A.nkb + 1) >> 1, acc0, acc1);
     else gt_lean_core<NW, KPW, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, NW * KPW}, MT, mchunk, acc0, acc1);
     GT_STAMP(A.dbg, 1);
     gt_lean_spill<NW, 1>(lds, acc0, acc1);
@@ -153,8 +154,9 @@ template <int TAG>
 static void launch_lstm_x(const LstmXArgs& a, int nkb, bool bf16, hipStream_t stream) {
     const dim3 grid((a.H + 3) / 4, (a.M + 31) / 32);
     if (nkb == 24) {
-        if (bf16) hipLaunchKernelGGL((gt_lstm_x_kernel<4, 3, TAG, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((gt_lstm_x_kernel<4, 6, TAG, false>), grid, dim3(256), 0, stream, a);
+        // K = 384 on 8 waves x 3 k-blocks (4 x 6 left the reduce + gate epilogue to 256 threads: 2.4 -> 1.7 us in-kernel)
+        if (bf16) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 2, TAG, true>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((gt_lstm_x_kernel<8, 3, TAG, false>), grid, dim3(512), 0, stream, a);
     } else {
         if (bf16) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 4, TAG, true>), grid, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG, false>), grid, dim3(512), 0, stream, a);
