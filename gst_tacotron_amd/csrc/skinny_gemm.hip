@@ -238,7 +238,7 @@ hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp
     return hipGetLastError();
 }
 
-// Bidirectional LSTM time step on the hoisted input halves (see BiLstmArgs): K = H = 256 -> 4 waves x 4 k-blocks.
+// Bidirectional LSTM time step on the hoisted input halves (see BiLstmArgs): K = H = 256 -> 8 waves x 2 k-blocks.
 template <int NW, int KPW>
 __global__ __launch_bounds__(NW * 64) void gt_bilstm_lean_kernel(BiLstmArgs A) {
     __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 1>::kFloats];
@@ -287,6 +287,6 @@ bool gt_bilstm_lean_supported(int nkb_h) { return nkb_h == 16; }
 
 hipError_t gt_launch_bilstm_lean(const BiLstmArgs& a, hipStream_t stream) {
     const dim3 grid((a.H + 3) / 4, (a.M + 31) / 32, 2);
-    hipLaunchKernelGGL((gt_bilstm_lean_kernel<4, 4>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((gt_bilstm_lean_kernel<8, 2>), grid, dim3(512), 0, stream, a);
     return hipGetLastError();
 }
