@@ -149,6 +149,11 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.x;
     const int mel = P.mel, P0 = P.P0, P1 = P.P1, TvFull = P.Tv;
+    // the seed is requested first and waited for only where the keep decisions are derived (below), so its latency
+    // overlaps the address arithmetic and the small-operand requests
+    const bool need_seed = P.drop_rate > 0.f && (!P.mask0 || !P.mask1);
+    uint64_t kseed = 0;
+    if (need_seed) asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(kseed) : "s"(P.seed_ptr) : "memory");
     // masked mode (A12): only the first tok_len[b] memory positions exist for this utterance
     const int Tv = P.tok_len ? max(1, min(TvFull, P.tok_len[b])) : TvFull;
 
@@ -220,10 +225,9 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     // Throughput mode at rate 0.5 (keep_hash): the keep decisions are words of a counter hash of the seed (gt_keep_word), so
     // each wave knows after one scalar load and ~25 scalar instructions which of ITS weight rows meet an exact zero: wave w
     // owns prenet-1 rows 16w..16w+15 (mask 0) and query rows 16w..16w+15 (mask 1, 8 per lane half).
-    uint64_t kseed = 0;
     uint32_t rb1 = 0xFFFFu, rbq = 0xFFu;
-    if (P.drop_rate > 0.f && (!P.mask0 || !P.mask1)) {
-        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kseed) : "s"(P.seed_ptr) : "memory");
+    if (need_seed) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kseed) : : "memory");
         if (EXACT && Z0 && P.keep_hash) {
             const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             rb1 = (gt_keep_word(kseed, P.rng_step, 0u, (uint32_t)b, wave >> 1) >> ((wave & 1u) * 16u)) & 0xFFFFu;
