@@ -42,12 +42,30 @@ def shard_inputs(inputs, rank, world):
     return {k: (v[lo:hi] if v is not None else None) for k, v in inputs.items()}
 
 
-def gather_to_root(local, n_total=None, dst=0):
+class PendingGather:
+    """Handle of a gather started with ``gather_to_root(..., async_op=True)``: the collective runs on the backend's own
+    stream while the caller enqueues the next batch; ``result()`` makes the current stream wait for it and returns what the
+    synchronous call returns (the concatenated tensor on ``dst``, None elsewhere)."""
+
+    def __init__(self, work, bufs, sizes, send, local):
+        self._work, self._bufs, self._sizes, self._send, self._local = work, bufs, sizes, send, local
+
+    def result(self):
+        if self._work is None:
+            return self._local
+        self._work.wait()
+        if self._bufs is None:
+            return None
+        return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(self._bufs, self._sizes)], dim=0)
+
+
+def gather_to_root(local, n_total=None, dst=0, async_op=False):
     """Gather per-rank ``[B_local, ...]`` tensors to ``dst``; returns the concatenated tensor on ``dst``
     and None elsewhere.  Ragged shards (batch not divisible by world size) are padded to the largest
-    shard for the collective and trimmed after it."""
+    shard for the collective and trimmed after it.  ``async_op=True`` returns a ``PendingGather`` instead, so that the
+    next batch's kernels are enqueued behind this batch's compute, not behind its gather."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return local
+        return PendingGather(None, None, None, None, local) if async_op else local
     world, rank = dist.get_world_size(), dist.get_rank()
     if n_total is None:
         cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
@@ -61,6 +79,8 @@ def gather_to_root(local, n_total=None, dst=0):
         send = torch.cat([local, pad], dim=0)
     send = send.contiguous()
     bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    if async_op:
+        return PendingGather(dist.gather(send, bufs, dst=dst, async_op=True), bufs, sizes, send, local)
     dist.gather(send, bufs, dst=dst)
     if rank != dst:
         return None

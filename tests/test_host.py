@@ -170,11 +170,13 @@ assert inputs["none"] is None and inputs["tokens"].shape[0] == hi - lo
 local = inputs["tokens"] * 2.0                # stands in for the per-rank Inference_Step output
 out = gd.gather_to_root(local, n_total=n_total)
 out2 = gd.gather_to_root(local)               # size discovered with an all_reduce
+pend = gd.gather_to_root(local, n_total=n_total, async_op=True)     # next batch's work would be enqueued here
+out3 = pend.result()
 if rank == 0:
-    assert torch.equal(out, full * 2.0) and torch.equal(out2, full * 2.0)
+    assert torch.equal(out, full * 2.0) and torch.equal(out2, full * 2.0) and torch.equal(out3, full * 2.0)
     print("GLOO_OK")
 else:
-    assert out is None and out2 is None
+    assert out is None and out2 is None and out3 is None
 dist.barrier()
 dist.destroy_process_group()
 '''
