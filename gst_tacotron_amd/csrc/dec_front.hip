@@ -367,18 +367,17 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
             __syncthreads();
         }
         const int t = c * ROWS + row;
-        float s = 0.f;
+        f32x2 s2 = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int a0 = 4 * (li + L * j);
             const float4 m4 = *reinterpret_cast<const float4*>(tile + row * LD + a0);
             const float4 q4 = *reinterpret_cast<const float4*>(qs + a0);
             const float4 w4 = *reinterpret_cast<const float4*>(vs + a0);
-            s += w4.x * gt_tanh(q4.x + m4.x);
-            s += w4.y * gt_tanh(q4.y + m4.y);
-            s += w4.z * gt_tanh(q4.z + m4.z);
-            s += w4.w * gt_tanh(q4.w + m4.w);
+            s2 += f32x2{w4.x, w4.y} * gt_tanh2(f32x2{q4.x, q4.y} + f32x2{m4.x, m4.y});
+            s2 += f32x2{w4.z, w4.w} * gt_tanh2(f32x2{q4.z, q4.w} + f32x2{m4.z, m4.w});
         }
+        float s = s2.x + s2.y;
 #pragma unroll
         for (int d = 1; d < L; d <<= 1) s += __shfl_xor(s, d, 64);
         if (li == 0 && t < Tv) sc[t] = s + sbias;

@@ -18,6 +18,21 @@ __device__ __forceinline__ float gt_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// two at a time on the packed fp32 VALU ops (v_pk_mul / v_pk_add / v_pk_fma): the attention score pass is 16 K tanh per
+// utterance and issue-bound, and only the two transcendentals per element cannot be paired
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gt_tanh2(f32x2 x) {
+    const f32x2 y = x * 2.885390081777927f;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(y.x);
+    e.y = __builtin_amdgcn_exp2f(y.y);
+    e = e + 1.0f;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(e.x);
+    r.y = __builtin_amdgcn_rcpf(e.y);
+    return 1.0f - 2.0f * r;
+}
+
 __device__ __forceinline__ float gt_sigmoid(float x) {
     const float e = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);    // exp(-x)
     return __builtin_amdgcn_rcpf(1.0f + e);
