@@ -148,6 +148,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     }
     const int tid = threadIdx.x, lane = tid & 63;
     const int b = blockIdx.x;
+    GT_STAMP(P.dbg, 12);
     const int mel = P.mel, P0 = P.P0, P1 = P.P1, TvFull = P.Tv;
     // the seed is requested first and waited for only where the keep decisions are derived (below), so its latency
     // overlaps the address arithmetic and the small-operand requests
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     // Throughput mode at rate 0.5 (keep_hash): the keep decisions are words of a counter hash of the seed (gt_keep_word), so
     // each wave knows after one scalar load and ~25 scalar instructions which of ITS weight rows meet an exact zero: wave w
     // owns prenet-1 rows 16w..16w+15 (mask 0) and query rows 16w..16w+15 (mask 1, 8 per lane half).
+    GT_STAMP(P.dbg, 13);
     uint32_t rb1 = 0xFFFFu, rbq = 0xFFu;
     if (need_seed) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kseed) : : "memory");
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
             rbq = (q16 >> ((lane >> 5) * 8)) & 0xFFu;
         }
     }
+    GT_STAMP(P.dbg, 14);
     if (Z0) {
         gemv_load<8, EXACT>(P.w1, P0, P1, g1, 0, r1a, rb1);
         gemv_load<8, EXACT>(P.w1, P0, P1, g1, 8, r1b, rb1 >> 8);
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         gemv_load<8, EXACT>(P.w1, P0, P1, g1, 0, r1a);
     }
 
+    GT_STAMP(P.dbg, 15);
     // dropout keep-scales and sigmoid noise (Philox, ~100 VALU ops each) while the first loads are in flight
     if (P.drop_rate > 0.f) {
         if (!P.mask0 && tid < P0) t_k0 = gt_drop_keep(kseed, P.rng_step, 0u, (uint32_t)b, (uint32_t)tid, (uint32_t)P0, P.drop_rate);

@@ -28,6 +28,7 @@ for k in (1, 2):
 f = [buf[i] for i in range(16)]
 t0 = f[0]
 print("front raw (us since stamp0):", {i: round((f[i]-t0)/100.0, 2) for i in range(16) if f[i]})
+print('front prologue (us since stamp0): WG entry', round((f[12]-t0)/100.0,2), 'small loads issued', round((f[13]-t0)/100.0,2), 'seed+hash done', round((f[14]-t0)/100.0,2), 'W1 issued', round((f[15]-t0)/100.0,2))
 print("front -> lstm1 start gap (us):", (buf[16] - buf[7]) / 100.0, " lstm1 end -> lstm2 start:", (buf[32] - buf[19]) / 100.0)
 w = {i: round((f[i]-t0)/100.0, 2) for i in (8, 9, 10, 11) if f[i]}
 print("front workers (us since utterance-WG0 stamp0): first worker start/end", w.get(8), w.get(9), " last worker start/end", w.get(10), w.get(11))
