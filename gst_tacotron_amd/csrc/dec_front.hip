@@ -152,9 +152,11 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     const int mel = P.mel, P0 = P.P0, P1 = P.P1, TvFull = P.Tv;
     // the seed is requested first and waited for only where the keep decisions are derived (below), so its latency
     // overlaps the address arithmetic and the small-operand requests
+    // (read through the constant address space: a scalar load the compiler schedules itself -- the seed was written by an
+    // earlier kernel of the stream, and a plain load of it compiles to a vector load + readfirstlane, waited for on the spot)
     const bool need_seed = P.drop_rate > 0.f && (!P.mask0 || !P.mask1);
     uint64_t kseed = 0;
-    if (need_seed) asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=s"(kseed) : "s"(P.seed_ptr) : "memory");
+    if (need_seed) kseed = *(const __attribute__((address_space(4))) uint64_t*)P.seed_ptr;
     // masked mode (A12): only the first tok_len[b] memory positions exist for this utterance
     const int Tv = P.tok_len ? max(1, min(TvFull, P.tok_len[b])) : TvFull;
 
@@ -229,7 +231,6 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     GT_STAMP(P.dbg, 13);
     uint32_t rb1 = 0xFFFFu, rbq = 0xFFu;
     if (need_seed) {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(kseed) : : "memory");
         if (EXACT && Z0 && P.keep_hash) {
             const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             rb1 = (gt_keep_word(kseed, P.rng_step, 0u, (uint32_t)b, wave >> 1) >> ((wave & 1u) * 16u)) & 0xFFFFu;
