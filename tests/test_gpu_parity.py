@@ -234,6 +234,32 @@ def test_throughput_mode_randomness_matches_oracle(att, rate, monkeypatch):
     assert np.abs(align - ref[3]).max() <= TOL
 
 
+def test_hashed_keep_decisions_look_random():
+    """The rate-0.5 keep decisions are words of a counter hash (device_utils.h gt_keep_word), not Philox: check the bits the
+    decode actually used for balance and for independence across steps, rows, layers and neighbouring columns."""
+    import torch
+    B, Tv, Tref, steps = 4, 16, 40, 64
+    hp, w, tokens, tl, mels, ml, _, _ = _full_case(B, Tv, Tref, steps, seed=41)
+    m = _model(hp, w, B, Tv, Tref + 1)
+    m.Inference_Step(tokens, tl, None, mels, ml, seed=987654321, steps=steps)
+    torch.cuda.synchronize()
+    k = m.debug_randomness(steps, B, Tv)[0].astype(np.int64)          # [steps, 2, B, 256]
+    n = k.size
+    tol = 4.0 / np.sqrt(n)                                            # 4 sigma of a fair coin over n bits
+    assert abs(k.mean() - 0.5) < tol
+    agree = lambda a, b: (a == b).mean()
+    assert abs(agree(k[1:], k[:-1]) - 0.5) < 2 * tol                  # consecutive steps
+    assert abs(agree(k[:, 0], k[:, 1]) - 0.5) < 2 * tol               # the two prenet layers
+    assert abs(agree(k[:, :, 1:], k[:, :, :-1]) - 0.5) < 2 * tol      # neighbouring utterances
+    assert abs(agree(k[..., 1:], k[..., :-1]) - 0.5) < 2 * tol        # neighbouring columns
+    assert abs(agree(k[..., 32:], k[..., :-32]) - 0.5) < 2 * tol      # same bit of neighbouring words
+    assert np.abs(k.mean(axis=(0, 1, 2)) - 0.5).max() < 6.0 / np.sqrt(steps * 2 * B)     # no stuck column
+    m.Inference_Step(tokens, tl, None, mels, ml, seed=987654322, steps=steps)
+    torch.cuda.synchronize()
+    k2 = m.debug_randomness(steps, B, Tv)[0].astype(np.int64)
+    assert abs(agree(k, k2) - 0.5) < 2 * tol                           # adjacent seeds
+
+
 def test_full_size_batch_independence_and_invariants():
     """BASELINE configs[1] at full size (batch 32 x 128 tokens x 500 steps), too big for the oracle in seconds, through
     size-independent properties: (1) utterances are independent -- utterance b decoded inside the batch of 32 equals the
