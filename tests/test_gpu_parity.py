@@ -260,6 +260,28 @@ def test_hashed_keep_decisions_look_random():
     assert abs(agree(k, k2) - 0.5) < 2 * tol                           # adjacent seeds
 
 
+def test_long_trajectory_matches_oracle():
+    """All Max_Step // r = 500 decode steps at the reference's dimensions against the float64 oracle (2 utterances, so the
+    oracle finishes in seconds): rounding differences must not grow along the recurrence."""
+    import time
+    import torch
+    from oracle import oracle_np
+    B, Tv, Tref, steps = 2, 48, 100, 500
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=51)
+    m = _model(hp, w, B, Tv, Tref + 1)
+    mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, dt=np.float64)
+    print("oracle: %.1f s" % (time.time() - t0))
+    assert mel.shape == (B, 1000, 80)
+    err = np.abs(mel.cpu().numpy() - ref[0]).max(axis=(0, 2))
+    print("mel max-abs error, first / last 100 frames:", err[:100].max(), err[-100:].max())
+    assert err.max() <= TOL
+    assert np.abs(stop.cpu().numpy() - ref[1]).max() <= TOL
+    assert np.abs(align.cpu().numpy() - ref[3]).max() <= TOL
+
+
 def test_full_size_batch_independence_and_invariants():
     """BASELINE configs[1] at full size (batch 32 x 128 tokens x 500 steps), too big for the oracle in seconds, through
     size-independent properties: (1) utterances are independent -- utterance b decoded inside the batch of 32 equals the
