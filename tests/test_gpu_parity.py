@@ -162,20 +162,21 @@ def test_eager_graph_and_unfused_paths_agree(monkeypatch):
     assert np.abs(outs[0][0] - outs[2][0]).max() <= TOL and np.abs(outs[0][1] - outs[2][1]).max() <= TOL
 
 
-@pytest.mark.parametrize("mixed", [False, True])
-def test_lean_and_general_decode_kernels_are_the_same_arithmetic(monkeypatch, mixed):
+@pytest.mark.parametrize("mixed,B", [(False, 5), (True, 5), (False, 37), (True, 37)])
+def test_lean_and_general_decode_kernels_are_the_same_arithmetic(monkeypatch, mixed, B):
     """csrc/lean_body.h restates the general skinny GEMM body for the decode shapes with K fixed at compile time: same
     k-block-to-wave assignment, same summation order, so the decode loop (LSTM input halves, projection, recurrent-half
     workers) is BITWISE the general kernels' result at full dimensions; the lean encoder BiLSTM hoists its input halves
     into one GEMM (different summation order) and agrees within the parity tolerance."""
     import torch
-    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(5, 40, 90, 12, seed=9)
+    # (B = 37: two 32-row chunks per tile, a partial 16-row M-tile, worker jobs looping over the chunks)
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, 40, 90, 12, seed=9)
     hp = dict(hp); hp["Use_Mixed_Precision"] = bool(mixed)        # bf16 operands: the lean bf16 bodies, same claim
     w64 = None
     outs = []
     for lean in ("1", "0"):
         monkeypatch.setenv("GSTTACO_LEAN", lean)
-        m = _model(hp, w, 5, 40, 91)
+        m = _model(hp, w, B, 40, 91)
         enc = m.encode(tokens)
         gst = m.Inference_GST_Step(mels, ml)
         torch.cuda.synchronize()
