@@ -389,21 +389,25 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     }
     __syncthreads();
     GT_STAMP(P.dbg, 5);
-    // ---- noise + sigmoid
-    for (int t = tid; t < Tv; t += FT) {
-        float s = sc[t];
-        if (P.sigmoid_noise > 0.f) s += snz[t];
-        sc[t] = gt_sigmoid(s);
-    }
-    __syncthreads();
-    // ---- alignment
+    // ---- noise + sigmoid + alignment
     if (P.type == GSTTACO_ATT_SMA) {
+        // each position needs its own and its left neighbour's probability: both sigmoids are evaluated here (same
+        // arithmetic as a separate sigmoid pass, one barrier and one LDS round trip fewer)
         for (int t = tid; t < Tv; t += FT) {
-            float v = pv[t] * sc[t];
-            if (t > 0) v += pv[t - 1] * (1.f - sc[t - 1]);
+            const bool nz = P.sigmoid_noise > 0.f;
+            float v = pv[t] * gt_sigmoid(sc[t] + (nz ? snz[t] : 0.f));
+            if (t > 0) v += pv[t - 1] * (1.f - gt_sigmoid(sc[t - 1] + (nz ? snz[t - 1] : 0.f)));
             al[t] = v;
         }
-    } else if (tid < 64) {
+    } else {
+        for (int t = tid; t < Tv; t += FT) {
+            float s = sc[t];
+            if (P.sigmoid_noise > 0.f) s += snz[t];
+            sc[t] = gt_sigmoid(s);
+        }
+        __syncthreads();
+    }
+    if (P.type != GSTTACO_ATT_SMA && tid < 64) {
         const int per = (Tv + 63) / 64;
         const int t0 = lane * per, t1 = min(Tv, t0 + per);
         float run = 0.f;
