@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mixed", action="store_true", help="Use_Mixed_Precision: bf16 GEMM operands, fp32 accumulation (BASELINE "
                     "configs[4]); NOT the headline metric -- dtype is then reported as bf16")
+    ap.add_argument("--batch-per-gpu", type=int, default=BATCH_PER_GPU, help="utterances per GPU (default 32 = the headline "
+                    "configuration; BASELINE configs[4] uses 64 with --mixed).  Any other value is NOT the headline metric")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
@@ -127,7 +129,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
     torch.cuda.set_device(local_rank)
 
-    hp, inputs = synthetic.config_inputs("cfg2", batch=BATCH_PER_GPU, seed=1 + rank)
+    hp, inputs = synthetic.config_inputs("cfg2", batch=args.batch_per_gpu, seed=1 + rank)
     hp["Use_Mixed_Precision"] = bool(args.mixed)
     w = weights.synthetic_weights(hp, seed=0)
     B, Tv = inputs["tokens"].shape
@@ -213,7 +215,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.mixed else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: GST on, batch 32 per GPU, 128-token utterances, "
+            "config": {"workload": ("" if args.batch_per_gpu == BATCH_PER_GPU and not args.mixed else "NOT THE HEADLINE CONFIGURATION -- ") +
+                                   "BASELINE configs[1]: GST on, batch {} per GPU, 128-token utterances, ".format(args.batch_per_gpu) +
                                    "Step_Reduction 2, Max_Step 1000, LJSpeech 80-mel hparams; whole Inference_Step "
                                    "(encoder+GST+decode+postnet, vocoder excluded)",
                        "global_batch": n_total, "tokens": Tv, "ref_frames": Tref1 - 1,
