@@ -753,6 +753,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                     rk.wp = L.wp; rk.bf16 = L.bf16; rk.bias = L.bias; rk.nkb = L.nkb;
                     rk.seg[0] = SkinnySeg{layer == 0 ? c->w_h1[p ^ 1] : c->w_h2[p ^ 1], 0, H / 16, 1};
                     rk.M = B; rk.N = H; rk.MT = MT;
+                    rk.keep_weights = 1;                    // default cache policy (see lean_body.h gt_lean_partial)
                     rk.partial_out = c->w_part[layer];
                     f.rec_begin[layer] = 0; f.rec_end[layer] = L.ntiles;
                 }
@@ -866,6 +867,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             rk.wp = L.wp; rk.bf16 = L.bf16; rk.bias = L.bias; rk.nkb = L.nkb;
             rk.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
             rk.M = B; rk.N = H2; rk.MT = MT;
+            rk.keep_weights = 1;
             rk.partial_out = c->w_part[1];
             if (c->lean && k.bf16 == rk.bf16 && gt_proj_lean_supported(k.nkb, rk.nkb) && k.seg[0].nkb + k.seg[1].nkb == k.nkb &&
                 k.seg[0].nkb % 2 == 0) {

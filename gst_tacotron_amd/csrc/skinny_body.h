@@ -307,7 +307,7 @@ __device__ __forceinline__ void gt_skinny_partial_multi(const SkinnyArgs& A, con
                         b[i][j] = make_uint4(0u, 0u, 0u, 0u);
                         if (j < ntile) {
                             const uint4* src = wq + ((size_t)j * nkb32 + kb32) * 64;
-                            if (NT_WEIGHTS) {
+                            if (NT_WEIGHTS && !A.keep_weights) {
                                 const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
                                 b[i][j] = make_uint4(t[0], t[1], t[2], t[3]);
                             } else {
@@ -359,7 +359,7 @@ __device__ __forceinline__ void gt_skinny_partial_multi(const SkinnyArgs& A, con
                         b[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (j < ntile) {
                             const float4* src = wp + ((size_t)j * nkb + kb) * 64;
-                            if (NT_WEIGHTS) {
+                            if (NT_WEIGHTS && !A.keep_weights) {
                                 const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
                                 b[i][j] = make_float4(t[0], t[1], t[2], t[3]);
                             } else {
