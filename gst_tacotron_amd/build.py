@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgsttaco.so")
 SOURCES = ["gsttaco.cpp", "skinny_gemm.hip", "gemm_conv.hip", "attention.hip", "dec_front.hip", "gst.hip", "audio.hip"]
-HEADERS = ["kernels.h", "device_utils.h", "skinny_body.h", os.path.join("..", "..", "include", "gsttaco.h")]
+FLAGS_STAMP = os.path.join(LIBDIR, ".flags")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -22,6 +22,22 @@ def _hipcc():
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
             return cand
     return "hipcc"
+
+
+def _headers():
+    """Every header a source may include: all of csrc/*.h plus the public ABI header.  Globbed, so a new header cannot be
+    forgotten (an edit to the hottest header once rebuilt nothing: a stale .so then ships to the GPU box)."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.normpath(os.path.join(HERE, "..", "include", "gsttaco.h"))]
+
+
+def _flags_changed():
+    """True when the compile flags / compiler differ from the ones the objects in lib/ were built with."""
+    want = " ".join([_hipcc()] + FLAGS)
+    try:
+        return open(FLAGS_STAMP).read() != want
+    except OSError:
+        return True
 
 
 def _stale(target, deps):
@@ -33,7 +49,9 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    hdrs = _headers()
+    if _flags_changed():
+        force = True
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
@@ -56,6 +74,8 @@ def build(force=False, verbose=False):
                 print(warn)
     if force or jobs or _stale(LIB, objs):
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(FLAGS_STAMP, "w") as f:
+        f.write(" ".join([_hipcc()] + FLAGS))
     return LIB
 
 

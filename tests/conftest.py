@@ -18,6 +18,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Without a GPU the `gpu` tests cannot do anything but fail with "no HIP device" (there is no CPU fallback): skip them,
+    so a plain `pytest tests` on the build container shows host-side regressions instead of 60 expected failures."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs an MI355X (no CPU fallback exists)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def load_golden(name):
     """Returns (hp, weights, fixture dict).  Weights are regenerated from the stored seed and verified
     against the per-tensor checksums stored with the vectors."""

@@ -44,6 +44,23 @@ def test_oracle_reproduces_synthetic_fixtures(name):
                                        atol=F32_STORE, rtol=0)
 
 
+def test_oracle_matches_reference_executed_pure_functions():
+    """The librosa-free functions of the reference's Audio.py (:11-15, :86-102), EXECUTED from the reference source in the build
+    container (oracle/gen_golden_audio_ref.py) -- reference-generated vectors, so these eight restatements are pinned."""
+    z = np.load(os.path.join(GOLD, "audio_ref_pure.npz"))
+    sig, mag, db, nrm = z["sig"], z["mag"], z["db"], z["nrm"]
+    eq = lambda got, key: np.testing.assert_allclose(got, z[key], rtol=1e-13, atol=1e-13)
+    eq(A.preemphasis(sig), "preemphasis")
+    eq(A.inv_preemphasis(sig), "inv_preemphasis")
+    eq(A.inv_preemphasis(A.preemphasis(sig)), "roundtrip")
+    eq(A.amp_to_db(mag), "amp_to_db")
+    eq(np.power(10.0, db * 0.05), "db_to_amp")                    # inlined in A.inv_spectrogram (Audio.py:26,89-90)
+    eq(A.normalize(db), "normalize")
+    eq(A.symmetric_normalize(db, max_abs_value=4), "symmetric_normalize")
+    eq(A.denormalize(nrm), "denormalize")
+    eq(A.symmetric_denormalize(nrm, max_abs_value=4), "symmetric_denormalize")
+
+
 def test_stft_matches_scipy():
     """Independent check of the restated librosa.stft: scipy.signal.stft on the reflect-padded signal, rescaled."""
     from scipy import signal

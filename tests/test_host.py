@@ -145,6 +145,66 @@ def test_feeder_inference_pattern_conventions():
     assert ragged["mels_for_gst"].shape == (2, 6, 80) and not ragged["mels_for_gst"][0, 4:].any()
 
 
+def test_feeder_matches_reference_generated_fixture():
+    """SURVEY row A0 against the REFERENCE's own Feeder.Get_Inference_Pattern / Get_Inference_GST_Pattern
+    (Feeder.py:161-252), executed in the build container by oracle/gen_golden_feeder.py on the 8 sentences of the
+    reference's Inference_Sentence_for_Training.txt -- the first fixture in tests/golden that the reference, not the
+    oracle, produced.  Bit-exact (integer / copy work)."""
+    import io
+    import contextlib
+    import json
+    import torch
+    z = np.load(os.path.join(ROOT, "tests", "golden", "feeder_tokens.npz"))
+    sentences = [str(s) for s in z["sentences"]]
+    assert len(sentences) == 8
+    bank = {k[4:]: z[k] for k in z.files if k.startswith("mel_ref")}
+    wavs = ["ref{}.wav".format(i) for i in range(8)]
+    calls = []
+
+    def frontend(wav_List, top_db):
+        # what GST_Tacotron.Mel_Generate hands back: the mels_for_gst layout (zero frame 0, zero padding) + lengths
+        calls.extend((w, int(top_db)) for w in wav_List)
+        mels = [bank[w] for w in wav_List]
+        out = np.zeros((len(mels), max(m.shape[0] for m in mels) + 1, 80), np.float32)
+        for i, m in enumerate(mels):
+            out[i, 1:m.shape[0] + 1] = m
+        return torch.from_numpy(out), torch.tensor([m.shape[0] for m in mels], dtype=torch.int32)
+
+    def same(pat, prefix, keys):
+        for k in keys:
+            got = pat[k].numpy() if hasattr(pat[k], "numpy") else pat[k]
+            want = z[prefix + "." + k]
+            assert got.dtype == want.dtype and got.shape == want.shape, (k, got.dtype, got.shape, want.dtype, want.shape)
+            assert np.array_equal(got, want), k
+
+    base = ("tokens", "token_lengths", "initial_mels")
+    gst = base + ("mels_for_gst", "mel_lengths_for_gst")
+    hp_off = hparams.load_hp()
+    hp_off["GST"]["Use"] = False
+    assert json.loads(str(z["token_dict_json"])) == Feeder(hp_off).token_Index_Dict
+    same(Feeder(hp_off).Get_Inference_Pattern(sentences), "nogst", base)
+
+    f = Feeder(hparams.load_hp(), mel_frontend=frontend)
+    same(f.Get_Inference_Pattern(sentences, [wavs[1]]), "gst_one", gst)
+    assert calls == [(w, db) for w, db, _ in json.loads(str(z["gst_one.calls"]))]          # top_db 60 (Feeder.py:205)
+    calls.clear()
+    same(f.Get_Inference_Pattern(sentences, wavs), "gst_many", gst)
+    assert calls == [(w, db) for w, db, _ in json.loads(str(z["gst_many.calls"]))]         # top_db 15 (Feeder.py:209)
+    calls.clear()
+    same(f.Get_Inference_GST_Pattern(wavs[2:6]), "gst_only", ("mels_for_gst", "mel_lengths_for_gst"))
+    assert calls == [(w, db) for w, db, _ in json.loads(str(z["gst_only.calls"]))]         # top_db 60 (Feeder.py:232)
+    # the precomputed-mel entry (no GPU): same layout from the arrays themselves
+    same(f.Get_Inference_Pattern(sentences, [bank[w] for w in wavs]), "gst_many", gst)
+    same(f.Get_Inference_Pattern(sentences, [bank[wavs[1]]]), "gst_one", gst)
+    # error behaviour: the reference's messages and None (Feeder.py:197-202), KeyError on OOV (:169)
+    for args, key in (((sentences, None), "err.no_wav_message"), ((sentences, wavs[:3]), "err.bad_count_message")):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            assert f.Get_Inference_Pattern(*args) is None
+        assert buf.getvalue() == str(z[key])
+    assert bool(z["err.oov_raises_keyerror"])
+
+
 def test_shard_bounds_cover_everything():
     from gst_tacotron_amd.distributed import shard_bounds
     for n in (1, 7, 32, 256, 257):
