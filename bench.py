@@ -4,7 +4,9 @@ postnet; CBHG vocoder excluded) on BASELINE.json configs[1]: GST on, batch 32 pe
 utterances, Step_Reduction 2, Max_Step 1000, LJSpeech 80-mel hyper-parameters, fp32.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1 under a launcher: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...;
+     N>1 WITHOUT a launcher: this process starts the N rank processes itself -- before anything touches the GPU -- and exits with
+     their status.  A --gpus that disagrees with the launcher's WORLD_SIZE is an error, never a silent 1-rank run.)
 
 A "step" is one Inference_Step over one synthetic batch per rank (inputs resident in HBM, weights
 random-init of the reference architecture, randomness from the on-device Philox generator).
@@ -34,17 +36,58 @@ BATCH_PER_GPU = 32
 PROFILE_EVERY = 20             # bracket every 20th decode step's LSTM launches with HIP events
 
 
-def cpu_baseline(hp, w, inputs, budget_s=15.0):
-    """The torch-CPU restatement of the TF2 graph (oracle/torch_ref.py, kind "port"; TensorFlow is not
-    installable here) timed on this box's host cores on a bounded sample of the same workload.  The thread
-    count is the fastest of a short calibration (eager per-op dispatch does not scale to every core)."""
+def host_cpu_info():
+    """CPU model string and core counts of this box (lscpu; /proc/cpuinfo as fallback) -- BASELINE.md section 3 asks for them next
+    to every CPU number."""
+    info = {"model": None, "logical_cpus": os.cpu_count(), "physical_cores": None, "sockets": None}
+    try:
+        import subprocess
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {}
+        for ln in out.splitlines():
+            if ":" in ln:
+                k, v = ln.split(":", 1)
+                kv[k.strip()] = v.strip()
+        info["model"] = kv.get("Model name")
+        if "Socket(s)" in kv and "Core(s) per socket" in kv:
+            info["sockets"] = int(kv["Socket(s)"])
+            info["physical_cores"] = int(kv["Socket(s)"]) * int(kv["Core(s) per socket"])
+    except Exception:
+        pass
+    if info["model"] is None:
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("model name"):
+                    info["model"] = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+    return info
+
+
+def _median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def cpu_baseline(hp, w, inputs, budget_s=15.0, runs=5):
+    """The torch-CPU restatement of the TF2 graph (oracle/torch_ref.py, kind "port"; TensorFlow is not installable here)
+    timed on this box's host cores, BASELINE.md section 3 protocol: 1 warm-up + `runs` timed runs, median (and min) reported,
+    CPU model and thread count stated.  Two workloads:
+      * like-for-like (the `value`): the bench's own configs[1] batch -- encoder + GST once, a BOUNDED number of decode
+        steps, postnet on the frames those steps emit -- sized so that the timed runs take about `budget_s` seconds;
+      * BASELINE configs[0], the reference's own CPU case, in full: GST off, batch 1, 32 tokens, Max_Step 200, r = 1.
+    The thread count is the fastest of a short calibration (eager per-op dispatch does not scale to every core)."""
     from oracle.torch_ref import TorchReference
     B, Tv = inputs["tokens"].shape
     d_r = int(hp["Step_Reduction"])
     total_steps = int(hp["Max_Step"]) // d_r
     rng = np.random.default_rng(123)
     masks, noise = synthetic.make_randomness(rng, total_steps, B, Tv, hp["Tacotron2"]["Decoder"]["Prenet"]["Size"])
-    ref = TorchReference(hp, w, torch.float32)
+    hp32 = dict(hp)
+    hp32["Use_Mixed_Precision"] = False
+    ref = TorchReference(hp32, w, torch.float32)
 
     def run(steps):
         t0 = time.perf_counter()
@@ -52,6 +95,7 @@ def cpu_baseline(hp, w, inputs, budget_s=15.0):
                            masks[:steps], noise[:steps], steps=steps)
         return time.perf_counter() - t0
 
+    cpu = host_cpu_info()
     ncpu = os.cpu_count() or 1
     best = None
     for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
@@ -64,14 +108,49 @@ def cpu_baseline(hp, w, inputs, budget_s=15.0):
             best = (nt, per_step, t1)
     nt, per_step, t_fixed = best
     torch.set_num_threads(nt)
-    steps_sample = int(max(10, min(total_steps, (budget_s - t_fixed) / per_step)))
-    dt = run(steps_sample)
+    per_run = budget_s / runs
+    steps_sample = int(max(10, min(total_steps, (per_run - t_fixed) / per_step)))
+    run(steps_sample)                                                   # warm-up
+    times = [run(steps_sample) for _ in range(runs)]
     frames = B * steps_sample * d_r
-    return {"value": frames / dt, "unit": "mel-frames/s", "cores": nt, "kind": "port",
-            "sample": "cfg2 batch {} x {} tokens: encoder+GST once, {} of {} decode steps, postnet on those {} frames; "
-                      "{:.1f} s wall on {} of {} host CPUs (fastest of 8/16/32/64 threads); torch-CPU eager restatement "
-                      "of the TF2 graph (TF not installable)".format(B, Tv, steps_sample, total_steps, steps_sample * d_r,
-                                                                      dt, nt, ncpu)}
+    med, mn = _median(times), min(times)
+
+    # BASELINE configs[0] in full (Model.py:249-255 with Device=-1): GST off, batch 1, 32 tokens, Max_Step 200, r = 1
+    hp0, in0 = synthetic.config_inputs("cfg1")
+    w0 = weights.synthetic_weights(hp0, seed=0)
+    ref0 = TorchReference(hp0, w0, torch.float32)
+    steps0 = int(hp0["Max_Step"]) // int(hp0["Step_Reduction"])
+    m0, n0 = synthetic.make_randomness(np.random.default_rng(5), steps0, 1, in0["tokens"].shape[1],
+                                       hp0["Tacotron2"]["Decoder"]["Prenet"]["Size"])
+
+    def run0():
+        t0 = time.perf_counter()
+        ref0.inference_step(in0["tokens"], None, None, m0, n0, steps=steps0)
+        return time.perf_counter() - t0
+
+    best0 = None
+    for nt0 in sorted({min(ncpu, n) for n in (1, 4, 8, 16)}):
+        torch.set_num_threads(nt0)
+        run0()
+        t = run0()
+        if best0 is None or t < best0[1]:
+            best0 = (nt0, t)
+    torch.set_num_threads(best0[0])
+    times0 = [run0() for _ in range(runs)]
+    frames0 = steps0 * int(hp0["Step_Reduction"])
+    torch.set_num_threads(nt)
+    return {"value": frames / med, "unit": "mel-frames/s", "cores": nt, "kind": "port",
+            "value_best_run": frames / mn, "runs": runs, "run_seconds": [round(t, 3) for t in times],
+            "cpu_model": cpu["model"], "host_logical_cpus": cpu["logical_cpus"], "host_physical_cores": cpu["physical_cores"],
+            "sample": "configs[1] batch {} x {} tokens: encoder+GST once, {} of {} decode steps, postnet on those {} frames; "
+                      "median of {} runs after 1 warm-up, {:.2f} s per run on {} threads (fastest of 8/16/32/64) of {}; "
+                      "torch-CPU eager restatement of the TF2 graph (TF not installable)".format(
+                          B, Tv, steps_sample, total_steps, steps_sample * d_r, runs, med, nt, cpu["model"]),
+            "configs0": {"value": frames0 / _median(times0), "value_best_run": frames0 / min(times0), "unit": "mel-frames/s",
+                         "cores": best0[0], "runs": runs, "run_seconds": [round(t, 3) for t in times0],
+                         "sample": "BASELINE configs[0] in full: GST off, batch 1, 32 tokens, Max_Step 200, Step_Reduction 1 "
+                                   "({} decode steps), whole Inference_Step; median of {} runs after 1 warm-up on {} threads "
+                                   "(fastest of 1/4/8/16)".format(steps0, runs, best0[0])}}
 
 
 def pmc_traffic(kernel_substr):
@@ -121,13 +200,24 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
-    rank, local_rank, world = gdist.init_process_group()
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus {} but WORLD_SIZE {}".format(args.gpus, world), file=sys.stderr)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the N rank processes ourselves.  This parent has not touched the GPU (importing torch does not
+        # initialise HIP) and never will: it only waits for its children and forwards their status.
+        raise SystemExit(gdist.spawn_local_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:
+        raise SystemExit("bench.py: --gpus {} but the launcher's WORLD_SIZE is {}: refusing to print a line that would "
+                         "misreport n_gpus".format(args.gpus, env_world))
+    if torch.cuda.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
+    rank, local_rank, world = gdist.init_process_group(device_index=int(os.environ.get("LOCAL_RANK", "0")))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        world = torch.distributed.get_world_size()          # what the collective library actually sees
+        assert world == args.gpus, (world, args.gpus)
 
     hp, inputs = synthetic.config_inputs("cfg2", batch=args.batch_per_gpu, seed=1 + rank)
     hp["Use_Mixed_Precision"] = bool(args.mixed)
@@ -145,7 +235,9 @@ def main():
     n_total = B * world
 
     def one_step(i):
-        mel, stop, _, align = model.Inference_Step(tok, None, None, mels, lens, seed=1000 + i)
+        # dropout / noise streams are indexed by the LOCAL utterance index: fold the rank into the seed so that shards
+        # do not draw identical randomness
+        mel, stop, _, align = model.Inference_Step(tok, None, None, mels, lens, seed=(1000 + i) * world + rank)
         return gdist.gather_to_root(mel, n_total=n_total)
 
     # Two cached graphs: the plain one, and one whose decode launches are bracketed by event-record nodes on every
@@ -223,7 +315,15 @@ def main():
                        "parallelism": "utterance-sharded x{} + final RCCL gather".format(world)},
             "roofline": {"bound": "hbm", "kernel": KNAMES[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": bytes1,
+                         "frac_basis": "in-run HIP event-record nodes around the launch (includes ~2.5 us of event-node overhead: understated)",
+                         "frac_rocprofv3": (bytes1 / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp_us else None,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": "FETCH_SIZE x2 + WRITE_SIZE per launch from the COMMITTED rocprofv3 --pmc profile named in "
+                                         "traffic_source (separate passes, tools/profile.sh); a constant, not measured in this run",
+                         "served_from": "weights: Infinity Cache (the 58 MB per-step working set is re-read every step and stays "
+                                        "resident in the 256 MiB MALL; the memory-side counters count those hits); shared "
+                                        "activations: XCD L2.  `peak` is the HBM3E spec rate the guide names for the hbm bound",
+                         "bytes_per_launch": bytes1,
                          "avg_launch_us": ms1 * 1e3, "launches_timed": cnt1, "empty_event_bracket_us": bracket_ms * 1e3,
                          "avg_launch_us_rocprofv3": rp_us, "rocprofv3_source": rp_src,
                          "decode_step": {"us": step_us, "algorithmic_bytes": step_bytes,

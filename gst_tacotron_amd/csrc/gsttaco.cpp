@@ -154,8 +154,17 @@ struct gsttaco_ctx {
           *w_mel = nullptr;
     size_t zero_floats = 0;
 
-    // graphs
-    std::map<GraphKey, hipGraphExec_t> graphs;
+    // graphs: LRU-bounded cache of instantiated executables, one per (kind, shape, flags) key.  A full Inference_Step
+    // graph holds ~2 200 kernel nodes; a caller whose shapes vary (the reference's Feeder pads to the batch maximum) would
+    // otherwise grow host and device memory without bound.  `graph_capture_after` = n: a key is captured at its n-th use and
+    // runs eagerly before (1 = capture at first use; 2 suits variable-shape serving, where most shapes never repeat).
+    struct GraphEntry { hipGraphExec_t exec; uint64_t last_use; };
+    std::map<GraphKey, GraphEntry> graphs;
+    std::map<GraphKey, std::pair<int, uint64_t>> graph_seen;     // uses so far (not yet captured), last use
+    uint64_t graph_clock = 0;
+    int graph_cache_max = 8;
+    int graph_capture_after = 1;
+    int n_cu = 256;             // compute units of the device (hipDeviceProp_t::multiProcessorCount), queried in ensure_device
 
     // profiling
     int prof_every = 0;
@@ -757,7 +766,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                     rk.partial_out = c->w_part[layer];
                     f.rec_begin[layer] = 0; f.rec_end[layer] = L.ntiles;
                 }
-                f.n_workers = B < 192 ? 256 - B : 64;
+                // one worker workgroup per compute unit the utterance workgroups leave free (a quarter of the chip at least)
+                f.n_workers = B < c->n_cu * 3 / 4 ? c->n_cu - B : c->n_cu / 4;
                 f.worker_tiles = c->worker_tiles;
                 f.lean_rec = (c->lean && f.rec[0].bf16 == f.rec[1].bf16 && f.rec[0].nkb == 64 && f.rec[1].nkb == 64) ? (f.rec[0].bf16 ? 2 : 1) : 0;
                 for (int layer = 0; layer < 2; ++layer)
@@ -953,6 +963,7 @@ int ensure_device(gsttaco_ctx* c) {
     HIPCHECK(c, hipGetDeviceProperties(&prop, g.device));
     if (!strstr(prop.gcnArchName, "gfx950"))
         return fail(c, GSTTACO_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    if (prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
     return 0;
 }
 
@@ -1117,12 +1128,28 @@ int check_shape(gsttaco_ctx* c, int B, int Tv, int Tref1, int steps) {
     return 0;
 }
 
-// Runs `body` either eagerly on `stream` or through a cached hipGraph captured on the internal stream.
+// Runs `body` either eagerly on `stream` or through a cached hipGraph captured on the internal stream (LRU-bounded,
+// see gsttaco_ctx::graphs).
 template <typename F>
 int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key, F body) {
-    if (!c->use_graph) return body(stream);
+    if (!c->use_graph || c->graph_cache_max < 1) return body(stream);
+    const uint64_t now = ++c->graph_clock;
     auto it = c->graphs.find(key);
     if (it == c->graphs.end()) {
+        if (c->graph_capture_after > 1) {
+            auto& seen = c->graph_seen[key];
+            seen.second = now;
+            if (++seen.first < c->graph_capture_after) {
+                if (c->graph_seen.size() > 256) {           // bound the bookkeeping too: forget the stalest key
+                    auto old = c->graph_seen.begin();
+                    for (auto j = c->graph_seen.begin(); j != c->graph_seen.end(); ++j)
+                        if (j->second.second < old->second.second) old = j;
+                    c->graph_seen.erase(old);
+                }
+                return body(stream);
+            }
+            c->graph_seen.erase(key);
+        }
         hipGraph_t graph = nullptr;
         HIPCHECK(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed));
         c->capturing = true;
@@ -1138,9 +1165,19 @@ int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key, F body) 
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) return fail(c, GSTTACO_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-        it = c->graphs.emplace(key, exec).first;
+        while ((int)c->graphs.size() >= c->graph_cache_max) {       // evict the least recently used executable
+            auto old = c->graphs.begin();
+            for (auto j = c->graphs.begin(); j != c->graphs.end(); ++j)
+                if (j->second.last_use < old->second.last_use) old = j;
+            // an evicted executable may still be running on the caller's stream from an earlier call
+            HIPCHECK(c, hipStreamSynchronize(stream));
+            (void)hipGraphExecDestroy(old->second.exec);
+            c->graphs.erase(old);
+        }
+        it = c->graphs.emplace(key, gsttaco_ctx::GraphEntry{exec, now}).first;
     }
-    HIPCHECK(c, hipGraphLaunch(it->second, stream));
+    it->second.last_use = now;
+    HIPCHECK(c, hipGraphLaunch(it->second.exec, stream));
     return 0;
 }
 
@@ -1235,6 +1272,8 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     if (const char* e = getenv("GSTTACO_WORKER_TILES")) c->worker_tiles = atoi(e);
     if (const char* e = getenv("GSTTACO_CO_WORKER_TILES")) c->co_worker_tiles = atoi(e);
     if (const char* e = getenv("GSTTACO_LEAN")) c->lean = e[0] != '0';
+    if (const char* e = getenv("GSTTACO_GRAPH_CACHE")) c->graph_cache_max = std::max(0, atoi(e));
+    if (const char* e = getenv("GSTTACO_GRAPH_CAPTURE_AFTER")) c->graph_capture_after = std::max(1, atoi(e));
     if (const char* e = getenv("GSTTACO_KEEP_HASH")) c->keep_hash = e[0] != '0';
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
@@ -1245,7 +1284,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
 
 void gsttaco_destroy(gsttaco_ctx* c) {
     if (!c) return;
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
     for (int l = 0; l < 5; ++l)
         for (auto e : c->prof_ev[l]) (void)hipEventDestroy(e);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
@@ -1791,6 +1830,23 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
     HIPCHECK(c, hipMemcpyAsync(align, c->w_align, (size_t)B * steps * Tv * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
+
+int gsttaco_set_graph_policy(gsttaco_ctx* c, int max_cached, int capture_after) {
+    if (!c || max_cached < 0 || capture_after < 1) return GSTTACO_E_INVALID;
+    c->graph_cache_max = max_cached;
+    c->graph_capture_after = capture_after;
+    while ((int)c->graphs.size() > max_cached) {
+        auto old = c->graphs.begin();
+        for (auto j = c->graphs.begin(); j != c->graphs.end(); ++j)
+            if (j->second.last_use < old->second.last_use) old = j;
+        HIPCHECK(c, hipDeviceSynchronize());
+        (void)hipGraphExecDestroy(old->second.exec);
+        c->graphs.erase(old);
+    }
+    return 0;
+}
+
+int gsttaco_graph_cache_size(const gsttaco_ctx* c) { return c ? (int)c->graphs.size() : GSTTACO_E_INVALID; }
 
 int gsttaco_set_profiling(gsttaco_ctx* c, int every) {
     if (!c || every < 0) return GSTTACO_E_INVALID;

@@ -16,16 +16,61 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_process_group(backend=None):
-    """Idempotent init from the torchrun environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE)."""
+def init_process_group(backend=None, device_index=None):
+    """Idempotent init from the torchrun environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE).  With the "nccl"
+    (= RCCL) backend the process group is bound to this rank's GPU (``device_id``), so the communicator is created eagerly
+    on the right device instead of lazily on whichever device is current at the first collective."""
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if torch.cuda.device_count() > 0 else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank if device_index is None else device_index)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def spawn_local_ranks(n_ranks, argv, extra_env=None):
+    """Start ``n_ranks`` fresh rank processes of ``argv`` on this node (one per GPU) with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT) and wait for them; returns the first non-zero
+    exit status (0 if all succeed).  The CALLER must not have initialised the GPU: children are separate processes created
+    by fork+exec from a parent that only waits (a process that has touched HIP must never exec another program)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL over xGMI needs it on this driver
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(argv), env=env))
+    status = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                try:
+                    rc = p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if rc != 0 and status == 0:
+                    status = rc
+                    for q in pending:           # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return status
 
 
 def shard_bounds(n_items, rank, world):

@@ -15,8 +15,9 @@ PyTorch is used for device memory and streams only.  Differences, all additive:
     ``attn_noise``) for parity runs, otherwise it is generated on the GPU from ``seed``;
   * ``token_lengths`` / ``initial_mels`` are accepted and ignored exactly like the
     reference ignores them at inference (Model.py:249-253, Taco2.py:161; SURVEY F5, F15);
-  * the CBHG vocoder output (3rd element of the returned tuple) is out of scope for this
-    path and returned as None.
+  * the CBHG vocoder output (3rd element of the returned tuple, Vocoder_Taco1) is computed when
+    ``with_vocoder=True`` (gsttaco_vocoder); by default it is None, because the north-star metric
+    (mel frames) excludes it.
 """
 import ctypes
 import os
@@ -65,20 +66,23 @@ class GST_Tacotron:
             if checkpoint_File_Path is None:
                 checkpoint_File_Path = tf_checkpoint.latest_checkpoint(self.hp_Dict.get("Checkpoint_Path", "."))   # :268-270
             if checkpoint_File_Path is not None and os.path.exists(str(checkpoint_File_Path) + ".index"):
+                # verify=True: every tensor's crc32c is checked (native gsttaco_crc32c), so a truncated or corrupted
+                # .data shard fails here instead of loading silently
                 weights = tf_checkpoint.load_reference_checkpoint(checkpoint_File_Path, self.hp_Dict,
-                                                                  vocab=len(self.token_Index_Dict))
+                                                                  vocab=len(self.token_Index_Dict), verify=True)
             elif checkpoint_File_Path is not None and os.path.exists(checkpoint_File_Path):
                 weights = weights_mod.load_npz(checkpoint_File_Path)
             else:
                 print("There is no checkpoint.")
                 return self
-            print("Checkpoint '{}' is loaded.".format(checkpoint_File_Path))
         weights_mod.check_weights(self.hp_Dict, weights, vocab=len(self.token_Index_Dict))
         if not torch.cuda.is_available():
             raise capi.GstTacoError(-2, "no HIP device: the gfx950 kernels are the only compute path (no CPU fallback)")
         self.ctx.load_weights(weights)
         self.ctx.finalize()
         self._ready = True
+        if checkpoint_File_Path is not None:
+            print("Checkpoint '{}' is loaded.".format(checkpoint_File_Path))       # reference Model.py:276, after the load
         return self
 
     # ------------------------------------------------------------------ helpers
@@ -105,7 +109,8 @@ class GST_Tacotron:
                        mel_lengths_for_gst=None, prenet_masks=None, attn_noise=None, seed=None,
                        steps=None, return_pre_mel=False, masked=False, with_vocoder=False):
         """reference Model.py:249-255.  Returns (mel_Logits [B,S*r,mel], stop_Logits [B,S],
-        spectrogram_Logits (None), alignments [B,S,T_v]) as CUDA tensors on the current stream.
+        spectrogram_Logits ([B,S*r,Spectrogram_Dim] with ``with_vocoder=True``, else None), alignments [B,S,T_v]) as
+        CUDA tensors on the current stream.
         ``masked=True`` (extension): honour ``token_lengths`` so each utterance of a ragged batch equals
         that utterance run alone; the default ignores them like the reference does.
         ``with_vocoder=True`` also runs Vocoder_Taco1 (CBHG) and returns spectrogram_Logits [B,S*r,513]
@@ -300,6 +305,15 @@ class GST_Tacotron:
         plan = (ctypes.c_int32 * 3)()
         self.ctx.check(self.ctx.lib.gsttaco_decode_plan(self.ctx.handle, int(Tv), plan))
         return bool(plan[0]), bool(plan[1]), bool(plan[2])
+
+    def set_graph_policy(self, max_cached=8, capture_after=1):
+        """hipGraph cache policy (``gsttaco_set_graph_policy``): at most ``max_cached`` graph executables are kept (LRU);
+        a shape is captured at its ``capture_after``-th use and enqueued eagerly before.  Use ``capture_after=2`` when
+        batch shapes vary from call to call (the reference's Feeder pads to the batch maximum, Feeder.py:175-180)."""
+        self.ctx.check(self.ctx.lib.gsttaco_set_graph_policy(self.ctx.handle, int(max_cached), int(capture_after)))
+
+    def graph_cache_size(self):
+        return int(self.ctx.lib.gsttaco_graph_cache_size(self.ctx.handle))
 
     def debug_randomness(self, steps, B, Tv):
         """(prenet_masks [steps, 2, B, P], attn_noise [steps, B, Tv]) the last decode of that shape used, as NumPy arrays in

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 7
+#define GSTTACO_ABI_VERSION 8
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -165,8 +165,15 @@ int gsttaco_gst(gsttaco_ctx* ctx, const float* mels_for_gst, const int32_t* mel_
                 int B, int Tref1, float* gst, void* stream);
 
 /* enc [B,Tv,2*enc_rnn], gst [B,gst_att] (NULL when GST is off)
- * prenet_mask: NULL (on-device Philox, `seed`) or keep-masks [steps,2,B,prenet] float32 (1 keep / 0 drop)
- * attn_noise : NULL (on-device Philox, `seed`) or N(0,1) samples [steps,B,Tv]
+ * prenet_mask: keep-masks [steps,2,B,prenet] float32 (1 keep / 0 drop), or NULL = generated on the device from `seed`:
+ *              at the reference's rate 0.5 the keep bit of (step, layer, utterance row, column) is bit (column & 31) of a
+ *              32-bit COUNTER HASH of (seed, step, layer, row, column >> 5) -- three murmur3 finalisers, device_utils.h
+ *              gt_keep_word; NOT Philox: the scalar unit derives a wave's 16 decisions in ~25 instructions, which is what
+ *              lets the front kernel skip the weight rows that meet an exact zero -- and at any other rate
+ *              Philox4x32-10 (u01 > rate).  The reference draws tf.nn.dropout's unseeded stream (Taco2.py:283): only
+ *              the distribution can match, checked by tests/test_gpu_parity.py::test_hashed_keep_decisions_look_random
+ * attn_noise : N(0,1) samples [steps,B,Tv], or NULL = Philox4x32-10 + Box-Muller from `seed`
+ *              (gsttaco_debug_randomness reads back what a call used)
  * steps      : 0 = Max_Step // Step_Reduction, else 1..that
  * outputs    : pre_mel [B,steps*r,mel], stop [B,steps], align [B,steps,Tv] */
 int gsttaco_decode(gsttaco_ctx* ctx, const float* enc, const float* gst, const int32_t* token_lengths,
@@ -222,6 +229,16 @@ int gsttaco_inference_step(gsttaco_ctx* ctx, const int32_t* tokens, const int32_
                            const float* prenet_mask, const float* attn_noise, uint64_t seed,
                            int B, int Tv, int Tref1, int steps,
                            float* mel, float* stop, float* align, float* pre_mel, float* spectrogram, void* stream);
+
+/* hipGraph cache policy.  Every entry point replays one cached graph executable per (entry, B, Tv, Tref1, steps, flags) key.
+ * The cache is LRU-bounded to `max_cached` executables (default 8; GSTTACO_GRAPH_CACHE; 0 = no graphs, everything is
+ * enqueued eagerly on the caller's stream); the least recently used one is destroyed when a new shape is captured.
+ * `capture_after` = n >= 1: a key is captured at its n-th use and enqueued eagerly before that (default 1;
+ * GSTTACO_GRAPH_CAPTURE_AFTER).  Callers whose shapes vary from batch to batch -- the reference's Feeder pads to the
+ * batch maximum (Feeder.py:175-180) -- should use 2, or bucket shapes with masked mode, so that a shape that never
+ * repeats never pays a ~2 000-node capture.  Results are identical either way (a GPU test compares them bitwise). */
+int gsttaco_set_graph_policy(gsttaco_ctx* ctx, int max_cached, int capture_after);
+int gsttaco_graph_cache_size(const gsttaco_ctx* ctx);
 
 /* Measurement support (bench.py): per-kernel timing of the last gsttaco_inference_step replay.
  * When enabled, HIP event-record nodes bracket the four kernels of every `every`-th decode step inside the graph. */

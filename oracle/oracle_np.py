@@ -423,7 +423,8 @@ def inference_step(hp, weights, tokens, mels_for_gst=None, mel_lengths_for_gst=N
     """Reference Model.py:249-255 with the wiring of Model.py:108-129,145-156.  ``mixed`` emulates the HIP path's
     Use_Mixed_Precision mode (bf16 GEMM operands, see `mm`); ``fused_prenet0`` (mixed only) says whether that path folds
     prenet layer 0 into the projection GEMM for this shape (``GST_Tacotron.decode_plan``).
-    Returns (mels [B,S*r,mel] post-net, stops [B,S], None (vocoder out of scope), alignments [B,S,T_v])
+    Returns (mels [B,S*r,mel] post-net, stops [B,S], spectrograms [B,S*r,Spectrogram_Dim] (``with_vocoder``; else None),
+    alignments [B,S,T_v])
     plus a dict of intermediates for per-module parity tests."""
     global MIXED, FUSED_PRENET0
     prev_mixed, MIXED = MIXED, bool(mixed)

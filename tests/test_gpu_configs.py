@@ -1,0 +1,172 @@
+"""GPU tests of the BASELINE.json configurations at their FULL sizes (configs[2] and the per-GPU shard of configs[4]) and of
+the hipGraph cache policy.  The oracle cannot run these sizes in seconds, so full-size checks go through size-independent
+properties (utterance independence, alignment invariants, round-robin speaker equality); the oracle itself is run on two
+utterances of the same workload."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import MIXED_MEAN, MIXED_TOL, TOL, _model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_full_size_all_500_steps_with_padding_masks():
+    """BASELINE configs[2] exactly as SURVEY 8(d) cfg 3 states it: batch 128, token lengths rng.integers(32, 257) padded to
+    the batch maximum, reference-mel lengths rng.integers(128, 513), seed 2, masked mode, ALL Max_Step // r = 500 decode
+    steps.  Every checked utterance of the padded batch equals that utterance decoded alone at its own length over the whole
+    trajectory; alignments are zero beyond each length and never gain mass."""
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    B, steps = 128, 500
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, seed=0)
+    rng = np.random.default_rng(2)
+    lens = rng.integers(32, 257, B).astype(np.int32)
+    lens[5], lens[6] = 256, 32
+    Tv = int(lens.max())
+    tokens, _ = synthetic.make_tokens(rng, B, Tv, lengths=lens)
+    ml = rng.integers(128, 513, B).astype(np.int32)
+    Tref = int(ml.max())
+    mels, ml = synthetic.make_ref_mels(rng, B, Tref, lengths=ml)
+    masks, noise = synthetic.make_randomness(rng, steps, B, Tv, [256, 256])
+    m = _model(hp, w, B, Tv, Tref + 1)
+    mel, stop, _, align = m.Inference_Step(tokens, lens, None, mels, ml, prenet_masks=masks, attn_noise=noise, masked=True)
+    torch.cuda.synchronize()
+    mel, stop, align = mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy()
+    assert mel.shape == (B, 1000, 80) and stop.shape == (B, 500) and align.shape == (B, 500, Tv)
+    assert np.isfinite(mel).all() and align.min() >= 0.0
+    for b in range(B):
+        assert not align[b][:, lens[b]:].any()
+    mass = align.sum(-1)
+    assert np.all(mass[:, 0] <= 1.0 + 1e-5) and np.all(np.diff(mass, axis=1) <= 1e-5)
+    for b in (5, 6, 64, 127):
+        n = int(lens[b])
+        one = m.Inference_Step(tokens[b:b + 1, :n], None, None, mels[b:b + 1], ml[b:b + 1], prenet_masks=masks[:, :, b:b + 1],
+                               attn_noise=np.ascontiguousarray(noise[:, b:b + 1, :n]))
+        torch.cuda.synchronize()
+        e_mel = np.abs(one[0].cpu().numpy()[0] - mel[b]).max()
+        e_al = np.abs(one[3].cpu().numpy()[0] - align[b][:, :n]).max()
+        print("utterance", b, "tokens", n, "alone vs in the batch of 128: mel", e_mel, "alignment", e_al)
+        assert e_mel <= TOL and e_al <= TOL, b
+
+
+def _cfg5_shard(B, seed=4):
+    """One GPU's shard of BASELINE configs[4] (SURVEY 8(d) cfg 5): Use_Mixed_Precision, Max_Step 1000, 128-token utterances,
+    7 synthetic "speakers" (seeded reference mels of 115-250 frames, about the 1.8-4.0 s of the 7 FastVox wavs at hop 256 /
+    16 kHz) assigned round-robin."""
+    from gst_tacotron_amd import synthetic, weights
+    hp = synthetic.config_hp("cfg2")
+    hp["Use_Mixed_Precision"] = True
+    w = weights.synthetic_weights(hp, seed=0)
+    rng = np.random.default_rng(seed)
+    spk_len = rng.integers(115, 251, 7)
+    spk = [np.clip(rng.normal(0.0, 1.5, (int(n), 80)), -4.0, 4.0).astype(np.float32) for n in spk_len]
+    Tref = int(spk_len.max())
+    mels = np.zeros((B, Tref + 1, 80), np.float32)
+    ml = np.zeros((B,), np.int32)
+    for b in range(B):
+        s = spk[b % 7]
+        mels[b, 1:s.shape[0] + 1] = s
+        ml[b] = s.shape[0]
+    tokens, tl = synthetic.make_tokens(rng, B, 128)
+    masks, noise = synthetic.make_randomness(rng, 500, B, 128, [256, 256])
+    return hp, w, tokens, tl, mels, ml, masks, noise
+
+
+def test_config5_shard_bf16_batch64_max_step_1000_round_robin_speakers():
+    """The configs[4] per-GPU shard at full size: bf16 mixed precision, 64 utterances, Max_Step 1000 (500 steps x r = 2), 7
+    reference mels round-robin.  Properties: shapes / finiteness / alignment invariants; utterances b and b + 7 share a
+    speaker, so their style embeddings are bitwise equal; utterance b inside the batch of 64 equals the same utterance
+    decoded alone; the mode stays within MIXED_VS_FP32-like distance of the fp32 path."""
+    import torch
+    B = 64
+    hp, w, tokens, tl, mels, ml, masks, noise = _cfg5_shard(B)
+    m = _model(hp, w, B, 128, mels.shape[1])
+    mel, stop, _, align = m.Inference_Step(tokens, None, None, mels, ml, prenet_masks=masks, attn_noise=noise)
+    torch.cuda.synchronize()
+    mel, align = mel.cpu().numpy(), align.cpu().numpy()
+    assert mel.shape == (B, 1000, 80) and stop.shape == (B, 500) and align.shape == (B, 500, 128)
+    assert np.isfinite(mel).all() and align.min() >= 0.0
+    mass = align.sum(-1)
+    assert np.all(mass[:, 0] <= 1.0 + 1e-5) and np.all(np.diff(mass, axis=1) <= 1e-5)
+    gst = m.Inference_GST_Step(mels, ml).cpu().numpy()
+    for b in range(7, B):
+        assert np.array_equal(gst[b], gst[b % 7])                  # same speaker, same style embedding
+    assert len({gst[s].tobytes() for s in range(7)}) == 7
+    worst = 0.0
+    for b in (0, 29, 63):
+        sl = slice(b, b + 1)
+        one = m.Inference_Step(tokens[sl], None, None, mels[sl], ml[sl], prenet_masks=masks[:, :, sl], attn_noise=noise[:, sl])
+        torch.cuda.synchronize()
+        d_mel = np.abs(one[0].cpu().numpy()[0] - mel[b])
+        d_al = np.abs(one[3].cpu().numpy()[0] - align[b]).max()
+        print("utterance", b, "alone vs in the batch of 64 (bf16): mel max", d_mel.max(), "mean", d_mel.mean(), "alignment", d_al)
+        worst = max(worst, d_mel.max())
+        # same per-row arithmetic in either tiling up to fp32 summation order; a flipped bf16 rounding is damped by the
+        # contractive recurrence but amplified by the postnet (see test_gpu_parity.py): the mixed tolerances apply
+        assert d_mel.max() <= MIXED_TOL and d_mel.mean() <= MIXED_MEAN and d_al <= MIXED_TOL
+    print("worst batch-vs-alone mel difference", worst)
+
+
+def test_config5_two_utterances_against_the_bf16_emulating_oracle():
+    """Two utterances of the configs[4] workload (two different speakers) over all 500 steps against the oracle that emulates
+    the bf16 operand roundings (oracle_np.inference_step(mixed=True)), with the fp32 oracle beside it."""
+    import time
+    import torch
+    from oracle import oracle_np
+    hp, w, tokens, tl, mels, ml, masks, noise = _cfg5_shard(2)
+    m = _model(hp, w, 2, 128, mels.shape[1])
+    mel, stop, _, align, pre = m.Inference_Step(tokens, None, None, mels, ml, prenet_masks=masks, attn_noise=noise,
+                                                return_pre_mel=True)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, dt=np.float64, mixed=True,
+                                   fused_prenet0=m.decode_plan(128)[1])
+    fp32 = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, dt=np.float64)
+    print("oracles: %.1f s" % (time.time() - t0))
+    mel, align, pre = mel.cpu().numpy(), align.cpu().numpy(), pre.cpu().numpy()
+    e_pre = np.abs(pre - ref[-1]["pre_mel"])
+    e_mel = np.abs(mel - ref[0])
+    e_al = np.abs(align - ref[3]).max()
+    drift = np.abs(ref[0] - fp32[0]).max()
+    print("bf16 path vs emulating oracle over 500 steps: pre-net mel max %.3g mean %.3g | mel max %.3g mean %.3g | alignment %.3g"
+          " | emulated-mixed vs fp32 oracle %.3g" % (e_pre.max(), e_pre.mean(), e_mel.max(), e_mel.mean(), e_al, drift))
+    assert mel.shape == (2, 1000, 80)
+    assert e_pre.max() <= MIXED_TOL and e_pre.mean() <= MIXED_MEAN
+    assert e_mel.max() <= MIXED_TOL and e_mel.mean() <= MIXED_MEAN and e_al <= MIXED_TOL
+    assert 0.0 < drift <= 0.25
+
+
+def test_graph_cache_is_lru_bounded_and_capture_after_matches_eager():
+    """Host robustness: the hipGraph cache keeps at most `max_cached` executables (least recently used evicted), and with
+    capture_after = 2 a shape runs eagerly at its first use and from a captured graph afterwards -- all bitwise the same."""
+    import torch
+    from test_gpu_parity import _full_case
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(3, 40, 64, 6, seed=61)
+    m = _model(hp, w, 3, 40, 65)
+    assert m.graph_cache_size() == 0
+    m.set_graph_policy(max_cached=2, capture_after=1)
+
+    def run(Tv, steps):
+        out = m.Inference_Step(tokens[:, :Tv], None, None, mels, ml, prenet_masks=masks[:steps], attn_noise=np.ascontiguousarray(noise[:steps, :, :Tv]),
+                               steps=steps)
+        torch.cuda.synchronize()
+        return out[0].cpu().numpy()
+
+    a0 = run(40, 6)
+    assert m.graph_cache_size() == 1
+    b0 = run(32, 6)
+    c0 = run(24, 5)
+    assert m.graph_cache_size() == 2                      # shape (40, 6) was evicted
+    a1 = run(40, 6)                                        # re-captured
+    assert m.graph_cache_size() == 2 and np.array_equal(a0, a1)
+    assert np.array_equal(b0, run(32, 6)) and np.array_equal(c0, run(24, 5))
+    m.set_graph_policy(max_cached=0, capture_after=1)      # no graphs at all: eager launches
+    assert m.graph_cache_size() == 0
+    assert np.array_equal(a0, run(40, 6)) and m.graph_cache_size() == 0
+    m.set_graph_policy(max_cached=4, capture_after=2)
+    e1 = run(16, 4)
+    assert m.graph_cache_size() == 0                       # first use: eager
+    e2 = run(16, 4)
+    assert m.graph_cache_size() == 1                       # second use: captured
+    assert np.array_equal(e1, e2) and np.array_equal(e2, run(16, 4))

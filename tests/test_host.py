@@ -254,3 +254,22 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GLOO_OK" in outs[0]
+
+
+def test_spawn_local_ranks_runs_the_gloo_worker_and_forwards_failures(tmp_path):
+    """bench.py --gpus N without a launcher starts its own rank processes (gst_tacotron_amd.distributed.spawn_local_ranks):
+    the same 2-rank shard + gather as above through the spawner, and a failing rank ends the job with its status."""
+    from gst_tacotron_amd.distributed import spawn_local_ranks
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    assert spawn_local_ranks(2, [sys.executable, str(script), ROOT]) == 0
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\nr = int(os.environ['RANK'])\ntime.sleep(0 if r else 60)\nsys.exit(7 if r else 0)\n")
+    assert spawn_local_ranks(2, [sys.executable, str(bad)]) == 7
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE is 4" in r.stderr and not r.stdout.strip()
