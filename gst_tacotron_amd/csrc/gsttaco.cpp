@@ -95,11 +95,20 @@ struct gsttaco_ctx {
     PackedLinear prenet0, prenet1, query, val_gst, lstm0, lstm1, proj;
     PackedLinear lstm_x[2], lstm_h[2];   // split packs: input half (critical path) / recurrent half + bias (front-kernel workers)
     float* w_part[2] = {nullptr, nullptr};
+    // merged "projection + front + recurrent halves" launch (kernels.h DecMergedArgs): K-slice slabs, z0 granules, second
+    // [prenet | context] buffer (the front end of step t writes it while the projection of step t-1 still reads the other)
+    float* w_slab[2] = {nullptr, nullptr};
+    GtGranule* w_z0g = nullptr;
+    uint32_t* w_err = nullptr;
+    float* w_xa2 = nullptr;
     bool split_rec = true;
     int keep_x_weights = 1;
     int co_tiles = 64;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
+    bool proj_helps = true;      // merged launch: projection workgroups take recurrent-half jobs after publishing (GSTTACO_PROJ_HELPS=0 off)
+    bool co_lstm2 = false;       // merged plan: layer 1's recurrent half computed by the layer-2 LSTM launch (GSTTACO_CO_LSTM2=0 off)
+    int worker_delay = 300;      // merged launch: the pure workers start this many 100 MHz ticks after it (GSTTACO_WORKER_DELAY)
     bool keep_hash = true;       // GSTTACO_KEEP_HASH=0: the front kernel reads the generated masks from HBM like injected ones
     bool lean = true;            // lean_body.h kernels for the decode shapes they cover (GSTTACO_LEAN=0: general kernels only)
 
@@ -677,6 +686,16 @@ int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
     return 0;
 }
 
+// Is the 3-launch decode step (merged projection + front + recurrent halves, kernels.h DecMergedArgs) used for this shape?
+bool merged_plan(const gsttaco_ctx* c, int B, int Tv) {
+    const gsttaco_config& g = c->cfg;
+    if (!(c->fused_front && c->split_rec && c->lean && c->fuse_prenet0 && c->keep_x_weights) || g.att_type == GSTTACO_ATT_LSA) return false;
+    if (c->proj_z.wp == nullptr || c->proj_z.bf16 || c->lstm_h[0].bf16 || c->lstm_x[0].bf16) return false;
+    if (!gt_lstm_x_supported(c->lstm_x[0].nkb) || !gt_lstm_x_supported(c->lstm_x[1].nkb)) return false;
+    if (c->lstm_h[0].nkb != 64 || c->lstm_h[1].nkb != 64) return false;
+    return gt_dec_merged_supported(g.mel_dim, c->P0, c->P1, c->att, Tv, B, c->proj_z.nkb, c->H1, c->H2);
+}
+
 int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool has_mask, bool has_noise, bool masked) {
     const int32_t* tlen = masked ? c->w_tok_len : nullptr;
     const gsttaco_config& g = c->cfg;
@@ -692,6 +711,13 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     if (g.att_type == GSTTACO_ATT_LSA) HIPCHECK(c, gt_launch_zero(c->w_lsa_state, (size_t)B * Tv, s));   // Layers.py:356
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
+    // merged launch (3 launches per step): fp32 lean shapes, B <= 32, prenet 0 folded into the projection
+    const bool merged_ok = merged_plan(c, B, Tv);
+    if (merged_ok) {
+        // tags of an earlier call must not match this call's step numbers
+        HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_z0g), (size_t)MT * 16 * P0 * 2, s));
+        HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_err), 4, s));
+    }
     // throughput mode: the whole decode's dropout masks and sigmoid noise are generated up front (same Philox streams the
     // step kernels would draw) into the buffers injected tensors use, so no step spends time on random numbers
     const bool injected_mask = has_mask;
@@ -731,7 +757,59 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         const bool fused = c->fused_front && g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv);
         const bool split = fused && c->split_rec;
         const bool use_z0 = split && c->proj_z.wp != nullptr;        // prenet-0 rides in the projection launch
-        if (fused) {
+        const bool merged = merged_ok && t > 0;
+        // [prenet | context] of step t: ping-pong when the merged launch is in use (see w_xa2)
+        float* xa_t = merged_ok ? ((t & 1) ? c->w_xa2 : c->w_xa) : c->w_xa;
+        float* xa_prev = merged_ok ? ((t & 1) ? c->w_xa : c->w_xa2) : c->w_xa;
+        if (merged) {
+            DecMergedArgs m{};
+            const PackedLinear& PJ = c->proj_z;
+            m.n_proj = PJ.ntiles * MT; m.B = B;
+            m.n_workers = std::max(1, c->n_cu - m.n_proj - B);
+            m.proj = ProjArgs{PJ.wp, PJ.bias, c->w_h2[p ^ 1], xa_prev + (size_t)(P1 / 16) * BLK, H2 / 16, B, MT, c->z_col0 + P0, mel * r,
+                              c->proj_out, c->z_col0, c->w_pre + (size_t)(t - 1) * r * mel, ld_pre, c->w_stop + (t - 1), (int64_t)steps,
+                              nullptr, 0, (c->stamps && t == steps / 2) ? c->w_dbg + 40 : nullptr};
+            m.proj_nkb = PJ.nkb;
+            m.z0g = c->w_z0g;
+            FrontLeanArgs& f = m.front;
+            f.w1 = c->pw1; f.b1 = c->pb1; f.wq = c->pwq; f.bq = c->pbq;
+            f.mask0 = mask0; f.mask1 = mask1; f.keep_hash = 0;
+            if (!injected_mask && g.prenet_rate == 0.5f && c->keep_hash) { f.mask0 = f.mask1 = nullptr; f.keep_hash = 1; }
+            f.pm = c->w_pm; f.v = c->att_v; f.score_bias = c->att_sb;
+            f.prev = c->w_align + (size_t)(t - 1) * Tv; f.ldprev = (int64_t)steps * Tv;
+            f.noise = has_noise ? c->w_noise + (size_t)t * B * Tv : nullptr; f.ldnoise = Tv;
+            f.align = c->w_align + (size_t)t * Tv; f.ldalign = (int64_t)steps * Tv;
+            f.xa = xa_t; f.seed_ptr = c->w_seed; f.tok_len = tlen;
+            f.dbg = (c->stamps && t == steps / 2) ? c->w_dbg : nullptr;
+            f.z0g = c->w_z0g; f.err = c->w_err;
+            f.MT = MT; f.B = B; f.Tv = Tv; f.mel = mel; f.P0 = P0; f.P1 = P1; f.type = g.att_type;
+            f.rng_step = (uint32_t)t; f.tag = (uint32_t)t;
+            f.drop_rate = g.prenet_rate; f.drop_scale = drop_scale; f.sigmoid_noise = g.sigmoid_noise;
+            KSliceArgs& w = m.work;
+            for (int layer = 0; layer < 2; ++layer) {
+                const PackedLinear& L = c->lstm_h[layer];
+                w.wp[layer] = L.wp; w.bias[layer] = L.bias; w.ntiles[layer] = L.ntiles;
+                w.x[layer] = layer == 0 ? c->w_h1[p ^ 1] : c->w_h2[p ^ 1];
+                w.out[layer] = c->w_slab[layer];
+            }
+            w.MT = MT;
+            // layer 1's recurrent half rides in the previous step's layer-2 LSTM launch (same input h1, LstmXArgs::wp_co)
+            w.first_layer = c->co_lstm2 ? 1 : 0;
+            const int nlay = 2 - w.first_layer;
+            const int ntl = std::max(w.ntiles[0], w.ntiles[1]);
+            w.proj_helps = c->proj_helps ? 1 : 0;
+            const int slots = m.n_workers + (w.proj_helps ? m.n_proj : 0);
+            const int want = std::max(1, slots / (4 * nlay));              // jobs per (layer, slice) if every taker gets one
+            w.tiles_per_job = std::min(16, std::max(1, (ntl + want - 1) / want));
+            if (const char* e = getenv("GSTTACO_TILES_PER_JOB")) w.tiles_per_job = std::min(16, std::max(1, atoi(e)));
+            w.jobs_per_ls = (ntl + w.tiles_per_job - 1) / w.tiles_per_job;
+            w.n_jobs = nlay * 4 * w.jobs_per_ls;
+            if (getenv("GSTTACO_DEBUG_NO_WORKERS")) w.n_jobs = 0;          // timing experiments only: results are WRONG
+            w.start_delay = c->worker_delay;
+            if (prof) { int rce = prof_begin(2); if (rce) return rce; }
+            HIPCHECK(c, gt_launch_dec_merged(m, s));
+            if (prof) { int rce = prof_end(2); if (rce) return rce; }
+        } else if (fused) {
             // 1-4 fused: prenet x2, query projection, score / alignment / context (dec_front.hip)
             DecFrontArgs f{};
             f.frame = frame_ptr; f.ldframe = frame_ld;
@@ -749,7 +827,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             f.prev = t == 0 ? nullptr : c->w_align + (size_t)(t - 1) * Tv; f.ldprev = (int64_t)steps * Tv;
             f.noise = has_noise ? c->w_noise + (size_t)t * B * Tv : nullptr; f.ldnoise = Tv;
             f.align = c->w_align + (size_t)t * Tv; f.ldalign = (int64_t)steps * Tv;
-            f.xa = c->w_xa; f.MT = MT;
+            f.xa = xa_t; f.MT = MT;
             f.B = B; f.Tv = Tv; f.mel = mel; f.P0 = P0; f.P1 = P1; f.A = att; f.type = g.att_type;
             f.sigmoid_noise = g.sigmoid_noise;
             f.tok_len = tlen;
@@ -768,6 +846,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 }
                 // one worker workgroup per compute unit the utterance workgroups leave free (a quarter of the chip at least)
                 f.n_workers = B < c->n_cu * 3 / 4 ? c->n_cu - B : c->n_cu / 4;
+                if (getenv("GSTTACO_DEBUG_NO_WORKERS")) f.n_workers = 0;      // timing experiments only: results are WRONG
                 f.worker_tiles = c->worker_tiles;
                 f.lean_rec = (c->lean && f.rec[0].bf16 == f.rec[1].bf16 && f.rec[0].nkb == 64 && f.rec[1].nkb == 64) ? (f.rec[0].bf16 ? 2 : 1) : 0;
                 for (int layer = 0; layer < 2; ++layer)
@@ -794,7 +873,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         k.wp = c->prenet1.wp; k.bf16 = c->prenet1.bf16; k.bias = c->prenet1.bias;
         k.seg[0] = SkinnySeg{c->w_p1, P0, P0 / 16, 0};
         k.nkb = c->prenet1.nkb; k.M = B; k.N = P1; k.n_split = P1; k.MT = MT;
-        k.out = c->w_xa; k.out_blocked = 1;
+        k.out = xa_t; k.out_blocked = 1;
         k.mask = mask1; k.ldm = P1;
         k.drop_rate = g.prenet_rate; k.drop_scale = drop_scale;
         k.seed_ptr = c->w_seed; k.rng_step = (uint32_t)t; k.rng_stream = 0x1001u;
@@ -802,7 +881,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         // 3. attention query projection (Steps.py:122)
         memset(&k, 0, sizeof(k));
         k.wp = c->query.wp; k.bf16 = c->query.bf16; k.bias = c->query.bias;
-        k.seg[0] = SkinnySeg{c->w_xa, 0, P1 / 16, 1};
+        k.seg[0] = SkinnySeg{xa_t, 0, P1 / 16, 1};
         k.nkb = c->query.nkb; k.M = B; k.N = att; k.n_split = att; k.MT = MT;
         k.out = c->w_q; k.ldo = att;
         HIPCHECK(c, launch_skinny(c, EPI_LINEAR, k, nullptr, c->query.ntiles, s));
@@ -812,7 +891,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         a.prev = t == 0 ? nullptr : c->w_align + (size_t)(t - 1) * Tv; a.ldprev = (int64_t)steps * Tv;
         a.noise = has_noise ? c->w_noise + (size_t)t * B * Tv : nullptr; a.ldnoise = Tv;
         a.align = c->w_align + (size_t)t * Tv; a.ldalign = (int64_t)steps * Tv;
-        a.ctx = c->w_xa + (size_t)(P1 / 16) * BLK; a.ldctx = 0; a.ctx_mt = MT;
+        a.ctx = xa_t + (size_t)(P1 / 16) * BLK; a.ldctx = 0; a.ctx_mt = MT;
         a.B = B; a.Tv = Tv; a.A = att; a.type = g.att_type; a.sigmoid_noise = g.sigmoid_noise;
         a.seed_ptr = c->w_seed; a.rng_step = (uint32_t)t; a.tok_len = tlen;
         a.loc_cw = c->loc_cw; a.loc_cb = c->loc_cb; a.loc_dw = c->loc_dw; a.loc_db = c->loc_db; a.att_bias = c->att_bias;
@@ -829,15 +908,15 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 // only the half that depends on this step's inputs; + partial_in (recurrent half + bias)
                 const PackedLinear& L = c->lstm_x[layer];
                 k.wp = L.wp; k.bf16 = L.bf16; k.bias = L.bias; k.nkb = L.nkb;
-                if (layer == 0) k.seg[0] = SkinnySeg{c->w_xa, 0, XA / 16, 1};
+                if (layer == 0) k.seg[0] = SkinnySeg{xa_t, 0, XA / 16, 1};
                 else k.seg[0] = SkinnySeg{c->w_h1[p], 0, H1 / 16, 1};
-                k.partial_in = c->w_part[layer];
+                k.partial_in = merged ? c->w_slab[layer] : c->w_part[layer];
                 k.keep_weights = c->keep_x_weights;
             } else {
                 const PackedLinear& L = layer == 0 ? c->lstm0 : c->lstm1;
                 k.wp = L.wp; k.bf16 = L.bf16; k.bias = L.bias; k.nkb = L.nkb;
                 if (layer == 0) {
-                    k.seg[0] = SkinnySeg{c->w_xa, 0, XA / 16, 1};
+                    k.seg[0] = SkinnySeg{xa_t, 0, XA / 16, 1};
                     k.seg[1] = SkinnySeg{c->w_h1[p ^ 1], 0, H1 / 16, 1};
                 } else {
                     k.seg[0] = SkinnySeg{c->w_h1[p], 0, H1 / 16, 1};
@@ -849,18 +928,29 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             k.dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
             if (prof) { int rce = prof_begin(layer); if (rce) return rce; }
             if (split && c->lean && c->keep_x_weights && gt_lstm_x_supported(k.nkb)) {
-                LstmXArgs la{k.wp, k.seg[0].ptr, k.partial_in, k.c, k.h, nullptr, k.dbg, B, MT, H, 0, k.nkb};
+                // merged plan with co_lstm2: layer 1 takes the old-layout partial the previous step's layer-2 launch wrote,
+                // layer 2 the workers' slabs and (not at the last step) produces layer 1's partial for the next step
+                const bool co = merged_ok && c->co_lstm2;
+                LstmXArgs la{k.wp, k.seg[0].ptr, k.partial_in, k.c, k.h, nullptr, k.dbg, B, MT, H, 0, k.nkb, merged ? 4 : 0,
+                             nullptr, nullptr, nullptr};
+                if (co && layer == 0 && merged) { la.partial_in = c->w_part[0]; la.nslab = 0; }
+                if (co && layer == 1 && t + 1 < steps) { la.wp_co = c->lstm_h[0].wp; la.bias_co = c->lstm_h[0].bias; la.partial_out = c->w_part[0]; }
                 HIPCHECK(c, gt_launch_lstm_x(la, k.nkb, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2, k.bf16 != 0, s));
             } else
             HIPCHECK(c, launch_skinny(c, EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));
             if (prof) { int rce = prof_end(layer); if (rce) return rce; }
         }
         // 7. projection [h2, ctx] -> r mel frames + stop logit, written in place (Taco2.py:112-118,194-205)
+        if (prof) {     // empty bracket
+            int rce = prof_begin(4); if (rce) return rce;
+            rce = prof_end(4); if (rce) return rce;
+        }
+        if (merged_ok && t + 1 < steps) continue;       // it runs inside the NEXT step's merged launch
         memset(&k, 0, sizeof(k));
         const PackedLinear& PJ = (use_z0 && t + 1 < steps) ? c->proj_z : c->proj;
         k.wp = PJ.wp; k.bf16 = PJ.bf16; k.bias = PJ.bias;
         k.seg[0] = SkinnySeg{c->w_h2[p], 0, H2 / 16, 1};
-        k.seg[1] = SkinnySeg{c->w_xa + (size_t)(P1 / 16) * BLK, 0, att / 16, 1};
+        k.seg[1] = SkinnySeg{xa_t + (size_t)(P1 / 16) * BLK, 0, att / 16, 1};
         k.nkb = PJ.nkb; k.M = B; k.N = c->proj_out; k.n_split = mel * r; k.MT = MT;
         if (&PJ == &c->proj_z) {
             k.N = c->z_col0 + P0; k.n_valid2 = c->proj_out; k.col3 = c->z_col0;
@@ -892,10 +982,6 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             HIPCHECK(c, launch_skinny(c, EPI_LINEAR, k, nullptr, PJ.ntiles, s));
         }
         if (prof) { int rce = prof_end(3); if (rce) return rce; }
-        if (prof) {     // empty bracket
-            int rce = prof_begin(4); if (rce) return rce;
-            rce = prof_end(4); if (rce) return rce;
-        }
     }
     if (c->prof_every > 0)      // an un-bracketed capture must not forget the brackets of an earlier, bracketed graph
         for (int i = 0; i < 5; ++i) c->prof_count[i] = nprof[i];
@@ -1275,6 +1361,9 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     if (const char* e = getenv("GSTTACO_GRAPH_CACHE")) c->graph_cache_max = std::max(0, atoi(e));
     if (const char* e = getenv("GSTTACO_GRAPH_CAPTURE_AFTER")) c->graph_capture_after = std::max(1, atoi(e));
     if (const char* e = getenv("GSTTACO_KEEP_HASH")) c->keep_hash = e[0] != '0';
+    if (const char* e = getenv("GSTTACO_WORKER_DELAY")) c->worker_delay = std::max(0, atoi(e));
+    if (const char* e = getenv("GSTTACO_CO_LSTM2")) c->co_lstm2 = e[0] != '0';
+    if (const char* e = getenv("GSTTACO_PROJ_HELPS")) c->proj_helps = e[0] != '0';
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);
@@ -1587,6 +1676,14 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     }
     if ((rc = fa(&c->w_part[0], Bp * 4 * c->H1))) return rc;
     if ((rc = fa(&c->w_part[1], Bp * 4 * c->H2))) return rc;
+    if ((rc = fa(&c->w_slab[0], 4 * Bp * 4 * c->H1))) return rc;
+    if ((rc = fa(&c->w_slab[1], 4 * Bp * 4 * c->H2))) return rc;
+    if ((rc = fa(&c->w_xa2, Bp * (c->P1 + c->att)))) return rc;
+    HIPCHECK(c, hipMemset(c->w_xa2, 0, Bp * (c->P1 + c->att) * sizeof(float)));
+    if ((rc = dev_alloc(c, (void**)&c->w_z0g, Bp * c->P0 * sizeof(GtGranule)))) return rc;
+    HIPCHECK(c, hipMemset(c->w_z0g, 0, Bp * c->P0 * sizeof(GtGranule)));
+    if ((rc = dev_alloc(c, (void**)&c->w_err, 16))) return rc;
+    HIPCHECK(c, hipMemset(c->w_err, 0, 16));
     if ((rc = fa(&c->w_c1, B * c->H1))) return rc;
     if ((rc = fa(&c->w_c2, B * c->H2))) return rc;
     if ((rc = fa(&c->w_pre, B * Tf * mel))) return rc;
@@ -1913,6 +2010,13 @@ int gsttaco_debug_randomness(gsttaco_ctx* c, float* host_masks, float* host_nois
     return 0;
 }
 
+int gsttaco_debug_handoff_error(gsttaco_ctx* c, uint32_t* host_out) {
+    if (!c || !host_out || !c->w_err) return GSTTACO_E_INVALID;
+    HIPCHECK(c, hipDeviceSynchronize());
+    HIPCHECK(c, hipMemcpy(host_out, c->w_err, 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int gsttaco_decode_plan(const gsttaco_ctx* c, int Tv, int32_t plan[3]) {
     if (!c || !plan || Tv < 1) return GSTTACO_E_INVALID;
     const gsttaco_config& g = c->cfg;
@@ -1941,10 +2045,13 @@ int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int which, int B) {
             return fused ? gemm(H1, 4 * H2, 4 * H2 + 3 * H2) : gemm(H1 + H2, 4 * H2, 3 * H2);
         case 2: {   // front: prenet x2 + query weights, processed memory, alignments; + workers' recurrent halves
             int64_t b = 4 * (mel * P0 + P0 + P0 * P1 + P1 + P1 * A + A) + 4 * (int64_t)B * (Tv * A + mel + 2 * Tv + P1 + A);
+            if (merged_plan(c, B, (int)Tv))     // merged launch: + the projection of the previous step and ALL recurrent tiles
+                return b + gemm(H2 + A, c->proj_out + P0, c->proj_out + P0) + gemm(H1, 4 * H1, 4 * H1) + gemm(H2, 4 * H2, 4 * H2);
             if (fused) b += gemm(H1, 4 * H1, 4 * H1) + (ntile2 - co_tiles) * (4 * (H2 * 16 + 16) + 4 * (int64_t)B * 16) + 4 * (int64_t)B * H2;
             return b;
         }
         default: {  // projection (+ co-scheduled layer-2 recurrent tiles)
+            if (merged_plan(c, B, (int)Tv)) return 0;      // inside the merged launch (which = 2)
             int64_t b = gemm(H2 + A, c->proj_out, c->proj_out);
             if (fused) b += co_tiles * (4 * (H2 * 16 + 16) + 4 * (int64_t)B * 16);
             return b;

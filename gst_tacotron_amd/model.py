@@ -312,6 +312,12 @@ class GST_Tacotron:
         batch shapes vary from call to call (the reference's Feeder pads to the batch maximum, Feeder.py:175-180)."""
         self.ctx.check(self.ctx.lib.gsttaco_set_graph_policy(self.ctx.handle, int(max_cached), int(capture_after)))
 
+    def handoff_error(self):
+        """1 if an in-kernel hand-off wait of the experimental merged decode launch gave up in the last call (test support)."""
+        out = ctypes.c_uint32(0)
+        self.ctx.check(self.ctx.lib.gsttaco_debug_handoff_error(self.ctx.handle, ctypes.byref(out)))
+        return int(out.value)
+
     def graph_cache_size(self):
         return int(self.ctx.lib.gsttaco_graph_cache_size(self.ctx.handle))
 

@@ -249,6 +249,9 @@ int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
 /* Diagnostic (GSTTACO_STAMPS=1): 3 x 16 phase stamps (100 MHz ticks) of workgroup 0 of the fused front kernel
  * and the two decode LSTM kernels at the middle decode step of the last replay.  Synchronises the device. */
 int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
+/* Test support (experimental three-launch decode step, GSTTACO_MERGED=1): 1 if an in-kernel wait for the projection's
+ * granules ever gave up in the last decode (a bug, never a normal outcome), else 0.  Synchronises the device. */
+int gsttaco_debug_handoff_error(gsttaco_ctx* ctx, uint32_t* host_out);
 /* Test support: the prenet keep-masks [steps][mask0 B*P0 | mask1 B*P1] (0/1) and SMA noise [steps][B][Tv] the LAST
  * gsttaco_inference_step / gsttaco_decode of that shape used -- generated from the seed in throughput mode, or the
  * injected tensors -- copied to HOST buffers (either may be NULL).  Synchronises the device. */

@@ -162,6 +162,42 @@ def test_eager_graph_and_unfused_paths_agree(monkeypatch):
     assert np.abs(outs[0][0] - outs[2][0]).max() <= TOL and np.abs(outs[0][1] - outs[2][1]).max() <= TOL
 
 
+@pytest.mark.parametrize("env", [{"GSTTACO_FRONT_LEAN": "0"}, {"GSTTACO_MERGED": "1"}, {"GSTTACO_MERGED": "1", "GSTTACO_CO_LSTM2": "1"},
+                                 {"GSTTACO_MERGED": "1", "GSTTACO_PROJ_HELPS": "0", "GSTTACO_WORKER_DELAY": "0"}])
+@pytest.mark.parametrize("att", ["SMA", "BMA"])
+def test_front_end_variants_match_oracle(monkeypatch, env, att):
+    """The decode step exists in variants that must all be the same function: the general fused front kernel vs the lean one
+    (front_lean.h, buffer loads with counted waits; the default), and the experimental three-launch step (GSTTACO_MERGED=1:
+    projection of step t-1 + front end of step t + recurrent halves in ONE launch, prenet-0 pre-activations handed over as
+    tagged granules; optionally layer 1's recurrent half fused into the layer-2 LSTM launch).  Each against the float64
+    oracle over 40 steps at full dimensions, injected and hashed (throughput-mode) dropout, 5 and 32 utterances; and the
+    hand-off's give-up flag must stay clear."""
+    import torch
+    from oracle import oracle_np
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for B in (5, 32):
+        steps, Tv, Tref = 40, 48, 80
+        hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=71 + B, att=att)
+        m = _model(hp, w, B, Tv, Tref + 1)
+        mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps)
+        torch.cuda.synchronize()
+        ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
+        assert np.abs(mel.cpu().numpy() - ref[0]).max() <= TOL
+        assert np.abs(stop.cpu().numpy() - ref[1]).max() <= TOL
+        assert np.abs(align.cpu().numpy() - ref[3]).max() <= TOL
+        # throughput mode: masks / noise from the seed, read back and fed to the oracle
+        mel2, _, _, align2 = m.Inference_Step(tokens, tl, None, mels, ml, seed=99, steps=steps)
+        torch.cuda.synchronize()
+        mk, nz = m.debug_randomness(steps, B, Tv)
+        from gst_tacotron_amd import hparams
+        ref2 = oracle_np.inference_step(hp, w, tokens, mels, ml, mk, nz if hparams.attention_sigmoid_noise(hp) > 0 else None,
+                                        steps=steps, dt=np.float64)
+        assert np.abs(mel2.cpu().numpy() - ref2[0]).max() <= TOL
+        assert np.abs(align2.cpu().numpy() - ref2[3]).max() <= TOL
+        assert m.handoff_error() == 0
+
+
 @pytest.mark.parametrize("mixed,B", [(False, 5), (True, 5), (False, 37), (True, 37)])
 def test_lean_and_general_decode_kernels_are_the_same_arithmetic(monkeypatch, mixed, B):
     """csrc/lean_body.h restates the general skinny GEMM body for the decode shapes with K fixed at compile time: same
