@@ -75,7 +75,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # GSTTACO_LIB: an alternative build of the same ABI (A/B timing of two builds on one GPU box; tools/ab.sh)
+    p = path or os.environ.get("GSTTACO_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise ImportError(
             "{} not found: build the HIP extension first (python -m gst_tacotron_amd.build). "
