@@ -276,9 +276,9 @@ def main():
     # per-kernel timing of the decode step: HIP event-record nodes inside the replayed graph (on the stream the
     # kernels run on), every PROFILE_EVERY-th decode step of the last timed replay
     KNAMES = {0: "gt_lstm_x_kernel<8,3> LSTM layer 1 (input half + gates)", 1: "gt_lstm_x_kernel<8,8> LSTM layer 2 (input half + gates)",
-              2: "gt_dec_front_kernel (prenet + query + attention per utterance; workers: recurrent halves W_h.h+b)",
+              2: "gt_dec_front_lean_kernel (prenet + query + attention per utterance; workers: recurrent halves W_h.h+b)",
               3: "gt_proj_lean_kernel (projection + next prenet-0; workers: layer-2 recurrent half)"}
-    KPMC = {0: "gt_lstm_x_kernel<8, 3, 1", 1: "gt_lstm_x_kernel<8, 8, 2", 2: "gt_dec_front_kernel<8, 4, true", 3: "gt_proj_lean_kernel"}
+    KPMC = {0: "gt_lstm_x_kernel<8, 3, 1", 1: "gt_lstm_x_kernel<8, 8, 2", 2: "gt_dec_front_lean_kernel<8, 4, 1", 3: "gt_proj_lean_kernel"}
     prof = {}
     for which in range(4):
         ms, cnt = ctypes.c_float(), ctypes.c_int()

@@ -56,5 +56,5 @@ for name in ("bench_trace.log",):
             open(os.path.join(summ, f"{tag}_bench_under_rocprof.json"), "w").write(line)
 if stats:
     print(open(os.path.join(summ, f"{tag}_kernel_stats.csv")).read()[:3000])
-print(json.dumps({k: v for k, v in res.items() if "skinny" in k or "front" in k}, indent=1)[:3000])
+print(json.dumps({k: v for k, v in res.items() if "skinny" in k or "front" in k or "lstm" in k or "proj" in k}, indent=1)[:3000])
 print(json.dumps({k[:50]: v for k, v in util.items() if v["mfma_util"]}, indent=1)[:3000])
