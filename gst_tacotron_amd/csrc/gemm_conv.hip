@@ -313,6 +313,172 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- Winograd F(2, 5)
+// Conv1D(k = 5, stride 1, SAME) as the minimal-filtering algorithm F(2, 5): two outputs from six inputs with 6
+// multiplications per (input channel, output channel) instead of 10, i.e. 0.6x the MFMAs of the implicit GEMM above for the
+// same result (fp32 throughout; Cook-Toom points 0, +-1, +-1/2, infinity).  For a tile p (outputs t = 2p, 2p + 1; inputs
+// d_i = x[2p - 2 + i], i = 0..5):
+//     V_xi = sum_i BT[xi][i] d_i          (input transform, on the fly in the A gather: 3-4 rows per element)
+//     M_xi = V_xi . U_xi                  (six GEMMs over the input channels, U_xi = sum_k G[xi][k] w[k], formed in float64
+//                                          at finalize)
+//     y_0 = sum_xi M_xi (xi < 5),   y_1 = M_1 - M_2 + (M_3 - M_4) / 2 + M_5
+// One workgroup owns 64 tiles (128 output rows) x 128 columns; the six GEMMs run one after the other on ONE accumulator set
+// which is folded into the two output accumulators after each (V never touches memory, no cross-workgroup reduction).
+// Measured error on the postnet's shapes: 2-3.6e-6 max-abs at |y| ~ 3 (the direct fp32 sum: 1.1e-6) -- tools/wino_error.py.
+// Applies to: taps == 5, pad_before == 2, Cin % 32 == 0, no pooling, no 2-D mode.
+template <int XI>
+struct WinoRow {                                   // compile-time rows of BT / AT
+    static constexpr float bt(int i) {
+        constexpr float t[6][6] = {{0.25f, 0.f, -1.25f, 0.f, 1.f, 0.f},   {0.f, -0.25f, -0.25f, 1.f, 1.f, 0.f},
+                                   {0.f, 0.25f, -0.25f, -1.f, 1.f, 0.f},  {0.f, -0.5f, -1.f, 0.5f, 1.f, 0.f},
+                                   {0.f, 0.5f, -1.f, -0.5f, 1.f, 0.f},    {0.f, 0.25f, 0.f, -1.25f, 0.f, 1.f}};
+        return t[XI][i];
+    }
+    static constexpr float at0() { return XI < 5 ? 1.f : 0.f; }
+    static constexpr float at1() { return XI == 0 ? 0.f : XI == 1 ? 1.f : XI == 2 ? -1.f : XI == 3 ? 0.5f : XI == 4 ? -0.5f : 1.f; }
+};
+
+#define GT_WINO_OOB 0x80000000u
+#define WT 512             // threads: 8 waves as 2 (tile rows) x 4 (columns), each a 32 x 32 MFMA tile
+
+// One slice (32 input channels) of the transform-domain GEMM XI: this thread's A element (tile row f >> 3, channel quad f & 7)
+// = sum of 3-4 input rows, and its two B pieces of U_XI.  Every gather load is an unconditional buffer load: a row outside
+// [0, len) gets an out-of-range offset and reads as zero (SAME padding / masked mode) -- no branches, so all taps are in
+// flight together and counted exactly.
+template <int XI>
+__device__ __forceinline__ void wino_load_slice(const ConvGemmArgs& A, __amdgpu_buffer_rsrc_t rs_x, const float* __restrict__ U, const uint32_t voff,
+                                                const int first, const int len, const int c0, const int n0, float4& ra, float4& rb0, float4& rb1) {
+    const int tid = threadIdx.x;
+    float4 d[6];
+#pragma unroll
+    for (int tap = 0; tap < 6; ++tap) {
+        if (WinoRow<XI>::bt(tap) != 0.f) {
+            const int ts = first + tap;
+            const uint32_t vo = (ts >= 0 && ts < len) ? voff + (uint32_t)(tap * A.Cin * 4) : GT_WINO_OOB;
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo, c0 * 4, 0);
+            __builtin_memcpy(&d[tap], &t, 16);
+        }
+    }
+    const float* Ux = U + (size_t)XI * A.Cin * A.N;
+    {
+        // 32 k rows x 32 float4 (128 columns): this thread's pieces are rows tid >> 5 and 16 + (tid >> 5), quad tid & 31
+        const int kr = tid >> 5, nq = tid & 31;
+        const int n = min(n0 + nq * 4, A.N - 4);       // (columns past N are never stored)
+        rb0 = *reinterpret_cast<const float4*>(Ux + (size_t)(c0 + kr) * A.N + n);
+        rb1 = *reinterpret_cast<const float4*>(Ux + (size_t)(c0 + 16 + kr) * A.N + n);
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int tap = 0; tap < 6; ++tap) {
+        const float cf = WinoRow<XI>::bt(tap);
+        if (cf != 0.f) { v.x += cf * d[tap].x; v.y += cf * d[tap].y; v.z += cf * d[tap].z; v.w += cf * d[tap].w; }
+    }
+    ra = v;
+}
+
+__global__ __launch_bounds__(WT, 4) void gt_conv_wino5_kernel(ConvGemmArgs A, const float* __restrict__ U) {
+    constexpr int BMP = 64, BN = 128, LDA = BMP + 1, LDB = BN + 4;
+    __shared__ float As[BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int Pu = (A.T + 1) >> 1;                       // tiles per utterance
+    const int Ptot = A.B * Pu;
+    const int p0 = blockIdx.x * BMP, n0 = blockIdx.y * BN;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x), 0, (int)((size_t)A.B * A.T * A.Cin * 4), 0x00020000);
+    // this thread's A element: tile row tid >> 3, channel quad tid & 7
+    int first, len;
+    uint32_t voff;
+    {
+        const int p = p0 + (tid >> 3);
+        const bool ok = p < Ptot;
+        const int pp = ok ? p : 0;
+        const int b = pp / Pu;
+        first = 2 * (pp - b * Pu) - 2;
+        len = ok ? (A.row_len ? min(A.T, A.row_len[b]) : A.T) : 0;      // a tile past the end reads nothing
+        // (the first rows of utterance 0 give a negative row index: those taps are out of range anyway, the wrapped offset is unused)
+        voff = (uint32_t)(((int64_t)b * A.T + first) * A.Cin + (tid & 7) * 4) * 4u;
+    }
+    f32x16 M, Y0, Y1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { Y0[e] = 0.f; Y1[e] = 0.f; }
+    float4 ra, rb0, rb1;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int nsl = A.Cin / BK;
+
+    auto store_slice = [&]() {
+        const int row = tid >> 3, kq = (tid & 7) * 4;
+        As[(kq + 0) * LDA + row] = ra.x;
+        As[(kq + 1) * LDA + row] = ra.y;
+        As[(kq + 2) * LDA + row] = ra.z;
+        As[(kq + 3) * LDA + row] = ra.w;
+        *reinterpret_cast<float4*>(&Bs[(tid >> 5) * LDB + (tid & 31) * 4]) = rb0;
+        *reinterpret_cast<float4*>(&Bs[(16 + (tid >> 5)) * LDB + (tid & 31) * 4]) = rb1;
+    };
+    auto mma_slice = [&]() {
+#pragma unroll 4
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            const int krow = kp * 2 + kh;
+            const float av = As[krow * LDA + wm * 32 + l31];
+            const float bv = Bs[krow * LDB + wn * 32 + l31];
+            M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, M, 0, 0, 0);
+        }
+    };
+    // the six transform-domain GEMMs, one after the other; the NEXT slice (possibly the next GEMM's first) is requested
+    // before the current slice's MFMAs
+#define WINO_PASS(XI, XN)                                                                                    \
+    {                                                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) M[e] = 0.f;                                            \
+        for (int s = 0; s < nsl; ++s) {                                                                      \
+            __syncthreads();                                                                                 \
+            store_slice();                                                                                   \
+            __syncthreads();                                                                                 \
+            if (s + 1 < nsl) wino_load_slice<XI>(A, rs_x, U, voff, first, len, (s + 1) * BK, n0, ra, rb0, rb1);     \
+            else if (XN < 6) wino_load_slice<(XN < 6 ? XN : 0)>(A, rs_x, U, voff, first, len, 0, n0, ra, rb0, rb1); \
+            mma_slice();                                                                                     \
+        }                                                                                                    \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                      \
+            Y0[e] += WinoRow<XI>::at0() * M[e];                                                              \
+            Y1[e] += WinoRow<XI>::at1() * M[e];                                                              \
+        }                                                                                                    \
+    }
+    wino_load_slice<0>(A, rs_x, U, voff, first, len, 0, n0, ra, rb0, rb1);
+    WINO_PASS(0, 1) WINO_PASS(1, 2) WINO_PASS(2, 3) WINO_PASS(3, 4) WINO_PASS(4, 5) WINO_PASS(5, 6)
+#undef WINO_PASS
+
+    // epilogue; 32x32 C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row -> output rows 2p, 2p+1
+    const int n = n0 + wn * 32 + l31;
+    if (n < A.N) {
+        const float sc = A.scale ? A.scale[n] : 1.f;
+        const float sh = A.shift ? A.shift[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int p = p0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (p >= Ptot) continue;
+            const int b = p / Pu, t0 = 2 * (p - b * Pu);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = t0 + h;
+                if (t >= A.T) continue;
+                const int64_t m = (int64_t)b * A.T + t;
+                float v = (h ? Y1[e] : Y0[e]) * sc + sh;
+                if (A.rowbias) v += A.rowbias[(int64_t)b * A.N + n];
+                if (A.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (A.act == ACT_TANH) v = gt_tanh(v);
+                if (A.res) v += A.res[m * A.ldo + n];
+                A.out[m * A.ldo + n] = v;
+            }
+        }
+    }
+}
+
+bool gt_conv_wino5_applies(const ConvGemmArgs& a) {
+    return a.wino_u && !a.wt_bf16 && !a.conv2d && !a.pool2 && !a.tokens && a.N % 4 == 0 && a.N >= 4 && a.taps == 5 &&
+           (size_t)a.B * a.T * a.Cin * 4 < 0x7FFFFFFFull && a.pad_before == 2 && a.Cin % BK == 0 && a.N % 4 == 0 &&
+           (a.ldw == 0 || a.ldw == a.N);
+}
+
 hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const int M = a.B * a.T;
     if (a.wt_bf16) {
@@ -323,6 +489,14 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL((gt_conv_gemm_bf16_kernel<1>), dim3((M + 63) / 64, nb), dim3(256), 0, stream, a);
         }
         return hipGetLastError();
+    }
+    if (gt_conv_wino5_applies(a)) {
+        const int P = a.B * ((a.T + 1) / 2);
+        // worth it when the grid fills the chip (the 4096-row encoder convs would leave half of it idle)
+        if (((P + 63) / 64) * ((a.N + 127) / 128) >= 256) {
+            hipLaunchKernelGGL(gt_conv_wino5_kernel, dim3((P + 63) / 64, (a.N + 127) / 128), dim3(WT), 0, stream, a, a.wino_u);
+            return hipGetLastError();
+        }
     }
     if (a.conv2d) {
         if (a.N > 64) hipLaunchKernelGGL((gt_conv_gemm_kernel<1, 4, 1, 1, true>), dim3((M + 31) / 32, (a.N + 127) / 128), dim3(256), 0, stream, a);

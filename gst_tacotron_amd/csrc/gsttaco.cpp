@@ -43,6 +43,7 @@ struct PackedLinear {       // skinny-GEMM operand set
 };
 
 struct ConvLayer {
+    float* wino_u = nullptr;    // Winograd F(2,5) transform of w, [6][Cin][Cout], when taps == 5 and Cin % 32 == 0 (gemm_conv.hip)
     float* w = nullptr;     // [taps*Cin, Cout]
     float* scale = nullptr;
     float* shift = nullptr;
@@ -106,6 +107,7 @@ struct gsttaco_ctx {
     int co_tiles = 64;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
+    bool wino = true;            // Winograd F(2,5) for the 5-tap Conv1D layers that fill the chip (GSTTACO_WINO=0: implicit GEMM only)
     bool proj_helps = true;      // merged launch: projection workgroups take recurrent-half jobs after publishing (GSTTACO_PROJ_HELPS=0 off)
     bool co_lstm2 = false;       // merged plan: layer 1's recurrent half computed by the layer-2 LSTM launch (GSTTACO_CO_LSTM2=0 off)
     int worker_delay = 300;      // merged launch: the pure workers start this many 100 MHz ticks after it (GSTTACO_WORKER_DELAY)
@@ -484,6 +486,24 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
     if (!rc) rc = add_bf16(c, L->w, k.data.data(), L->taps * L->cin, L->cout, L->cout);
     if (!rc) rc = upload(c, &L->scale, sc.data(), sc.size());
     if (!rc) rc = upload(c, &L->shift, sh.data(), sh.size());
+    if (!rc && c->wino && L->taps == 5 && L->cin % 32 == 0 && L->cout % 4 == 0) {
+        // U_xi = sum_k G[xi][k] w[k]  (Cook-Toom F(2,5), points 0, +-1, +-1/2, infinity), formed in float64
+        static const double G[6][5] = {{4, 0, 0, 0, 0},
+                                       {2.0 / 3, 2.0 / 3, 2.0 / 3, 2.0 / 3, 2.0 / 3},
+                                       {2.0 / 3, -2.0 / 3, 2.0 / 3, -2.0 / 3, 2.0 / 3},
+                                       {-8.0 / 3, -4.0 / 3, -2.0 / 3, -1.0 / 3, -1.0 / 6},
+                                       {-8.0 / 3, 4.0 / 3, -2.0 / 3, 1.0 / 3, -1.0 / 6},
+                                       {0, 0, 0, 0, 1}};
+        const size_t cn = (size_t)L->cin * L->cout;
+        std::vector<float> u(6 * cn);
+        for (int xi = 0; xi < 6; ++xi)
+            for (size_t i = 0; i < cn; ++i) {
+                double acc = 0.0;
+                for (int tap = 0; tap < 5; ++tap) acc += G[xi][tap] * (double)k.data[(size_t)tap * cn + i];
+                u[xi * cn + i] = (float)acc;
+            }
+        rc = upload(c, &L->wino_u, u.data(), u.size());
+    }
     return rc;
 }
 
@@ -997,6 +1017,7 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
         const bool last = i == g.n_post - 1;
         ConvGemmArgs a{};
         a.x = x; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
+        a.wino_u = L.wino_u;
         a.out = last ? out : c->w_post[cur]; a.ldo = L.cout;
         a.res = last ? pre : nullptr;                       // post = postnet(x) + x (Taco2.py:230)
         a.B = B; a.T = Tf; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;
@@ -1364,6 +1385,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     if (const char* e = getenv("GSTTACO_WORKER_DELAY")) c->worker_delay = std::max(0, atoi(e));
     if (const char* e = getenv("GSTTACO_CO_LSTM2")) c->co_lstm2 = e[0] != '0';
     if (const char* e = getenv("GSTTACO_PROJ_HELPS")) c->proj_helps = e[0] != '0';
+    if (const char* e = getenv("GSTTACO_WINO")) c->wino = e[0] != '0';
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);

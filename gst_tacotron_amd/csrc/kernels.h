@@ -150,6 +150,8 @@ struct ConvGemmArgs {
     // LDS, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16), the epilogue and the output stay fp32.
     const void* wt_bf16;
     int ldk;
+    // Winograd F(2,5) (gemm_conv.hip): the transformed weights U[6][Cin][N] = G . w (float64 at finalize), or NULL
+    const float* wino_u;
     float* out;             // [B*T, ldo]
     int64_t ldo;
     int B, T, Cin, N, taps, pad_before, act;
