@@ -15,6 +15,7 @@
 // bank groups); the next slice's global loads are issued before the current slice's MFMAs.
 #include "device_utils.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define BK 32
 
@@ -360,7 +361,7 @@ __device__ __forceinline__ void wino_load_slice(const ConvGemmArgs& A, __amdgpu_
             __builtin_memcpy(&d[tap], &t, 16);
         }
     }
-    const float* Ux = U + (size_t)XI * A.Cin * A.N;
+    const float* Ux = U + (size_t)XI * A.wino_cin * A.N;
     {
         // 32 k rows x 32 float4 (128 columns): this thread's pieces are rows tid >> 5 and 16 + (tid >> 5), quad tid & 31
         const int kr = tid >> 5, nq = tid & 31;
@@ -405,7 +406,9 @@ __global__ __launch_bounds__(WT, 4) void gt_conv_wino5_kernel(ConvGemmArgs A, co
     for (int e = 0; e < 16; ++e) { Y0[e] = 0.f; Y1[e] = 0.f; }
     float4 ra, rb0, rb1;
     const int kh = lane >> 5, l31 = lane & 31;
-    const int nsl = A.Cin / BK;
+    // wino_cin = Cin rounded up to the slice width: U holds zero rows for the padding channels, whose x operand is whatever
+    // follows in memory (the next row's first channels, or zero past the tensor's end: the descriptor covers exactly B*T*Cin)
+    const int nsl = A.wino_cin / BK;
 
     auto store_slice = [&]() {
         const int row = tid >> 3, kq = (tid & 7) * 4;
@@ -475,8 +478,8 @@ __global__ __launch_bounds__(WT, 4) void gt_conv_wino5_kernel(ConvGemmArgs A, co
 
 bool gt_conv_wino5_applies(const ConvGemmArgs& a) {
     return a.wino_u && !a.wt_bf16 && !a.conv2d && !a.pool2 && !a.tokens && a.N % 4 == 0 && a.N >= 4 && a.taps == 5 &&
-           (size_t)a.B * a.T * a.Cin * 4 < 0x7FFFFFFFull && a.pad_before == 2 && a.Cin % BK == 0 && a.N % 4 == 0 &&
-           (a.ldw == 0 || a.ldw == a.N);
+           (size_t)a.B * a.T * a.Cin * 4 < 0x7FFFFFFFull && a.pad_before == 2 && a.Cin % 4 == 0 && a.wino_cin % BK == 0 &&
+           a.wino_cin >= a.Cin && (a.ldw == 0 || a.ldw == a.N);
 }
 
 hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
@@ -492,8 +495,10 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     }
     if (gt_conv_wino5_applies(a)) {
         const int P = a.B * ((a.T + 1) / 2);
-        // worth it when the grid fills the chip (the 4096-row encoder convs would leave half of it idle)
-        if (((P + 63) / 64) * ((a.N + 127) / 128) >= 256) {
+        // worth it when the grid (nearly) fills the chip: the 4096-row encoder convs would leave half of it idle (one round of
+        // 128 Winograd workgroups ~275 us against 136 us for the implicit GEMM); 250 workgroups (the 512 -> 80 layer) do pay
+        static const int min_wgs = getenv("GSTTACO_WINO_MIN_WGS") ? atoi(getenv("GSTTACO_WINO_MIN_WGS")) : 240;
+        if (((P + 63) / 64) * ((a.N + 127) / 128) >= min_wgs) {
             hipLaunchKernelGGL(gt_conv_wino5_kernel, dim3((P + 63) / 64, (a.N + 127) / 128), dim3(WT), 0, stream, a, a.wino_u);
             return hipGetLastError();
         }

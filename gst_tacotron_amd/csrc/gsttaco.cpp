@@ -43,7 +43,8 @@ struct PackedLinear {       // skinny-GEMM operand set
 };
 
 struct ConvLayer {
-    float* wino_u = nullptr;    // Winograd F(2,5) transform of w, [6][Cin][Cout], when taps == 5 and Cin % 32 == 0 (gemm_conv.hip)
+    float* wino_u = nullptr;    // Winograd F(2,5) transform of w, [6][wino_cin][Cout], for 5-tap layers (gemm_conv.hip)
+    int wino_cin = 0;
     float* w = nullptr;     // [taps*Cin, Cout]
     float* scale = nullptr;
     float* shift = nullptr;
@@ -486,7 +487,7 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
     if (!rc) rc = add_bf16(c, L->w, k.data.data(), L->taps * L->cin, L->cout, L->cout);
     if (!rc) rc = upload(c, &L->scale, sc.data(), sc.size());
     if (!rc) rc = upload(c, &L->shift, sh.data(), sh.size());
-    if (!rc && c->wino && L->taps == 5 && L->cin % 32 == 0 && L->cout % 4 == 0) {
+    if (!rc && c->wino && L->taps == 5 && L->cin % 4 == 0 && L->cout % 4 == 0) {
         // U_xi = sum_k G[xi][k] w[k]  (Cook-Toom F(2,5), points 0, +-1, +-1/2, infinity), formed in float64
         static const double G[6][5] = {{4, 0, 0, 0, 0},
                                        {2.0 / 3, 2.0 / 3, 2.0 / 3, 2.0 / 3, 2.0 / 3},
@@ -495,12 +496,14 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
                                        {-8.0 / 3, 4.0 / 3, -2.0 / 3, 1.0 / 3, -1.0 / 6},
                                        {0, 0, 0, 0, 1}};
         const size_t cn = (size_t)L->cin * L->cout;
-        std::vector<float> u(6 * cn);
+        L->wino_cin = (L->cin + 31) / 32 * 32;                  // zero rows for the padding channels
+        const size_t cnp = (size_t)L->wino_cin * L->cout;
+        std::vector<float> u(6 * cnp, 0.f);
         for (int xi = 0; xi < 6; ++xi)
             for (size_t i = 0; i < cn; ++i) {
                 double acc = 0.0;
                 for (int tap = 0; tap < 5; ++tap) acc += G[xi][tap] * (double)k.data[(size_t)tap * cn + i];
-                u[xi * cn + i] = (float)acc;
+                u[xi * cnp + i] = (float)acc;
             }
         rc = upload(c, &L->wino_u, u.data(), u.size());
     }
@@ -1017,7 +1020,7 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
         const bool last = i == g.n_post - 1;
         ConvGemmArgs a{};
         a.x = x; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
-        a.wino_u = L.wino_u;
+        a.wino_u = L.wino_u; a.wino_cin = L.wino_cin;
         a.out = last ? out : c->w_post[cur]; a.ldo = L.cout;
         a.res = last ? pre : nullptr;                       // post = postnet(x) + x (Taco2.py:230)
         a.B = B; a.T = Tf; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;

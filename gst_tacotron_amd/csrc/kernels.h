@@ -152,6 +152,7 @@ struct ConvGemmArgs {
     int ldk;
     // Winograd F(2,5) (gemm_conv.hip): the transformed weights U[6][Cin][N] = G . w (float64 at finalize), or NULL
     const float* wino_u;
+    int wino_cin;           // rows of each U_xi: Cin rounded up to a multiple of 32 (zero rows for the padding)
     float* out;             // [B*T, ldo]
     int64_t ldo;
     int B, T, Cin, N, taps, pad_before, act;
