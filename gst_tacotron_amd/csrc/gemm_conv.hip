@@ -328,33 +328,51 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
 // which is folded into the two output accumulators after each (V never touches memory, no cross-workgroup reduction).
 // Measured error on the postnet's shapes: 2-3.6e-6 max-abs at |y| ~ 3 (the direct fp32 sum: 1.1e-6) -- tools/wino_error.py.
 // Applies to: taps == 5, pad_before == 2, Cin % 32 == 0, no pooling, no 2-D mode.
-template <int XI>
-struct WinoRow {                                   // compile-time rows of BT / AT
-    static constexpr float bt(int i) {
-        constexpr float t[6][6] = {{0.25f, 0.f, -1.25f, 0.f, 1.f, 0.f},   {0.f, -0.25f, -0.25f, 1.f, 1.f, 0.f},
-                                   {0.f, 0.25f, -0.25f, -1.f, 1.f, 0.f},  {0.f, -0.5f, -1.f, 0.5f, 1.f, 0.f},
-                                   {0.f, 0.5f, -1.f, -0.5f, 1.f, 0.f},    {0.f, 0.25f, 0.f, -1.25f, 0.f, 1.f}};
-        return t[XI][i];
+// Transform rows at compile time.  MO = outputs per tile: 2 -> F(2,5), points 0, +-1, +-1/2, inf (6 GEMMs per 2 outputs, 0.6x
+// the multiplications of the direct sum); 4 -> F(4,5), points 0, +-1, +-1/2, +-2, inf (8 GEMMs per 4 outputs, 0.4x).
+template <int MO>
+struct Wino {
+    static constexpr int ALPHA = MO + 4;
+    static constexpr float bt(int xi, int i) {
+        if (MO == 2) {
+            constexpr float t[6][6] = {{0.25f, 0.f, -1.25f, 0.f, 1.f, 0.f},   {0.f, -0.25f, -0.25f, 1.f, 1.f, 0.f},
+                                       {0.f, 0.25f, -0.25f, -1.f, 1.f, 0.f},  {0.f, -0.5f, -1.f, 0.5f, 1.f, 0.f},
+                                       {0.f, 0.5f, -1.f, -0.5f, 1.f, 0.f},    {0.f, 0.25f, 0.f, -1.25f, 0.f, 1.f}};
+            return t[xi % 6][i % 6];
+        }
+        constexpr float t[8][8] = {{-1.f, 0.f, 5.25f, 0.f, -5.25f, 0.f, 1.f, 0.f},     {0.f, 1.f, 1.f, -4.25f, -4.25f, 1.f, 1.f, 0.f},
+                                   {0.f, -1.f, 1.f, 4.25f, -4.25f, -1.f, 1.f, 0.f},    {0.f, 2.f, 4.f, -2.5f, -5.f, 0.5f, 1.f, 0.f},
+                                   {0.f, -2.f, 4.f, 2.5f, -5.f, -0.5f, 1.f, 0.f},      {0.f, 0.5f, 0.25f, -2.5f, -1.25f, 2.f, 1.f, 0.f},
+                                   {0.f, -0.5f, 0.25f, 2.5f, -1.25f, -2.f, 1.f, 0.f},  {0.f, -1.f, 0.f, 5.25f, 0.f, -5.25f, 0.f, 1.f}};
+        return t[xi % 8][i % 8];
     }
-    static constexpr float at0() { return XI < 5 ? 1.f : 0.f; }
-    static constexpr float at1() { return XI == 0 ? 0.f : XI == 1 ? 1.f : XI == 2 ? -1.f : XI == 3 ? 0.5f : XI == 4 ? -0.5f : 1.f; }
+    static constexpr float at(int o, int xi) {
+        if (MO == 2) {
+            constexpr float t[2][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 0.5f, -0.5f, 1.f}};
+            return t[o % 2][xi % 6];
+        }
+        constexpr float t[4][8] = {{1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.f},          {0.f, 1.f, -1.f, 0.5f, -0.5f, 2.f, -2.f, 0.f},
+                                   {0.f, 1.f, 1.f, 0.25f, 0.25f, 4.f, 4.f, 0.f},      {0.f, 1.f, -1.f, 0.125f, -0.125f, 8.f, -8.f, 1.f}};
+        return t[o % 4][xi % 8];
+    }
 };
 
 #define GT_WINO_OOB 0x80000000u
 #define WT 512             // threads: 8 waves as 2 (tile rows) x 4 (columns), each a 32 x 32 MFMA tile
 
 // One slice (32 input channels) of the transform-domain GEMM XI: this thread's A element (tile row f >> 3, channel quad f & 7)
-// = sum of 3-4 input rows, and its two B pieces of U_XI.  Every gather load is an unconditional buffer load: a row outside
-// [0, len) gets an out-of-range offset and reads as zero (SAME padding / masked mode) -- no branches, so all taps are in
-// flight together and counted exactly.
-template <int XI>
+// = a combination of up to six input rows, and its two B pieces of U_XI.  Every gather load is an unconditional buffer load:
+// a row outside [0, len) gets an out-of-range offset and reads as zero (SAME padding / masked mode) -- no branches, so all
+// taps are in flight together and counted exactly.
+template <int MO, int XI>
 __device__ __forceinline__ void wino_load_slice(const ConvGemmArgs& A, __amdgpu_buffer_rsrc_t rs_x, const float* __restrict__ U, const uint32_t voff,
                                                 const int first, const int len, const int c0, const int n0, float4& ra, float4& rb0, float4& rb1) {
+    constexpr int AL = Wino<MO>::ALPHA;
     const int tid = threadIdx.x;
-    float4 d[6];
+    float4 d[AL];
 #pragma unroll
-    for (int tap = 0; tap < 6; ++tap) {
-        if (WinoRow<XI>::bt(tap) != 0.f) {
+    for (int tap = 0; tap < AL; ++tap) {
+        if (Wino<MO>::bt(XI, tap) != 0.f) {
             const int ts = first + tap;
             const uint32_t vo = (ts >= 0 && ts < len) ? voff + (uint32_t)(tap * A.Cin * 4) : GT_WINO_OOB;
             const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo, c0 * 4, 0);
@@ -371,20 +389,23 @@ __device__ __forceinline__ void wino_load_slice(const ConvGemmArgs& A, __amdgpu_
     }
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int tap = 0; tap < 6; ++tap) {
-        const float cf = WinoRow<XI>::bt(tap);
+    for (int tap = 0; tap < AL; ++tap) {
+        const float cf = Wino<MO>::bt(XI, tap);
         if (cf != 0.f) { v.x += cf * d[tap].x; v.y += cf * d[tap].y; v.z += cf * d[tap].z; v.w += cf * d[tap].w; }
     }
     ra = v;
 }
 
-__global__ __launch_bounds__(WT, 4) void gt_conv_wino5_kernel(ConvGemmArgs A, const float* __restrict__ U) {
+template <int MO>
+__global__ __launch_bounds__(WT, MO == 4 ? 2 : 4) void gt_conv_wino5_kernel(ConvGemmArgs A, const float* __restrict__ U) {
+    constexpr int AL = Wino<MO>::ALPHA;
     constexpr int BMP = 64, BN = 128, LDA = BMP + 1, LDB = BN + 4;
-    __shared__ float As[BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+    // two LDS stages: slice s + 1 is written while slice s is read, ONE barrier per slice (50 KB per workgroup)
+    __shared__ float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
-    const int Pu = (A.T + 1) >> 1;                       // tiles per utterance
+    const int Pu = (A.T + MO - 1) / MO;                  // tiles per utterance
     const int Ptot = A.B * Pu;
     const int p0 = blockIdx.x * BMP, n0 = blockIdx.y * BN;
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x), 0, (int)((size_t)A.B * A.T * A.Cin * 4), 0x00020000);
@@ -396,61 +417,65 @@ __global__ __launch_bounds__(WT, 4) void gt_conv_wino5_kernel(ConvGemmArgs A, co
         const bool ok = p < Ptot;
         const int pp = ok ? p : 0;
         const int b = pp / Pu;
-        first = 2 * (pp - b * Pu) - 2;
+        first = MO * (pp - b * Pu) - 2;
         len = ok ? (A.row_len ? min(A.T, A.row_len[b]) : A.T) : 0;      // a tile past the end reads nothing
         // (the first rows of utterance 0 give a negative row index: those taps are out of range anyway, the wrapped offset is unused)
         voff = (uint32_t)(((int64_t)b * A.T + first) * A.Cin + (tid & 7) * 4) * 4u;
     }
-    f32x16 M, Y0, Y1;
+    f32x16 M, Y[MO];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { Y0[e] = 0.f; Y1[e] = 0.f; }
+    for (int o = 0; o < MO; ++o)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Y[o][e] = 0.f;
     float4 ra, rb0, rb1;
     const int kh = lane >> 5, l31 = lane & 31;
     // wino_cin = Cin rounded up to the slice width: U holds zero rows for the padding channels, whose x operand is whatever
     // follows in memory (the next row's first channels, or zero past the tensor's end: the descriptor covers exactly B*T*Cin)
     const int nsl = A.wino_cin / BK;
+    int cur = 0;                                          // LDS stage the current slice sits in
 
-    auto store_slice = [&]() {
+    auto store_slice = [&](int st) {
         const int row = tid >> 3, kq = (tid & 7) * 4;
-        As[(kq + 0) * LDA + row] = ra.x;
-        As[(kq + 1) * LDA + row] = ra.y;
-        As[(kq + 2) * LDA + row] = ra.z;
-        As[(kq + 3) * LDA + row] = ra.w;
-        *reinterpret_cast<float4*>(&Bs[(tid >> 5) * LDB + (tid & 31) * 4]) = rb0;
-        *reinterpret_cast<float4*>(&Bs[(16 + (tid >> 5)) * LDB + (tid & 31) * 4]) = rb1;
+        As[st][(kq + 0) * LDA + row] = ra.x;
+        As[st][(kq + 1) * LDA + row] = ra.y;
+        As[st][(kq + 2) * LDA + row] = ra.z;
+        As[st][(kq + 3) * LDA + row] = ra.w;
+        *reinterpret_cast<float4*>(&Bs[st][(tid >> 5) * LDB + (tid & 31) * 4]) = rb0;
+        *reinterpret_cast<float4*>(&Bs[st][(16 + (tid >> 5)) * LDB + (tid & 31) * 4]) = rb1;
     };
-    auto mma_slice = [&]() {
+    auto mma_slice = [&](int st) {
 #pragma unroll 4
         for (int kp = 0; kp < BK / 2; ++kp) {
             const int krow = kp * 2 + kh;
-            const float av = As[krow * LDA + wm * 32 + l31];
-            const float bv = Bs[krow * LDB + wn * 32 + l31];
+            const float av = As[st][krow * LDA + wm * 32 + l31];
+            const float bv = Bs[st][krow * LDB + wn * 32 + l31];
             M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, M, 0, 0, 0);
         }
     };
-    // the six transform-domain GEMMs, one after the other; the NEXT slice (possibly the next GEMM's first) is requested
-    // before the current slice's MFMAs
-#define WINO_PASS(XI, XN)                                                                                    \
-    {                                                                                                        \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) M[e] = 0.f;                                            \
-        for (int s = 0; s < nsl; ++s) {                                                                      \
-            __syncthreads();                                                                                 \
-            store_slice();                                                                                   \
-            __syncthreads();                                                                                 \
-            if (s + 1 < nsl) wino_load_slice<XI>(A, rs_x, U, voff, first, len, (s + 1) * BK, n0, ra, rb0, rb1);     \
-            else if (XN < 6) wino_load_slice<(XN < 6 ? XN : 0)>(A, rs_x, U, voff, first, len, 0, n0, ra, rb0, rb1); \
-            mma_slice();                                                                                     \
-        }                                                                                                    \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                      \
-            Y0[e] += WinoRow<XI>::at0() * M[e];                                                              \
-            Y1[e] += WinoRow<XI>::at1() * M[e];                                                              \
-        }                                                                                                    \
+    // the transform-domain GEMMs, one after the other.  Per slice: request the NEXT slice (possibly the next GEMM's first),
+    // MFMAs on the current stage, write the next slice into the other stage, barrier.
+#define WINO_PASS(XI)                                                                                             \
+    if constexpr (XI < AL) {                                                                                      \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) M[e] = 0.f;                                                 \
+        for (int s = 0; s < nsl; ++s) {                                                                           \
+            const bool more = s + 1 < nsl || XI + 1 < AL;                                                         \
+            if (s + 1 < nsl) wino_load_slice<MO, XI>(A, rs_x, U, voff, first, len, (s + 1) * BK, n0, ra, rb0, rb1); \
+            else if (XI + 1 < AL) wino_load_slice<MO, (XI + 1 < AL ? XI + 1 : 0)>(A, rs_x, U, voff, first, len, 0, n0, ra, rb0, rb1); \
+            mma_slice(cur);                                                                                       \
+            if (more) store_slice(cur ^ 1);                                                                       \
+            __syncthreads();                                                                                      \
+            cur ^= 1;                                                                                             \
+        }                                                                                                         \
+        _Pragma("unroll") for (int o = 0; o < MO; ++o)                                                             \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) Y[o][e] += Wino<MO>::at(o, XI) * M[e];                  \
     }
-    wino_load_slice<0>(A, rs_x, U, voff, first, len, 0, n0, ra, rb0, rb1);
-    WINO_PASS(0, 1) WINO_PASS(1, 2) WINO_PASS(2, 3) WINO_PASS(3, 4) WINO_PASS(4, 5) WINO_PASS(5, 6)
+    wino_load_slice<MO, 0>(A, rs_x, U, voff, first, len, 0, n0, ra, rb0, rb1);
+    store_slice(0);
+    __syncthreads();
+    WINO_PASS(0) WINO_PASS(1) WINO_PASS(2) WINO_PASS(3) WINO_PASS(4) WINO_PASS(5) WINO_PASS(6) WINO_PASS(7)
 #undef WINO_PASS
 
-    // epilogue; 32x32 C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row -> output rows 2p, 2p+1
+    // epilogue; 32x32 C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row -> MO output rows
     const int n = n0 + wn * 32 + l31;
     if (n < A.N) {
         const float sc = A.scale ? A.scale[n] : 1.f;
@@ -459,13 +484,13 @@ __global__ __launch_bounds__(WT, 4) void gt_conv_wino5_kernel(ConvGemmArgs A, co
         for (int e = 0; e < 16; ++e) {
             const int p = p0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
             if (p >= Ptot) continue;
-            const int b = p / Pu, t0 = 2 * (p - b * Pu);
+            const int b = p / Pu, t0 = MO * (p - b * Pu);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int t = t0 + h;
+            for (int o = 0; o < MO; ++o) {
+                const int t = t0 + o;
                 if (t >= A.T) continue;
                 const int64_t m = (int64_t)b * A.T + t;
-                float v = (h ? Y1[e] : Y0[e]) * sc + sh;
+                float v = Y[o][e] * sc + sh;
                 if (A.rowbias) v += A.rowbias[(int64_t)b * A.N + n];
                 if (A.act == ACT_RELU) v = fmaxf(v, 0.f);
                 else if (A.act == ACT_TANH) v = gt_tanh(v);
@@ -494,12 +519,18 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         return hipGetLastError();
     }
     if (gt_conv_wino5_applies(a)) {
-        const int P = a.B * ((a.T + 1) / 2);
         // worth it when the grid (nearly) fills the chip: the 4096-row encoder convs would leave half of it idle (one round of
-        // 128 Winograd workgroups ~275 us against 136 us for the implicit GEMM); 250 workgroups (the 512 -> 80 layer) do pay
+        // 128 Winograd workgroups ~275 us against 136 us for the implicit GEMM); 250 workgroups (the 512 -> 80 layer) do pay.
+        // F(4,5) where its (half as large) grid still does, else F(2,5).
         static const int min_wgs = getenv("GSTTACO_WINO_MIN_WGS") ? atoi(getenv("GSTTACO_WINO_MIN_WGS")) : 240;
-        if (((P + 63) / 64) * ((a.N + 127) / 128) >= min_wgs) {
-            hipLaunchKernelGGL(gt_conv_wino5_kernel, dim3((P + 63) / 64, (a.N + 127) / 128), dim3(WT), 0, stream, a, a.wino_u);
+        const int nb = (a.N + 127) / 128;
+        const int P4 = a.B * ((a.T + 3) / 4), P2 = a.B * ((a.T + 1) / 2);
+        if (a.wino_u4 && ((P4 + 63) / 64) * nb >= min_wgs) {
+            hipLaunchKernelGGL(gt_conv_wino5_kernel<4>, dim3((P4 + 63) / 64, nb), dim3(WT), 0, stream, a, a.wino_u4);
+            return hipGetLastError();
+        }
+        if (((P2 + 63) / 64) * nb >= min_wgs) {
+            hipLaunchKernelGGL(gt_conv_wino5_kernel<2>, dim3((P2 + 63) / 64, nb), dim3(WT), 0, stream, a, a.wino_u);
             return hipGetLastError();
         }
     }

@@ -44,6 +44,7 @@ struct PackedLinear {       // skinny-GEMM operand set
 
 struct ConvLayer {
     float* wino_u = nullptr;    // Winograd F(2,5) transform of w, [6][wino_cin][Cout], for 5-tap layers (gemm_conv.hip)
+    float* wino_u4 = nullptr;   // F(4,5): [8][wino_cin][Cout]
     int wino_cin = 0;
     float* w = nullptr;     // [taps*Cin, Cout]
     float* scale = nullptr;
@@ -108,6 +109,7 @@ struct gsttaco_ctx {
     int co_tiles = 64;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
+    bool wino4 = true;           // ... F(4,5) where its grid still fills the chip (GSTTACO_WINO4=0: F(2,5) only)
     bool wino = true;            // Winograd F(2,5) for the 5-tap Conv1D layers that fill the chip (GSTTACO_WINO=0: implicit GEMM only)
     bool proj_helps = true;      // merged launch: projection workgroups take recurrent-half jobs after publishing (GSTTACO_PROJ_HELPS=0 off)
     bool co_lstm2 = false;       // merged plan: layer 1's recurrent half computed by the layer-2 LSTM launch (GSTTACO_CO_LSTM2=0 off)
@@ -506,6 +508,25 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
                 u[xi * cnp + i] = (float)acc;
             }
         rc = upload(c, &L->wino_u, u.data(), u.size());
+        if (!rc && c->wino4) {
+            // F(4,5), points 0, +-1, +-1/2, +-2, infinity
+            static const double G4[8][5] = {{-1, 0, 0, 0, 0},
+                                            {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                            {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                            {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                                            {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                                            {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                                            {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                                            {0, 0, 0, 0, 1}};
+            std::vector<float> u4(8 * cnp, 0.f);
+            for (int xi = 0; xi < 8; ++xi)
+                for (size_t i = 0; i < cn; ++i) {
+                    double acc = 0.0;
+                    for (int tap = 0; tap < 5; ++tap) acc += G4[xi][tap] * (double)k.data[(size_t)tap * cn + i];
+                    u4[xi * cnp + i] = (float)acc;
+                }
+            rc = upload(c, &L->wino_u4, u4.data(), u4.size());
+        }
     }
     return rc;
 }
@@ -1020,7 +1041,7 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
         const bool last = i == g.n_post - 1;
         ConvGemmArgs a{};
         a.x = x; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
-        a.wino_u = L.wino_u; a.wino_cin = L.wino_cin;
+        a.wino_u = L.wino_u; a.wino_u4 = L.wino_u4; a.wino_cin = L.wino_cin;
         a.out = last ? out : c->w_post[cur]; a.ldo = L.cout;
         a.res = last ? pre : nullptr;                       // post = postnet(x) + x (Taco2.py:230)
         a.B = B; a.T = Tf; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;
@@ -1389,6 +1410,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     if (const char* e = getenv("GSTTACO_CO_LSTM2")) c->co_lstm2 = e[0] != '0';
     if (const char* e = getenv("GSTTACO_PROJ_HELPS")) c->proj_helps = e[0] != '0';
     if (const char* e = getenv("GSTTACO_WINO")) c->wino = e[0] != '0';
+    if (const char* e = getenv("GSTTACO_WINO4")) c->wino4 = e[0] != '0';
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);

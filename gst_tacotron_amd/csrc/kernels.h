@@ -151,7 +151,8 @@ struct ConvGemmArgs {
     const void* wt_bf16;
     int ldk;
     // Winograd F(2,5) (gemm_conv.hip): the transformed weights U[6][Cin][N] = G . w (float64 at finalize), or NULL
-    const float* wino_u;
+    const float* wino_u;    // F(2,5): [6][wino_cin][N]
+    const float* wino_u4;   // F(4,5): [8][wino_cin][N], or NULL
     int wino_cin;           // rows of each U_xi: Cin rounded up to a multiple of 32 (zero rows for the padding)
     float* out;             // [B*T, ldo]
     int64_t ldo;
