@@ -90,6 +90,8 @@ struct gsttaco_ctx {
         PackedLinear h[2];
         float *xw = nullptr, *xb = nullptr;         // [C, 2*4H], [2*4H]
         float *z = nullptr, *hb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        float* ph = nullptr;                        // persistent kernel: [8 groups][2 parities] blocked state of 16 rows
+        uint32_t* pflags = nullptr;                 // persistent kernel: [8 groups][2 parities][32] publish tags + [8] member counters
         int H = 0, C = 0;
     } enc_lean, voc_lean;
     struct { float *w, *scale, *shift; int k, cin, cout, stride; } ref_conv[GSTTACO_MAX_LAYERS]{};
@@ -110,6 +112,7 @@ struct gsttaco_ctx {
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
     bool wino4 = true;           // ... F(4,5) where its grid still fills the chip (GSTTACO_WINO4=0: F(2,5) only)
+    bool bilstm_persist = true;  // one persistent launch per BiLSTM instead of one per time step (GSTTACO_BILSTM_PERSIST=0: per step)
     bool wino = true;            // Winograd F(2,5) for the 5-tap Conv1D layers that fill the chip (GSTTACO_WINO=0: implicit GEMM only)
     bool proj_helps = true;      // merged launch: projection workgroups take recurrent-half jobs after publishing (GSTTACO_PROJ_HELPS=0 off)
     bool co_lstm2 = false;       // merged plan: layer 1's recurrent half computed by the layer-2 LSTM launch (GSTTACO_CO_LSTM2=0 off)
@@ -593,6 +596,10 @@ int alloc_lean_bilstm(gsttaco_ctx* c, gsttaco_ctx::LeanBiLstm* L, size_t B, size
     for (int d = 0; d < 2; ++d)
         for (int q = 0; q < 2; ++q)
             if ((rc = dev_alloc(c, (void**)&L->hb[d][q], ((B + 15) / 16) * 16 * L->H * sizeof(float)))) return rc;
+    if (gt_bilstm_persist_supported(L->H, 1, c->n_cu)) {        // used for calls of up to 64 utterances (8 groups)
+        if ((rc = dev_alloc(c, (void**)&L->ph, (size_t)8 * 2 * 16 * L->H * sizeof(float)))) return rc;
+        if ((rc = dev_alloc(c, (void**)&L->pflags, (size_t)(8 * 2 * 32 + 8) * sizeof(uint32_t)))) return rc;
+    }
     return 0;
 }
 
@@ -605,6 +612,18 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
     a.out = L.z; a.ldo = 8 * H;
     a.B = B; a.T = Tn; a.Cin = L.C; a.N = 8 * H; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
     HIPCHECK(c, launch_conv(c, a, s));
+    // One persistent launch for the whole sequence, one (direction, 16 utterances) group per XCD (skinny_gemm.hip
+    // gt_bilstm_persist_kernel; same arithmetic, bitwise the same outputs); GSTTACO_BILSTM_PERSIST=0 keeps the launch per step.
+    if (L.ph && c->bilstm_persist && gt_bilstm_persist_supported(H, B, c->n_cu)) {
+        HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(L.pflags), (size_t)8 * 2 * 32 + 8, s));
+        BiLstmPersistArgs k{};
+        k.wp[0] = L.h[0].wp; k.wp[1] = L.h[1].wp;
+        k.zx = L.z; k.out = out; k.h = L.ph; k.flags = L.pflags; k.row_len = row_len; k.err = c->w_err + 1;
+        k.ldz = (int64_t)Tn * 8 * H; k.ldo = (int64_t)Tn * EO;
+        k.M = B; k.MT = MT; k.H = H; k.T = Tn;
+        HIPCHECK(c, gt_launch_bilstm_persist(k, s));
+        return 0;
+    }
     for (int d = 0; d < 2; ++d) HIPCHECK(c, gt_launch_zero(L.hb[d][1], (size_t)MT * 16 * H, s));
     for (int t = 0; t < Tn; ++t) {
         BiLstmArgs k{};
@@ -1411,6 +1430,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     if (const char* e = getenv("GSTTACO_PROJ_HELPS")) c->proj_helps = e[0] != '0';
     if (const char* e = getenv("GSTTACO_WINO")) c->wino = e[0] != '0';
     if (const char* e = getenv("GSTTACO_WINO4")) c->wino4 = e[0] != '0';
+    if (const char* e = getenv("GSTTACO_BILSTM_PERSIST")) c->bilstm_persist = e[0] != '0';
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);
@@ -1757,6 +1777,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     HIPCHECK(c, gt_attn_init());
     HIPCHECK(c, gt_dec_front_init());
     HIPCHECK(c, gt_gst_init());
+    HIPCHECK(c, gt_bilstm_persist_init());
     HIPCHECK(c, hipDeviceSynchronize());
     // host copies are no longer needed
     for (auto& t : c->tensors) std::vector<float>().swap(t.data);
@@ -2060,7 +2081,9 @@ int gsttaco_debug_randomness(gsttaco_ctx* c, float* host_masks, float* host_nois
 int gsttaco_debug_handoff_error(gsttaco_ctx* c, uint32_t* host_out) {
     if (!c || !host_out || !c->w_err) return GSTTACO_E_INVALID;
     HIPCHECK(c, hipDeviceSynchronize());
-    HIPCHECK(c, hipMemcpy(host_out, c->w_err, 4, hipMemcpyDeviceToHost));
+    uint32_t words[2] = {0, 0};                     // [0] merged decode launch, [1] persistent BiLSTM (sticky)
+    HIPCHECK(c, hipMemcpy(words, c->w_err, 8, hipMemcpyDeviceToHost));
+    *host_out = words[0] | (words[1] << 8);
     return 0;
 }
 

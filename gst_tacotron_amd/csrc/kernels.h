@@ -113,6 +113,23 @@ struct BiLstmArgs {
     int M, MT, H;
 };
 bool gt_bilstm_lean_supported(int nkb_h);
+
+// Persistent BiLSTM: every time step of both directions in one launch (skinny_gemm.hip gt_bilstm_persist_kernel).
+// Group g = direction + 2 * M-tile lives on XCD g.
+struct BiLstmPersistArgs {
+    const float* wp[2];         // packed W_h per direction [H/4 tiles][H/16][64][4]
+    const float* zx;            // hoisted input halves: (row, time tt, direction d, tile, col) at zx[row*ldz + tt*8H + d*4H + tile*16 + col]
+    float* out;                 // (row, tt, d, unit) at out[row*ldo + tt*2H + d*H + unit]
+    float* h;                   // workspace [8 groups][2 parities][H/16][64][4]: blocked state of the group's 16 rows
+    uint32_t* flags;            // workspace [8 groups][2 parities][32 members] + [8] member counters, zeroed before the launch
+    const int32_t* row_len;     // masked-mode extension (A12) or NULL
+    uint32_t* err;              // bit 0: a wait gave up
+    int64_t ldz, ldo;
+    int M, MT, H, T;
+};
+bool gt_bilstm_persist_supported(int H, int B, int n_cu);
+hipError_t gt_launch_bilstm_persist(const BiLstmPersistArgs& a, hipStream_t stream);
+hipError_t gt_bilstm_persist_init();       // opt in to >64 KiB dynamic LDS; call once outside stream capture
 hipError_t gt_launch_bilstm_lean(const BiLstmArgs& a, hipStream_t stream);
 
 // Projection [h2 | ctx] -> mel frames | stop logit | (optional) next step's prenet-0 pre-activations, with co-scheduled

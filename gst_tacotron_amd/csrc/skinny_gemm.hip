@@ -389,6 +389,167 @@ __global__ __launch_bounds__(NW * 64) void gt_bilstm_lean_kernel(BiLstmArgs A) {
     }
 }
 
+
+// ======================================================================================================================
+// Persistent Bidirectional LSTM: ALL time steps of both directions in ONE launch (reference Taco2.py:39-43, 394-398).
+//
+// The per-step kernel above is a chain of 128 launches of ~2 us of kernel boundary + ~3 us of kernel each, whose work (16
+// MFMAs per wave) is a small part of it, and which re-reads its weight tile every step.  Here the workgroups stay resident for
+// the whole sequence with their weight tiles and cell state in REGISTERS and hand the hidden state around themselves.
+//
+// What makes that cheap is WHERE the workgroups sit (tools/handoff3.hip, profiles/r02_handoff_one_xcd.txt): an all-to-all
+// among workgroups spread over the chip needs write-through stores and fabric-served loads and costs as much as the kernel
+// boundary it replaces (tools/handoff.hip; measured on this very kernel: 5.6 us / step against 5.3 us for the launches); the
+// same exchange among the 32 workgroups of ONE XCD goes through that XCD's L2, which is coherent for them -- plain
+// stores, loads that only have to miss the reader's L1 (sc1) -- and costs 1.15 us, flags and a 32 KiB read included.
+// The recurrences of different utterances are independent, so the job is cut into GROUPS = (direction, 16-utterance M-tile),
+// each wholly on one XCD (2 directions x up to 4 M-tiles = 64 utterances on the 8 XCDs), 32 members per group, each member
+// owning 2 gate tiles (8 hidden units x 4 gates) for its group's 16 rows.  Groups never talk to each other.  The launch is
+// 512 workgroups, which the dispatcher deals round-robin to the XCDs; a workgroup reads the XCD it landed on from the
+// hardware (XCC_ID) -- that is its group -- and takes the next free member slot of that group from a counter; groups that
+// have nothing to do and arrivals beyond the 32nd exit at once.  (Nothing is assumed about blockIdx -> XCD except that
+// every XCD receives at least 32 of the 512.)
+//
+// Hand-off per step inside a group: the 128 owner lanes store h_t into the group's blocked 16 KiB state (parity t & 1), every
+// storing wave drains (vmcnt(0)), workgroup barrier, one lane stores the member's flag (= t + 1, tags only grow; zeroed before
+// the launch); every wave polls the group's 32 flags itself (sc1 loads, one per lane) and then loads its two k-blocks of the
+// state with sc1 loads.  A member can only overwrite the parity of step t - 2 once all members have published t - 1, i.e.
+// have finished reading t - 2.  Waits are bounded (error word instead of a hung GPU).
+//
+// Arithmetic = gt_bilstm_lean_kernel<8, 2>'s exactly (k-block kb on wave kb % 8, ascending; partial sums added over waves in
+// ascending order after the hoisted input half): bitwise equal outputs, which is what the GPU test checks.
+__device__ __forceinline__ uint32_t gt_ldu_sc1(const uint32_t* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gt_ld2x4_sc1(const float* p0, const float* p1, float4& a, float4& b) {
+    f32x4 ra, rb;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(ra), "=&v"(rb)
+                 : "v"(p0), "v"(p1)
+                 : "memory");
+    a = make_float4(ra[0], ra[1], ra[2], ra[3]); b = make_float4(rb[0], rb[1], rb[2], rb[3]);
+}
+
+constexpr int kPersistLds = 96 * 1024;
+__global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArgs A) {
+    constexpr int NW = 8, KPW = 2, NT = 2, NM = 32;                // waves, k-blocks per wave, tiles per member, members per group
+    // (launched with kPersistLds bytes of dynamic LDS, more than half a CU's: one workgroup per CU, so that the 32 members of
+    // a group sit on the 32 CUs of their XCD instead of sharing matrix cores in pairs)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_slot;
+    float (*part)[NT][16][17] = reinterpret_cast<float (*)[NT][16][17]>(lds);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // which XCD am I on?  (the hardware's answer, not blockIdx % 8: under graph replay the round-robin has been seen to start
+    // elsewhere.)  The XCD is the group; the first 32 arrivals on it are its members, later ones have nothing to do.
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int g = (int)(xcc & 7);
+    if (g >= 2 * A.MT) return;
+    if (tid == 0) s_slot = (int)atomicAdd(A.flags + 8 * 2 * NM + g, 1u);
+    __syncthreads();
+    const int rank = s_slot;
+    if (rank >= NM) return;
+    const int d = g & 1, mt = g >> 1, H = A.H;
+    // this thread's element of the member's 16 rows x (2 tiles x 16 gate columns)
+    const int row = tid >> 5, j_own = (tid >> 4) & 1, col = tid & 15;
+    const int grow = mt * 16 + row, tile0 = rank * NT, unit = (tile0 + j_own) * 4 + col;
+    const bool owner = col < 4;                                    // lanes that own a hidden unit (rows beyond M publish zeros)
+    const bool real = grow < A.M;
+    // weights: k-blocks wave and wave + 8 of both tiles, resident for the whole sequence
+    float4 b[KPW][NT];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            b[i][j] = (reinterpret_cast<const float4*>(A.wp[d]) + ((size_t)(tile0 + j) * (NW * KPW) + wave + i * NW) * 64)[lane];
+    float* hbuf = A.h + (size_t)g * 2 * 16 * H;                     // [2 parities][H/16 k-blocks][64 lanes][4]
+    uint32_t* fl = A.flags + (size_t)g * 2 * NM;                   // [2 parities][32 members]
+    // (rows beyond M read the group's first row, which exists, and are never used: no load under a branch, no wait at its join)
+    const float* zrow = A.zx + (size_t)(real ? grow : mt * 16) * A.ldz + (size_t)d * 4 * H + (tile0 + j_own) * 16 + col;
+    float c_state = 0.f;
+    float pin = zrow[(size_t)(d == 0 ? 0 : A.T - 1) * 8 * H];
+    const int n_valid = (A.row_len && real) ? A.row_len[grow] : A.T;       // masked mode: steps tt >= n_valid do not exist for this row
+    for (int t = 0; t < A.T; ++t) {
+        const int tt = d == 0 ? t : A.T - 1 - t;
+        float4 x[KPW];
+        if (t == 0) {
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const int par = (t - 1) & 1;
+            const uint32_t want = (uint32_t)t;                     // step t - 1 publishes tag t
+            uint32_t spins = 0;
+            for (;;) {
+                const uint32_t v = lane < NM ? gt_ldu_sc1(fl + par * NM + lane) : want;
+                if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(v >= want))) == 64) break;
+                if (++spins > (1u << 18)) { if (lane == 0) atomicOr(A.err, 1u); break; }
+            }
+            const float* hp = hbuf + (size_t)par * 16 * H + lane * 4;
+            gt_ld2x4_sc1(hp + (size_t)wave * 256, hp + (size_t)(wave + NW) * 256, x[0], x[1]);
+        }
+        // the next step's hoisted input half: requested now, needed after the next wait
+        const float cur = pin;
+        {
+            const int tn = min(t + 1, A.T - 1);
+            pin = zrow[(size_t)(d == 0 ? tn : A.T - 1 - tn) * 8 * H];
+        }
+        f32x4 acc[NT] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].x, b[i][j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].y, b[i][j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].z, b[i][j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].w, b[i][j].w, acc[j], 0, 0, 0);
+            }
+        {   // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+            const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) part[wave][j][q * 4 + v][r] = acc[j][v];
+        }
+        __syncthreads();
+        float z = cur;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) z += part[w][j_own][row][col];
+        const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+        float hv = 0.f;
+        if (owner && real && tt < n_valid) {
+            const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
+            c_state = __builtin_fmaf(gf, c_state, gi * gg);
+            hv = go * gt_tanh(c_state);
+        }
+        // (the encoding first: its acknowledgement is then waited for together with the state's)
+        if (owner && real) A.out[(size_t)grow * A.ldo + (size_t)tt * 2 * H + (size_t)d * H + unit] = hv;
+        if (t + 1 < A.T) {
+            if (owner) hbuf[(size_t)(t & 1) * 16 * H + gt_blk_off(row, unit, 1)] = hv;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's part of h_t is in the L2
+            __syncthreads();                                        // ... every wave's; and the LDS partials have been read
+            if (tid == 0) fl[(t & 1) * NM + rank] = (uint32_t)(t + 1);
+        }
+    }
+}
+
+// H = 256 (16 k-blocks on 8 waves, 64 tiles on 32 members); 2 directions x ceil(B/16) M-tiles must fit the 8 XCDs, each of
+// which must be able to hold its 32 members at once.
+bool gt_bilstm_persist_supported(int H, int B, int n_cu) { return H == 256 && B <= 64 && n_cu >= 256; }
+
+hipError_t gt_launch_bilstm_persist(const BiLstmPersistArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(gt_bilstm_persist_kernel, dim3(512), dim3(512), kPersistLds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t gt_bilstm_persist_init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gt_bilstm_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds);
+}
+
 bool gt_bilstm_lean_supported(int nkb_h) { return nkb_h == 16; }
 
 hipError_t gt_launch_bilstm_lean(const BiLstmArgs& a, hipStream_t stream) {

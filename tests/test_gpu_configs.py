@@ -198,3 +198,39 @@ def test_winograd_postnet_matches_the_oracle_and_the_implicit_gemm(monkeypatch):
         errs = {k: float(np.abs(v - ref).max()) for k, v in outs.items()}
         print("postnet", B, T, "max-abs error vs the float64 oracle:", errs)
         assert max(errs.values()) <= TOL
+
+
+def test_persistent_bilstm_is_bitwise_the_per_step_bilstm(monkeypatch):
+    """The encoder BiLSTM runs as ONE persistent launch (skinny_gemm.hip gt_bilstm_persist_kernel: weights and cell state in
+    registers, the hidden state handed between the 128 workgroups in memory with tagged flags) instead of one launch per token.
+    It is the per-step kernel's arithmetic in the per-step kernel's order, so the encodings must be BITWISE equal -- full
+    dimensions, 1 / 5 / 17 / 32 utterances (one and two M-tiles, partial tiles), 3 / 4 / 33 / 128 tokens, reference (unmasked) and
+    masked mode with ragged lengths, several calls per model (flags and state are re-used) -- and the wait's give-up flag clear.
+    33 utterances falls back to the per-step kernel by itself."""
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    from oracle import oracle_np
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, seed=3)
+    rng = np.random.default_rng(12)
+    cases = [(1, 3), (5, 4), (17, 33), (32, 128), (33, 20)]
+    enc = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GSTTACO_BILSTM_PERSIST", mode)
+        m = _model(hp, w, 33, 128, 4)
+        r = np.random.default_rng(12)
+        for B, Tv in cases:
+            tokens, tl = synthetic.make_tokens(r, B, Tv)
+            tl = r.integers(1, Tv + 1, B).astype(np.int32)
+            for rep in range(2):
+                enc[(mode, B, Tv, "ref", rep)] = m.encode(tokens).cpu().numpy()
+                enc[(mode, B, Tv, "masked", rep)] = m.encode(tokens, tl).cpu().numpy()
+        torch.cuda.synchronize()
+        assert m.handoff_error() == 0
+        if mode == "1":
+            ref = oracle_np.encoder(hp, oracle_np.cast_weights(w, np.float64), tokens, np.float64)
+            assert np.abs(enc[("1", 33, 20, "ref", 0)] - ref).max() <= TOL
+    for key, v in enc.items():
+        if key[0] == "1":
+            assert np.array_equal(v, enc[("0",) + key[1:]]), key
+            assert np.isfinite(v).all()
