@@ -16,12 +16,13 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_process_group(backend=None, device_index=None):
+def init_process_group(backend=None, device_index=None, force=False):
     """Idempotent init from the torchrun environment (MASTER_ADDR / MASTER_PORT / RANK / WORLD_SIZE).  With the "nccl"
     (= RCCL) backend the process group is bound to this rank's GPU (``device_id``), so the communicator is created eagerly
-    on the right device instead of lazily on whichever device is current at the first collective."""
+    on the right device instead of lazily on whichever device is current at the first collective.  A world of one needs no
+    process group and gets none unless ``force`` (the single-GPU RCCL test: communicator, gather and barrier on hardware)."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.device_count() > 0 else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -104,12 +105,13 @@ class PendingGather:
         return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(self._bufs, self._sizes)], dim=0)
 
 
-def gather_to_root(local, n_total=None, dst=0, async_op=False):
+def gather_to_root(local, n_total=None, dst=0, async_op=False, force=False):
     """Gather per-rank ``[B_local, ...]`` tensors to ``dst``; returns the concatenated tensor on ``dst``
     and None elsewhere.  Ragged shards (batch not divisible by world size) are padded to the largest
     shard for the collective and trimmed after it.  ``async_op=True`` returns a ``PendingGather`` instead, so that the
-    next batch's kernels are enqueued behind this batch's compute, not behind its gather."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    next batch's kernels are enqueued behind this batch's compute, not behind its gather.  A world of one returns ``local``
+    without a collective unless ``force``."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return PendingGather(None, None, None, None, local) if async_op else local
     world, rank = dist.get_world_size(), dist.get_rank()
     if n_total is None:

@@ -234,3 +234,39 @@ def test_persistent_bilstm_is_bitwise_the_per_step_bilstm(monkeypatch):
         if key[0] == "1":
             assert np.array_equal(v, enc[("0",) + key[1:]]), key
             assert np.isfinite(v).all()
+
+
+def test_rccl_communicator_gather_and_barrier_on_this_gpu(monkeypatch):
+    """The multi-GPU path's only collective is one gather of the mels to rank 0 over RCCL (`distributed.gather_to_root`).  The
+    test boxes have one GPU, so the N > 1 logic is covered by the world-size-2 gloo tests; what those cannot show is that the
+    "nccl" (= RCCL) backend initialises on this hardware with the process group bound to the device, and that the gather /
+    all-reduce / barrier calls the path makes run on it.  A forced world of ONE rank does exactly that: shard (the whole
+    batch), Inference_Step, synchronous and asynchronous gather through RCCL, compared with the local result."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from gst_tacotron_amd import distributed as gdist
+    from test_gpu_parity import _full_case
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    for k, v in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port)),
+                 ("HSA_ENABLE_IPC_MODE_LEGACY", "0")):
+        monkeypatch.setenv(k, v)
+    assert not dist.is_initialized()
+    rank, local_rank, world = gdist.init_process_group(backend="nccl", device_index=0, force=True)
+    try:
+        assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl"
+        B, Tv, Tref, steps = 5, 24, 40, 6
+        hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=3)
+        shard = gdist.shard_inputs({"tokens": tokens, "mels": mels, "mel_lengths": ml}, rank, world)
+        m = _model(hp, w, B, Tv, Tref + 1)
+        mel = m.Inference_Step(shard["tokens"], None, None, shard["mels"], shard["mel_lengths"], prenet_masks=masks, attn_noise=noise, steps=steps)[0]
+        got = gdist.gather_to_root(mel, force=True)                      # n_total via all_reduce, then dist.gather
+        pend = gdist.gather_to_root(mel, n_total=B, async_op=True, force=True)
+        got2 = pend.result()
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert got.shape == mel.shape and torch.equal(got, mel) and torch.equal(got2, mel)
+    finally:
+        dist.destroy_process_group()
