@@ -360,16 +360,17 @@ struct Wino {
 #define GT_WINO_OOB 0x80000000u
 #define WT 512             // threads: 8 waves as 2 (tile rows) x 4 (columns), each a 32 x 32 MFMA tile
 
-// One slice (32 input channels) of the transform-domain GEMM XI: this thread's A element (tile row f >> 3, channel quad f & 7)
-// = a combination of up to six input rows, and its two B pieces of U_XI.  Every gather load is an unconditional buffer load:
-// a row outside [0, len) gets an out-of-range offset and reads as zero (SAME padding / masked mode) -- no branches, so all
-// taps are in flight together and counted exactly.
+// One slice (32 input channels) of the transform-domain GEMM XI, REQUESTED: this thread's A element (tile row f >> 3, channel
+// quad f & 7) is a combination of up to six input rows -- the taps with a non-zero coefficient are loaded raw into d[] -- and
+// its two B pieces of U_XI.  Every gather load is an unconditional buffer load: a row outside [0, len) gets an out-of-range
+// offset and reads as zero (SAME padding / masked mode) -- no branches, so the number of loads in flight is known exactly at
+// every later point and the waits the compiler inserts are counted, not vmcnt(0).
 template <int MO, int XI>
-__device__ __forceinline__ void wino_load_slice(const ConvGemmArgs& A, __amdgpu_buffer_rsrc_t rs_x, const float* __restrict__ U, const uint32_t voff,
-                                                const int first, const int len, const int c0, const int n0, float4& ra, float4& rb0, float4& rb1) {
+__device__ __forceinline__ void wino_issue(const ConvGemmArgs& A, __amdgpu_buffer_rsrc_t rs_x, const float* __restrict__ U, const uint32_t voff,
+                                           const int first, const int len, const int c0, const int n0, float4 (&d)[Wino<MO>::ALPHA], float4& rb0,
+                                           float4& rb1) {
     constexpr int AL = Wino<MO>::ALPHA;
     const int tid = threadIdx.x;
-    float4 d[AL];
 #pragma unroll
     for (int tap = 0; tap < AL; ++tap) {
         if (Wino<MO>::bt(XI, tap) != 0.f) {
@@ -380,27 +381,36 @@ __device__ __forceinline__ void wino_load_slice(const ConvGemmArgs& A, __amdgpu_
         }
     }
     const float* Ux = U + (size_t)XI * A.wino_cin * A.N;
-    {
-        // 32 k rows x 32 float4 (128 columns): this thread's pieces are rows tid >> 5 and 16 + (tid >> 5), quad tid & 31
-        const int kr = tid >> 5, nq = tid & 31;
-        const int n = min(n0 + nq * 4, A.N - 4);       // (columns past N are never stored)
-        rb0 = *reinterpret_cast<const float4*>(Ux + (size_t)(c0 + kr) * A.N + n);
-        rb1 = *reinterpret_cast<const float4*>(Ux + (size_t)(c0 + 16 + kr) * A.N + n);
-    }
+    // 32 k rows x 32 float4 (128 columns): this thread's pieces are rows tid >> 5 and 16 + (tid >> 5), quad tid & 31
+    const int kr = tid >> 5, nq = tid & 31;
+    const int n = min(n0 + nq * 4, A.N - 4);           // (columns past N are never stored)
+    rb0 = *reinterpret_cast<const float4*>(Ux + (size_t)(c0 + kr) * A.N + n);
+    rb1 = *reinterpret_cast<const float4*>(Ux + (size_t)(c0 + 16 + kr) * A.N + n);
+}
+// ... and TRANSFORMED once it has arrived: V_XI = sum_tap BT[XI][tap] d[tap]
+template <int MO, int XI>
+__device__ __forceinline__ float4 wino_xform(const float4 (&d)[Wino<MO>::ALPHA]) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int tap = 0; tap < AL; ++tap) {
+    for (int tap = 0; tap < Wino<MO>::ALPHA; ++tap) {
         const float cf = Wino<MO>::bt(XI, tap);
         if (cf != 0.f) { v.x += cf * d[tap].x; v.y += cf * d[tap].y; v.z += cf * d[tap].z; v.w += cf * d[tap].w; }
     }
-    ra = v;
+    return v;
 }
 
+#ifdef GT_WINO_STAMPS          // tools/wino_bench.hip: cycle stamps of one step of workgroup (0, 0), wave 0
+__device__ unsigned long long gt_wino_stamp[64];
+#define WINO_STAMP(i) do { if (stamp_on) gt_wino_stamp[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WINO_STAMP(i) do { } while (0)
+#endif
+
 template <int MO>
-__global__ __launch_bounds__(WT, MO == 4 ? 2 : 4) void gt_conv_wino5_kernel(ConvGemmArgs A, const float* __restrict__ U) {
+__global__ __launch_bounds__(WT, 2) void gt_conv_wino5_kernel(ConvGemmArgs A, const float* __restrict__ U) {
     constexpr int AL = Wino<MO>::ALPHA;
     constexpr int BMP = 64, BN = 128, LDA = BMP + 1, LDB = BN + 4;
-    // two LDS stages: slice s + 1 is written while slice s is read, ONE barrier per slice (50 KB per workgroup)
+    // two LDS stages: slice g + 1 is written while slice g is read, ONE barrier per slice (50 KB per workgroup)
     __shared__ float As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -427,14 +437,13 @@ __global__ __launch_bounds__(WT, MO == 4 ? 2 : 4) void gt_conv_wino5_kernel(Conv
     for (int o = 0; o < MO; ++o)
 #pragma unroll
         for (int e = 0; e < 16; ++e) Y[o][e] = 0.f;
-    float4 ra, rb0, rb1;
     const int kh = lane >> 5, l31 = lane & 31;
-    // wino_cin = Cin rounded up to the slice width: U holds zero rows for the padding channels, whose x operand is whatever
+    // wino_cin = Cin rounded up to TWO slice widths: U holds zero rows for the padding channels, whose x operand is whatever
     // follows in memory (the next row's first channels, or zero past the tensor's end: the descriptor covers exactly B*T*Cin)
-    const int nsl = A.wino_cin / BK;
+    const int nsl = A.wino_cin / BK;                      // even, >= 4 (gt_conv_wino5_applies)
     int cur = 0;                                          // LDS stage the current slice sits in
 
-    auto store_slice = [&](int st) {
+    auto store_slice = [&](int st, const float4 ra, const float4 rb0, const float4 rb1) {
         const int row = tid >> 3, kq = (tid & 7) * 4;
         As[st][(kq + 0) * LDA + row] = ra.x;
         As[st][(kq + 1) * LDA + row] = ra.y;
@@ -443,37 +452,64 @@ __global__ __launch_bounds__(WT, MO == 4 ? 2 : 4) void gt_conv_wino5_kernel(Conv
         *reinterpret_cast<float4*>(&Bs[st][(tid >> 5) * LDB + (tid & 31) * 4]) = rb0;
         *reinterpret_cast<float4*>(&Bs[st][(16 + (tid >> 5)) * LDB + (tid & 31) * 4]) = rb1;
     };
+    // all 32 operand words of the slice are requested from LDS before the first MFMA (fully unrolled: counted lgkmcnt waits), so
+    // that the 16 dependent MFMAs run back to back instead of paying an LDS latency every other one
     auto mma_slice = [&](int st) {
-#pragma unroll 4
+        float av[BK / 2], bv[BK / 2];
+#pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             const int krow = kp * 2 + kh;
-            const float av = As[st][krow * LDA + wm * 32 + l31];
-            const float bv = Bs[st][krow * LDB + wn * 32 + l31];
-            M = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, M, 0, 0, 0);
+            av[kp] = As[st][krow * LDA + wm * 32 + l31];
+            bv[kp] = Bs[st][krow * LDB + wn * 32 + l31];
         }
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) M = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp], bv[kp], M, 0, 0, 0);
     };
-    // the transform-domain GEMMs, one after the other.  Per slice: request the NEXT slice (possibly the next GEMM's first),
-    // MFMAs on the current stage, write the next slice into the other stage, barrier.
+    // The transform-domain GEMMs, one after the other, as ONE stream of slices g = XI * nsl + s.  A slice's operands are
+    // requested TWO slices ahead into one of two register sets (dA / dB: the raw taps and the two B pieces) -- one slice of
+    // MFMAs (~0.9 us per SIMD) does not cover a trip to the L2 / Infinity Cache under load, two do -- and are transformed and
+    // written to the other LDS stage one slice ahead.  Step g: request g + 2 into the set slice g came from, MFMAs on the
+    // current stage, transform + store g + 1 from the other set, barrier.  The loop is unrolled by two so that the sets are
+    // named statically, and the last two steps of a pass (which request the NEXT pass's first slices, with its tap pattern)
+    // are peeled, so that every wait is a counted one.
+    float4 dA[AL], dB[AL], bA0, bA1, bB0, bB1;
+#define WINO_ISSUE(XIv, c0, D, B0, B1) wino_issue<MO, XIv>(A, rs_x, U, voff, first, len, (c0), n0, D, B0, B1)
+#define WINO_XSTORE(XIv, D, B0, B1) store_slice(cur ^ 1, wino_xform<MO, XIv>(D), B0, B1)
+#define WINO_END_STEP() do { __syncthreads(); cur ^= 1; } while (0)
+    // Nothing pins the order of the three parts of a step (requests, MFMAs, transform + store): left to the scheduler, the
+    // transform's VALU work and the LDS writes land between the dependent MFMAs (404 vs 415 us per 512 -> 512 layer with
+    // sched_barriers between the parts).  Tried and dropped: the two waves that share a SIMD doing MFMAs / transform + store in
+    // opposite order -- one wave's chain of dependent 32x32x2 MFMAs alone issues every ~135 cycles, two waves' interleaved
+    // chains every ~60 (the pipe's rate), so the MFMA phases must coincide (428 vs 418 us).
+#ifdef GT_WINO_STAMPS
+    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+#endif
+#define WINO_WORK(XIv, D, B0, B1) do { WINO_STAMP(1); mma_slice(cur); WINO_STAMP(2); WINO_XSTORE(XIv, D, B0, B1); WINO_STAMP(3); } while (0)
 #define WINO_PASS(XI)                                                                                             \
     if constexpr (XI < AL) {                                                                                      \
+        constexpr int XN = XI + 1 < AL ? XI + 1 : XI;                                                             \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) M[e] = 0.f;                                                 \
-        for (int s = 0; s < nsl; ++s) {                                                                           \
-            const bool more = s + 1 < nsl || XI + 1 < AL;                                                         \
-            if (s + 1 < nsl) wino_load_slice<MO, XI>(A, rs_x, U, voff, first, len, (s + 1) * BK, n0, ra, rb0, rb1); \
-            else if (XI + 1 < AL) wino_load_slice<MO, (XI + 1 < AL ? XI + 1 : 0)>(A, rs_x, U, voff, first, len, 0, n0, ra, rb0, rb1); \
-            mma_slice(cur);                                                                                       \
-            if (more) store_slice(cur ^ 1);                                                                       \
-            __syncthreads();                                                                                      \
-            cur ^= 1;                                                                                             \
+        for (int s = 0; s < nsl - 2; s += 2) {                                                                    \
+            WINO_STAMP(0); WINO_ISSUE(XI, (s + 2) * BK, dA, bA0, bA1); WINO_WORK(XI, dB, bB0, bB1); WINO_END_STEP(); WINO_STAMP(4); \
+            WINO_ISSUE(XI, (s + 3) * BK, dB, bB0, bB1); WINO_WORK(XI, dA, bA0, bA1); WINO_END_STEP();               \
         }                                                                                                         \
+        if constexpr (XI + 1 < AL) WINO_ISSUE(XN, 0, dA, bA0, bA1);                                               \
+        WINO_WORK(XI, dB, bB0, bB1); WINO_END_STEP();                                                             \
+        if constexpr (XI + 1 < AL) WINO_ISSUE(XN, BK, dB, bB0, bB1);                                              \
+        if constexpr (XI + 1 < AL) { WINO_WORK(XN, dA, bA0, bA1); WINO_END_STEP(); } else mma_slice(cur);         \
         _Pragma("unroll") for (int o = 0; o < MO; ++o)                                                             \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) Y[o][e] += Wino<MO>::at(o, XI) * M[e];                  \
     }
-    wino_load_slice<MO, 0>(A, rs_x, U, voff, first, len, 0, n0, ra, rb0, rb1);
-    store_slice(0);
+    WINO_ISSUE(0, 0, dA, bA0, bA1);
+    WINO_ISSUE(0, BK, dB, bB0, bB1);
+    store_slice(0, wino_xform<MO, 0>(dA), bA0, bA1);
     __syncthreads();
     WINO_PASS(0) WINO_PASS(1) WINO_PASS(2) WINO_PASS(3) WINO_PASS(4) WINO_PASS(5) WINO_PASS(6) WINO_PASS(7)
 #undef WINO_PASS
+#undef WINO_ISSUE
+#undef WINO_XSTORE
+#undef WINO_END_STEP
+#undef WINO_WORK
 
     // epilogue; 32x32 C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row -> MO output rows
     const int n = n0 + wn * 32 + l31;
@@ -503,8 +539,8 @@ __global__ __launch_bounds__(WT, MO == 4 ? 2 : 4) void gt_conv_wino5_kernel(Conv
 
 bool gt_conv_wino5_applies(const ConvGemmArgs& a) {
     return a.wino_u && !a.wt_bf16 && !a.conv2d && !a.pool2 && !a.tokens && a.N % 4 == 0 && a.N >= 4 && a.taps == 5 &&
-           (size_t)a.B * a.T * a.Cin * 4 < 0x7FFFFFFFull && a.pad_before == 2 && a.Cin % 4 == 0 && a.wino_cin % BK == 0 &&
-           a.wino_cin >= a.Cin && (a.ldw == 0 || a.ldw == a.N);
+           (size_t)a.B * a.T * a.Cin * 4 < 0x7FFFFFFFull && a.pad_before == 2 && a.Cin % 4 == 0 && a.wino_cin % (2 * BK) == 0 &&
+           a.wino_cin >= 4 * BK && a.wino_cin >= a.Cin && (a.ldw == 0 || a.ldw == a.N);
 }
 
 hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {

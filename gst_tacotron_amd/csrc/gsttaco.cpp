@@ -501,7 +501,7 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
                                        {-8.0 / 3, 4.0 / 3, -2.0 / 3, 1.0 / 3, -1.0 / 6},
                                        {0, 0, 0, 0, 1}};
         const size_t cn = (size_t)L->cin * L->cout;
-        L->wino_cin = (L->cin + 31) / 32 * 32;                  // zero rows for the padding channels
+        L->wino_cin = std::max(128, (L->cin + 63) / 64 * 64);   // zero rows for the padding channels (an even number >= 4 of 32-channel slices)
         const size_t cnp = (size_t)L->wino_cin * L->cout;
         std::vector<float> u(6 * cnp, 0.f);
         for (int xi = 0; xi < 6; ++xi)
