@@ -324,8 +324,9 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
 //     M_xi = V_xi . U_xi                  (six GEMMs over the input channels, U_xi = sum_k G[xi][k] w[k], formed in float64
 //                                          at finalize)
 //     y_0 = sum_xi M_xi (xi < 5),   y_1 = M_1 - M_2 + (M_3 - M_4) / 2 + M_5
-// One workgroup owns 64 tiles (128 output rows) x 128 columns; the six GEMMs run one after the other on ONE accumulator set
-// which is folded into the two output accumulators after each (V never touches memory, no cross-workgroup reduction).
+// One workgroup owns 64 tiles (128 output rows) x 128 columns; each of the six GEMMs has its own 32 x 32 accumulator tile per wave,
+// advanced one 32-channel slice at a time in turn (the slice's input rows are fetched once for all six), and the output
+// transform is the epilogue's (V never touches memory, no cross-workgroup reduction).
 // Measured error on the postnet's shapes: 2-3.6e-6 max-abs at |y| ~ 3 (the direct fp32 sum: 1.1e-6) -- tools/wino_error.py.
 // Applies to: taps == 5, pad_before == 2, Cin % 32 == 0, no pooling, no 2-D mode.
 // Transform rows at compile time.  MO = outputs per tile: 2 -> F(2,5), points 0, +-1, +-1/2, inf (6 GEMMs per 2 outputs, 0.6x
@@ -360,32 +361,33 @@ struct Wino {
 #define GT_WINO_OOB 0x80000000u
 #define WT 512             // threads: 8 waves as 2 (tile rows) x 4 (columns), each a 32 x 32 MFMA tile
 
-// One slice (32 input channels) of the transform-domain GEMM XI, REQUESTED: this thread's A element (tile row f >> 3, channel
-// quad f & 7) is a combination of up to six input rows -- the taps with a non-zero coefficient are loaded raw into d[] -- and
-// its two B pieces of U_XI.  Every gather load is an unconditional buffer load: a row outside [0, len) gets an out-of-range
-// offset and reads as zero (SAME padding / masked mode) -- no branches, so the number of loads in flight is known exactly at
-// every later point and the waits the compiler inserts are counted, not vmcnt(0).
-template <int MO, int XI>
-__device__ __forceinline__ void wino_issue(const ConvGemmArgs& A, __amdgpu_buffer_rsrc_t rs_x, const float* __restrict__ U, const uint32_t voff,
-                                           const int first, const int len, const int c0, const int n0, float4 (&d)[Wino<MO>::ALPHA], float4& rb0,
-                                           float4& rb1) {
-    constexpr int AL = Wino<MO>::ALPHA;
-    const int tid = threadIdx.x;
+// One slice (32 input channels), REQUESTED: this thread's A element (tile row f >> 3, channel quad f & 7) of every one of the
+// ALPHA transform-domain GEMMs is a combination of the same ALPHA input rows ("taps"), which are loaded raw into d[] ONCE per
+// slice.  Every gather load is an unconditional buffer load: a row outside [0, len) gets an out-of-range offset and reads as
+// zero (SAME padding / masked mode; also a slice past the last one) -- no branches, so the number of loads in flight is known
+// exactly at every later point and the waits the compiler inserts are counted, not vmcnt(0).
+template <int MO>
+__device__ __forceinline__ void wino_issue_taps(const ConvGemmArgs& A, __amdgpu_buffer_rsrc_t rs_x, const uint32_t voff, const int first, const int len,
+                                                const int c0, const bool live, float4 (&d)[Wino<MO>::ALPHA]) {
 #pragma unroll
-    for (int tap = 0; tap < AL; ++tap) {
-        if (Wino<MO>::bt(XI, tap) != 0.f) {
-            const int ts = first + tap;
-            const uint32_t vo = (ts >= 0 && ts < len) ? voff + (uint32_t)(tap * A.Cin * 4) : GT_WINO_OOB;
-            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo, c0 * 4, 0);
-            __builtin_memcpy(&d[tap], &t, 16);
-        }
+    for (int tap = 0; tap < Wino<MO>::ALPHA; ++tap) {
+        const int ts = first + tap;
+        const uint32_t vo = (live && ts >= 0 && ts < len) ? voff + (uint32_t)(tap * A.Cin * 4) : GT_WINO_OOB;
+        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo, c0 * 4, 0);
+        __builtin_memcpy(&d[tap], &t, 16);
     }
-    const float* Ux = U + (size_t)XI * A.wino_cin * A.N;
-    // 32 k rows x 32 float4 (128 columns): this thread's pieces are rows tid >> 5 and 16 + (tid >> 5), quad tid & 31
-    const int kr = tid >> 5, nq = tid & 31;
-    const int n = min(n0 + nq * 4, A.N - 4);           // (columns past N are never stored)
-    rb0 = *reinterpret_cast<const float4*>(Ux + (size_t)(c0 + kr) * A.N + n);
-    rb1 = *reinterpret_cast<const float4*>(Ux + (size_t)(c0 + 16 + kr) * A.N + n);
+}
+// ... and this thread's two pieces of the B slice U_XI[c0 .. c0 + 32): k rows tid >> 5 and 16 + (tid >> 5), quad tid & 31.  Buffer
+// loads with the (XI, slice) part of the address in the SCALAR offset: the two per-thread offsets are the same for every
+// step, so nothing per step lives in vector registers (as 64-bit pointers, hoisted out of the unrolled loop, the 16 steps'
+// addresses cost 32 registers -- spilled, and every scratch reload waits for vmcnt(0), i.e. for all the prefetches).
+__device__ __forceinline__ void wino_issue_b(const ConvGemmArgs& A, __amdgpu_buffer_rsrc_t rs_u, const uint32_t vb0, const uint32_t vb1, const int xi,
+                                             const int c0, float4& rb0, float4& rb1) {
+    const int so = (xi * A.wino_cin + c0) * A.N * 4;
+    const auto t0 = __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)vb0, so, 0);
+    const auto t1 = __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)vb1, so, 0);
+    __builtin_memcpy(&rb0, &t0, 16);
+    __builtin_memcpy(&rb1, &t1, 16);
 }
 // ... and TRANSFORMED once it has arrived: V_XI = sum_tap BT[XI][tap] d[tap]
 template <int MO, int XI>
@@ -399,11 +401,8 @@ __device__ __forceinline__ float4 wino_xform(const float4 (&d)[Wino<MO>::ALPHA])
     return v;
 }
 
-#ifdef GT_WINO_STAMPS          // tools/wino_bench.hip: cycle stamps of one step of workgroup (0, 0), wave 0
-__device__ unsigned long long gt_wino_stamp[64];
-#define WINO_STAMP(i) do { if (stamp_on) gt_wino_stamp[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define WINO_STAMP(i) do { } while (0)
+#ifdef GT_WINO_STAMPS          // tools/wino_bench.hip: one cycle stamp per step of workgroup 0, wave 0
+__device__ unsigned long long gt_wino_stamp[1024];
 #endif
 
 template <int MO>
@@ -417,7 +416,16 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5_kernel(ConvGemmArgs A, co
     const int wm = wave >> 2, wn = wave & 3;
     const int Pu = (A.T + MO - 1) / MO;                  // tiles per utterance
     const int Ptot = A.B * Pu;
-    const int p0 = blockIdx.x * BMP, n0 = blockIdx.y * BN;
+    // Workgroup -> (row block, column block): the column blocks of one row block read the same input rows, and an XCD's L2
+    // (4 MB) holds the rows of about eight row blocks -- so they must run on the SAME XCD at the SAME time.  Workgroups are
+    // dealt to the XCDs round-robin by linear id: XCD x's i-th workgroup takes column block i % ncb of row block
+    // (i / ncb) * 8 + x.  (Pass-major kernel: 1.9 GB fetched from the memory side per 512 -> 512 layer for 73 MB of operands,
+    // L2 hit rate 0.39; with this mapping 0.55 GB and 0.80.  The launch is 1-D, rounded up to whole groups of 8 row blocks.)
+    const int ncb = (A.N + BN - 1) / BN;
+    const int wi = blockIdx.x >> 3;
+    const int rb = (wi / ncb) * 8 + (blockIdx.x & 7), cb = wi % ncb;
+    if (rb * BMP >= Ptot) return;
+    const int p0 = rb * BMP, n0 = cb * BN;
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x), 0, (int)((size_t)A.B * A.T * A.Cin * 4), 0x00020000);
     // this thread's A element: tile row tid >> 3, channel quad tid & 7
     int first, len;
@@ -432,16 +440,17 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5_kernel(ConvGemmArgs A, co
         // (the first rows of utterance 0 give a negative row index: those taps are out of range anyway, the wrapped offset is unused)
         voff = (uint32_t)(((int64_t)b * A.T + first) * A.Cin + (tid & 7) * 4) * 4u;
     }
-    f32x16 M, Y[MO];
+    // one accumulator tile per transform-domain GEMM (8 x 16 registers for F(4,5)); the output transform is the epilogue's
+    f32x16 M[AL];
 #pragma unroll
-    for (int o = 0; o < MO; ++o)
+    for (int xi = 0; xi < AL; ++xi)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Y[o][e] = 0.f;
+        for (int e = 0; e < 16; ++e) M[xi][e] = 0.f;
     const int kh = lane >> 5, l31 = lane & 31;
     // wino_cin = Cin rounded up to TWO slice widths: U holds zero rows for the padding channels, whose x operand is whatever
     // follows in memory (the next row's first channels, or zero past the tensor's end: the descriptor covers exactly B*T*Cin)
     const int nsl = A.wino_cin / BK;                      // even, >= 4 (gt_conv_wino5_applies)
-    int cur = 0;                                          // LDS stage the current slice sits in
+    int cur = 0;                                          // LDS stage the current step's operands sit in
 
     auto store_slice = [&](int st, const float4 ra, const float4 rb0, const float4 rb1) {
         const int row = tid >> 3, kq = (tid & 7) * 4;
@@ -452,64 +461,74 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5_kernel(ConvGemmArgs A, co
         *reinterpret_cast<float4*>(&Bs[st][(tid >> 5) * LDB + (tid & 31) * 4]) = rb0;
         *reinterpret_cast<float4*>(&Bs[st][(16 + (tid >> 5)) * LDB + (tid & 31) * 4]) = rb1;
     };
-    // all 32 operand words of the slice are requested from LDS before the first MFMA (fully unrolled: counted lgkmcnt waits), so
-    // that the 16 dependent MFMAs run back to back instead of paying an LDS latency every other one
-    auto mma_slice = [&](int st) {
-        float av[BK / 2], bv[BK / 2];
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            const int krow = kp * 2 + kh;
-            av[kp] = As[st][krow * LDA + wm * 32 + l31];
-            bv[kp] = Bs[st][krow * LDB + wn * 32 + l31];
-        }
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) M = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kp], bv[kp], M, 0, 0, 0);
-    };
-    // The transform-domain GEMMs, one after the other, as ONE stream of slices g = XI * nsl + s.  A slice's operands are
-    // requested TWO slices ahead into one of two register sets (dA / dB: the raw taps and the two B pieces) -- one slice of
-    // MFMAs (~0.9 us per SIMD) does not cover a trip to the L2 / Infinity Cache under load, two do -- and are transformed and
-    // written to the other LDS stage one slice ahead.  Step g: request g + 2 into the set slice g came from, MFMAs on the
-    // current stage, transform + store g + 1 from the other set, barrier.  The loop is unrolled by two so that the sets are
-    // named statically, and the last two steps of a pass (which request the NEXT pass's first slices, with its tap pattern)
-    // are peeled, so that every wait is a counted one.
-    float4 dA[AL], dB[AL], bA0, bA1, bB0, bB1;
-#define WINO_ISSUE(XIv, c0, D, B0, B1) wino_issue<MO, XIv>(A, rs_x, U, voff, first, len, (c0), n0, D, B0, B1)
-#define WINO_XSTORE(XIv, D, B0, B1) store_slice(cur ^ 1, wino_xform<MO, XIv>(D), B0, B1)
-#define WINO_END_STEP() do { __syncthreads(); cur ^= 1; } while (0)
-    // Nothing pins the order of the three parts of a step (requests, MFMAs, transform + store): left to the scheduler, the
-    // transform's VALU work and the LDS writes land between the dependent MFMAs (404 vs 415 us per 512 -> 512 layer with
-    // sched_barriers between the parts).  Tried and dropped: the two waves that share a SIMD doing MFMAs / transform + store in
-    // opposite order -- one wave's chain of dependent 32x32x2 MFMAs alone issues every ~135 cycles, two waves' interleaved
-    // chains every ~60 (the pipe's rate), so the MFMA phases must coincide (428 vs 418 us).
-#ifdef GT_WINO_STAMPS
-    const bool stamp_on = blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
-#endif
-#define WINO_WORK(XIv, D, B0, B1) do { WINO_STAMP(1); mma_slice(cur); WINO_STAMP(2); WINO_XSTORE(XIv, D, B0, B1); WINO_STAMP(3); } while (0)
-#define WINO_PASS(XI)                                                                                             \
-    if constexpr (XI < AL) {                                                                                      \
-        constexpr int XN = XI + 1 < AL ? XI + 1 : XI;                                                             \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) M[e] = 0.f;                                                 \
-        for (int s = 0; s < nsl - 2; s += 2) {                                                                    \
-            WINO_STAMP(0); WINO_ISSUE(XI, (s + 2) * BK, dA, bA0, bA1); WINO_WORK(XI, dB, bB0, bB1); WINO_END_STEP(); WINO_STAMP(4); \
-            WINO_ISSUE(XI, (s + 3) * BK, dB, bB0, bB1); WINO_WORK(XI, dA, bA0, bA1); WINO_END_STEP();               \
-        }                                                                                                         \
-        if constexpr (XI + 1 < AL) WINO_ISSUE(XN, 0, dA, bA0, bA1);                                               \
-        WINO_WORK(XI, dB, bB0, bB1); WINO_END_STEP();                                                             \
-        if constexpr (XI + 1 < AL) WINO_ISSUE(XN, BK, dB, bB0, bB1);                                              \
-        if constexpr (XI + 1 < AL) { WINO_WORK(XN, dA, bA0, bA1); WINO_END_STEP(); } else mma_slice(cur);         \
-        _Pragma("unroll") for (int o = 0; o < MO; ++o)                                                             \
-            _Pragma("unroll") for (int e = 0; e < 16; ++e) Y[o][e] += Wino<MO>::at(o, XI) * M[e];                  \
+    // A step's 32 operand words are requested from LDS before its first MFMA (fully unrolled: counted lgkmcnt waits), so that
+    // the 16 dependent MFMAs run back to back instead of paying an LDS latency every other one.
+#define WINO_MMA(ACC) do {                                                                                         \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                         \
+            float av_[BK / 4], bv_[BK / 4];                                                                        \
+            _Pragma("unroll") for (int kp = 0; kp < BK / 4; ++kp) {                                                \
+                const int krow = (h_ * (BK / 4) + kp) * 2 + kh;                                                    \
+                av_[kp] = As[cur][krow * LDA + wm * 32 + l31];                                                     \
+                bv_[kp] = Bs[cur][krow * LDB + wn * 32 + l31];                                                     \
+            }                                                                                                      \
+            _Pragma("unroll") for (int kp = 0; kp < BK / 4; ++kp) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[kp], bv_[kp], ACC, 0, 0, 0); \
+        }                                                                                                          \
+    } while (0)
+    // The work is ONE stream of steps g = s * ALPHA + XI, SLICE-major: the ALPHA transform-domain GEMMs of a 32-channel slice
+    // follow each other, each on its own accumulator, so that the slice's raw input rows are fetched ONCE (into dE / dO, even /
+    // odd slices, seven steps ahead) instead of once per GEMM -- the pass-major order moved 61 KB per step and CU through the
+    // L1 (1 630 cycles per step with the MFMAs taken out, against 2 050 of MFMA), this one 24 KB.  Per step: request the B
+    // slice of step g + 2 (two register sets by step parity), at XI = 0 the next slice's taps; the MFMAs on the current LDS
+    // stage; transform + store the operands of step g + 1 into the other stage; barrier.  Nothing pins the order inside a
+    // step: left to the scheduler, the transform's VALU work and the LDS writes land between the dependent MFMAs.  Slices are
+    // unrolled by two so that the tap sets are named statically; every load is unconditional, so every wait is a counted one.
+    // (Tried and dropped: the two waves that share a SIMD doing MFMAs / transform + store in opposite order -- one wave's chain
+    // of dependent 32x32x2 MFMAs alone issues every ~135 cycles, two waves' interleaved chains every ~60 = the pipe's rate; two
+    // 4-wave workgroups per CU instead of one 8-wave one; three LDS stages with the next step's operands read ahead of the
+    // barrier -- none faster while the L1 traffic was the limit.)
+    float4 dE[AL], dO[AL], bP0, bP1;
+    const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, (int)((size_t)AL * A.wino_cin * A.N * 4), 0x00020000);
+    const uint32_t vb0 = (uint32_t)(((tid >> 5) * A.N + min(n0 + (tid & 31) * 4, A.N - 4)) * 4);   // (columns past N are never stored)
+    const uint32_t vb1 = vb0 + (uint32_t)(16 * A.N * 4);
+#define WINO_BSET0 bP0, bP1
+#define WINO_BSET1 bQ0, bQ1
+#define WINO_STEP(XI, DCUR, DNXT, s_)                                                                              \
+    {                                                                                                             \
+        constexpr int XI1 = (XI + 1) % AL;                                                                         \
+        /* (past the last step: a valid address whose data is never used) */                                      \
+        wino_issue_b(A, rs_u, vb0, vb1, XI1, min((s_) + (XI + 1 >= AL ? 1 : 0), nsl - 1) * BK, bP0, bP1);          \
+        if constexpr (XI == 0) wino_issue_taps<MO>(A, rs_x, voff, first, len, min((s_) + 1, nsl - 1) * BK, (s_) + 1 < nsl, DNXT); \
+        WINO_MMA(M[XI]);                                                                                          \
+        if constexpr (XI + 1 < AL) store_slice(cur ^ 1, wino_xform<MO, XI1>(DCUR), bP0, bP1);                     \
+        else store_slice(cur ^ 1, wino_xform<MO, 0>(DNXT), bP0, bP1);                                             \
+        __syncthreads();                                                                                          \
+        cur ^= 1;                                                                                                 \
+        WINO_STAMP_STEP();                                                                                        \
     }
-    WINO_ISSUE(0, 0, dA, bA0, bA1);
-    WINO_ISSUE(0, BK, dB, bB0, bB1);
-    store_slice(0, wino_xform<MO, 0>(dA), bA0, bA1);
+#define WINO_SLICE(DCUR, DNXT, s_)                                                                                 \
+    WINO_STEP(0, DCUR, DNXT, s_) WINO_STEP(1, DCUR, DNXT, s_) WINO_STEP(2, DCUR, DNXT, s_) WINO_STEP(3, DCUR, DNXT, s_) \
+    WINO_STEP(4, DCUR, DNXT, s_) WINO_STEP(5, DCUR, DNXT, s_)                                                      \
+    if constexpr (AL == 8) { WINO_STEP(6 % AL, DCUR, DNXT, s_) WINO_STEP(7 % AL, DCUR, DNXT, s_) }
+#ifdef GT_WINO_STAMPS
+    const bool stamp_on = blockIdx.x == 0 && tid == 0;
+    int nstamp = 0;
+#define WINO_STAMP_STEP() do { if (stamp_on && nstamp < 1023) gt_wino_stamp[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WINO_STAMP_STEP() do { } while (0)
+#endif
+    // B(g) lives in set g & 1 (ALPHA is even).  Prologue: taps of slice 0, B of steps 0 and 1, operands of step 0 into stage 0.
+    wino_issue_taps<MO>(A, rs_x, voff, first, len, 0, true, dE);
+    wino_issue_b(A, rs_u, vb0, vb1, 0, 0, bP0, bP1);
+    store_slice(0, wino_xform<MO, 0>(dE), bP0, bP1);
     __syncthreads();
-    WINO_PASS(0) WINO_PASS(1) WINO_PASS(2) WINO_PASS(3) WINO_PASS(4) WINO_PASS(5) WINO_PASS(6) WINO_PASS(7)
-#undef WINO_PASS
-#undef WINO_ISSUE
-#undef WINO_XSTORE
-#undef WINO_END_STEP
-#undef WINO_WORK
+    for (int s = 0; s < nsl; s += 2) {
+        WINO_SLICE(dE, dO, s)
+        WINO_SLICE(dO, dE, s + 1)
+    }
+#undef WINO_SLICE
+#undef WINO_STEP
+#undef WINO_MMA
+#undef WINO_STAMP_STEP
 
     // epilogue; 32x32 C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row -> MO output rows
     const int n = n0 + wn * 32 + l31;
@@ -526,7 +545,11 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5_kernel(ConvGemmArgs A, co
                 const int t = t0 + o;
                 if (t >= A.T) continue;
                 const int64_t m = (int64_t)b * A.T + t;
-                float v = Y[o][e] * sc + sh;
+                float y = 0.f;                         // output transform: y_o = sum_xi AT[o][xi] M_xi
+#pragma unroll
+                for (int xi = 0; xi < AL; ++xi)
+                    if (Wino<MO>::at(o, xi) != 0.f) y += Wino<MO>::at(o, xi) * M[xi][e];
+                float v = y * sc + sh;
                 if (A.rowbias) v += A.rowbias[(int64_t)b * A.N + n];
                 if (A.act == ACT_RELU) v = fmaxf(v, 0.f);
                 else if (A.act == ACT_TANH) v = gt_tanh(v);
@@ -561,12 +584,13 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         static const int min_wgs = getenv("GSTTACO_WINO_MIN_WGS") ? atoi(getenv("GSTTACO_WINO_MIN_WGS")) : 240;
         const int nb = (a.N + 127) / 128;
         const int P4 = a.B * ((a.T + 3) / 4), P2 = a.B * ((a.T + 1) / 2);
+        // (1-D grids: 8 XCDs x ceil(row blocks / 8) x column blocks, see the kernel)
         if (a.wino_u4 && ((P4 + 63) / 64) * nb >= min_wgs) {
-            hipLaunchKernelGGL(gt_conv_wino5_kernel<4>, dim3((P4 + 63) / 64, nb), dim3(WT), 0, stream, a, a.wino_u4);
+            hipLaunchKernelGGL(gt_conv_wino5_kernel<4>, dim3(8 * (((P4 + 63) / 64 + 7) / 8) * nb), dim3(WT), 0, stream, a, a.wino_u4);
             return hipGetLastError();
         }
         if (((P2 + 63) / 64) * nb >= min_wgs) {
-            hipLaunchKernelGGL(gt_conv_wino5_kernel<2>, dim3((P2 + 63) / 64, nb), dim3(WT), 0, stream, a, a.wino_u);
+            hipLaunchKernelGGL(gt_conv_wino5_kernel<2>, dim3(8 * (((P2 + 63) / 64 + 7) / 8) * nb), dim3(WT), 0, stream, a, a.wino_u);
             return hipGetLastError();
         }
     }

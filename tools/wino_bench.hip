@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <vector>
 #include <random>
+#include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 int main() {
     const int B = 32, T = 1000, C = 512, N = 512;
@@ -21,16 +22,19 @@ int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(gt_conv_wino5_kernel<4>, dim3((P4 + 63) / 64, 4), dim3(WT), 0, 0, a, a.wino_u4);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(gt_conv_wino5_kernel<4>, dim3(8 * (((P4 + 63) / 64 + 7) / 8) * 4), dim3(WT), 0, 0, a, a.wino_u4);
         CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("F(4,5) 512->512, 32 x 1000 frames: %.1f us / launch = %.1f TF of MFMA work (%.1f TF direct-equivalent)\n", ms * 100, 33.55e9 / (ms * 1e-4) * 1e-12,
                83.9e9 / (ms * 1e-4) * 1e-12);
     }
 #ifdef GT_WINO_STAMPS
-    unsigned long long st[64]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(gt_wino_stamp), sizeof(st)));
-    printf("step of WG(0,0) wave 0, cycles: issue %llu | mma %llu | xform+store %llu | barrier %llu | total %llu\n", st[1] - st[0], st[2] - st[1], st[3] - st[2],
-           st[4] - st[3], st[4] - st[0]);
+    static unsigned long long st[1024]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(gt_wino_stamp), sizeof(st)));
+    std::vector<long long> dt;
+    for (int i = 1; i < 127; ++i) dt.push_back((long long)(st[i] - st[i - 1]));
+    std::sort(dt.begin(), dt.end());
+    printf("cycles per step (s_memtime ticks), WG 0 wave 0: min %lld median %lld p90 %lld max %lld; first->last %lld over 126 steps\n", dt[0], dt[dt.size() / 2],
+           dt[dt.size() * 9 / 10], dt.back(), (long long)(st[126] - st[0]));
 #endif
     return 0;
 }
