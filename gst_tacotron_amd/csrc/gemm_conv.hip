@@ -492,15 +492,27 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5_kernel(ConvGemmArgs A, co
     const uint32_t vb1 = vb0 + (uint32_t)(16 * A.N * 4);
 #define WINO_BSET0 bP0, bP1
 #define WINO_BSET1 bQ0, bQ1
+    // (ablation switches of tools/wino_bench.hip; the product compiles the plain forms)
+#ifdef GT_WINO_NO_MFMA
+#define WINO_ABL_MMA(ACC) do { ACC[0] += As[cur][tid & 31] + Bs[cur][tid & 31]; } while (0)
+#else
+#define WINO_ABL_MMA(ACC) WINO_MMA(ACC)
+#endif
+#ifdef GT_WINO_NO_XSTORE
+    auto abl_sink = [&](int, const float4 ra_, const float4 b0_, const float4 b1_) { M[0][1] += ra_.x + ra_.y + ra_.z + ra_.w + b0_.x + b1_.y; };
+#define WINO_ABL_STORE(...) abl_sink(__VA_ARGS__)
+#else
+#define WINO_ABL_STORE(...) store_slice(__VA_ARGS__)
+#endif
 #define WINO_STEP(XI, DCUR, DNXT, s_)                                                                              \
     {                                                                                                             \
         constexpr int XI1 = (XI + 1) % AL;                                                                         \
         /* (past the last step: a valid address whose data is never used) */                                      \
         wino_issue_b(A, rs_u, vb0, vb1, XI1, min((s_) + (XI + 1 >= AL ? 1 : 0), nsl - 1) * BK, bP0, bP1);          \
         if constexpr (XI == 0) wino_issue_taps<MO>(A, rs_x, voff, first, len, min((s_) + 1, nsl - 1) * BK, (s_) + 1 < nsl, DNXT); \
-        WINO_MMA(M[XI]);                                                                                          \
-        if constexpr (XI + 1 < AL) store_slice(cur ^ 1, wino_xform<MO, XI1>(DCUR), bP0, bP1);                     \
-        else store_slice(cur ^ 1, wino_xform<MO, 0>(DNXT), bP0, bP1);                                             \
+        WINO_ABL_MMA(M[XI]);                                                                                      \
+        if constexpr (XI + 1 < AL) WINO_ABL_STORE(cur ^ 1, wino_xform<MO, XI1>(DCUR), bP0, bP1);                  \
+        else WINO_ABL_STORE(cur ^ 1, wino_xform<MO, 0>(DNXT), bP0, bP1);                                          \
         __syncthreads();                                                                                          \
         cur ^= 1;                                                                                                 \
         WINO_STAMP_STEP();                                                                                        \
@@ -528,6 +540,8 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5_kernel(ConvGemmArgs A, co
 #undef WINO_SLICE
 #undef WINO_STEP
 #undef WINO_MMA
+#undef WINO_ABL_MMA
+#undef WINO_ABL_STORE
 #undef WINO_STAMP_STEP
 
     // epilogue; 32x32 C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); tile row -> MO output rows
