@@ -104,7 +104,8 @@ struct gsttaco_ctx {
     // [prenet | context] buffer (the front end of step t writes it while the projection of step t-1 still reads the other)
     float* w_slab[2] = {nullptr, nullptr};
     GtGranule* w_z0g = nullptr;
-    uint32_t* w_err = nullptr;
+    uint32_t* w_err = nullptr;   // device alias of h_err: [0] merged decode launch, [1] persistent BiLSTM
+    uint32_t* h_err = nullptr;
     float* w_xa2 = nullptr;
     bool split_rec = true;
     int keep_x_weights = 1;
@@ -779,7 +780,6 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     if (merged_ok) {
         // tags of an earlier call must not match this call's step numbers
         HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_z0g), (size_t)MT * 16 * P0 * 2, s));
-        HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_err), 4, s));
     }
     // throughput mode: the whole decode's dropout masks and sigmoid noise are generated up front (same Philox streams the
     // step kernels would draw) into the buffers injected tensors use, so no step spends time on random numbers
@@ -1282,6 +1282,11 @@ int check_shape(gsttaco_ctx* c, int B, int Tv, int Tref1, int steps) {
 // see gsttaco_ctx::graphs).
 template <typename F>
 int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key, F body) {
+    // an in-kernel wait of an EARLIER call gave up (a producer workgroup never became resident): that call's outputs were
+    // garbage; say so now rather than never.  Sticky until the context is destroyed.
+    if (c->h_err && (c->h_err[0] | c->h_err[1]))
+        return fail(c, GSTTACO_E_HIP, "an in-kernel hand-off of a previous call gave up (persistent BiLSTM / merged decode launch): its outputs are invalid; "
+                                      "set GSTTACO_BILSTM_PERSIST=0 / GSTTACO_MERGED=0 and re-create the context");
     if (!c->use_graph || c->graph_cache_max < 1) return body(stream);
     const uint64_t now = ++c->graph_clock;
     auto it = c->graphs.find(key);
@@ -1447,6 +1452,7 @@ void gsttaco_destroy(gsttaco_ctx* c) {
 
 
     for (void* p : c->allocs) (void)hipFree(p);
+    if (c->h_err) (void)hipHostFree(c->h_err);
     delete c;
 }
 
@@ -1749,8 +1755,11 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     HIPCHECK(c, hipMemset(c->w_xa2, 0, Bp * (c->P1 + c->att) * sizeof(float)));
     if ((rc = dev_alloc(c, (void**)&c->w_z0g, Bp * c->P0 * sizeof(GtGranule)))) return rc;
     HIPCHECK(c, hipMemset(c->w_z0g, 0, Bp * c->P0 * sizeof(GtGranule)));
-    if ((rc = dev_alloc(c, (void**)&c->w_err, 16))) return rc;
-    HIPCHECK(c, hipMemset(c->w_err, 0, 16));
+    // the give-up words of the in-kernel hand-offs live in host-mapped memory: the device raises them with a system-scope
+    // atomic (failure path only), the host reads them without a synchronisation at the start of the next call
+    HIPCHECK(c, hipHostMalloc((void**)&c->h_err, 16, hipHostMallocMapped));
+    memset(c->h_err, 0, 16);
+    HIPCHECK(c, hipHostGetDevicePointer((void**)&c->w_err, c->h_err, 0));
     if ((rc = fa(&c->w_c1, B * c->H1))) return rc;
     if ((rc = fa(&c->w_c2, B * c->H2))) return rc;
     if ((rc = fa(&c->w_pre, B * Tf * mel))) return rc;
@@ -2081,9 +2090,14 @@ int gsttaco_debug_randomness(gsttaco_ctx* c, float* host_masks, float* host_nois
 int gsttaco_debug_handoff_error(gsttaco_ctx* c, uint32_t* host_out) {
     if (!c || !host_out || !c->w_err) return GSTTACO_E_INVALID;
     HIPCHECK(c, hipDeviceSynchronize());
-    uint32_t words[2] = {0, 0};                     // [0] merged decode launch, [1] persistent BiLSTM (sticky)
-    HIPCHECK(c, hipMemcpy(words, c->w_err, 8, hipMemcpyDeviceToHost));
-    *host_out = words[0] | (words[1] << 8);
+    *host_out = c->h_err[0] | (c->h_err[1] << 8);   // [0] merged decode launch, [1] persistent BiLSTM (sticky)
+    return 0;
+}
+
+int gsttaco_debug_raise_handoff_error(gsttaco_ctx* c, uint32_t bits) {
+    if (!c || !c->h_err) return GSTTACO_E_INVALID;
+    c->h_err[0] |= bits & 0xFFu;
+    c->h_err[1] |= bits >> 8;
     return 0;
 }
 

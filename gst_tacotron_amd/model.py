@@ -313,7 +313,8 @@ class GST_Tacotron:
         self.ctx.check(self.ctx.lib.gsttaco_set_graph_policy(self.ctx.handle, int(max_cached), int(capture_after)))
 
     def handoff_error(self):
-        """1 if an in-kernel hand-off wait of the experimental merged decode launch gave up in the last call (test support)."""
+        """Non-zero if an in-kernel hand-off wait ever gave up on this context (bit 0: merged decode launch, bit 8: persistent
+        BiLSTM; ``gsttaco_debug_handoff_error``).  The library itself refuses every later compute call once that happens."""
         out = ctypes.c_uint32(0)
         self.ctx.check(self.ctx.lib.gsttaco_debug_handoff_error(self.ctx.handle, ctypes.byref(out)))
         return int(out.value)

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 8
+#define GSTTACO_ABI_VERSION 9
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -249,9 +249,15 @@ int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
 /* Diagnostic (GSTTACO_STAMPS=1): 3 x 16 phase stamps (100 MHz ticks) of workgroup 0 of the fused front kernel
  * and the two decode LSTM kernels at the middle decode step of the last replay.  Synchronises the device. */
 int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
-/* Test support (experimental three-launch decode step, GSTTACO_MERGED=1): 1 if an in-kernel wait for the projection's
- * granules ever gave up in the last decode (a bug, never a normal outcome), else 0.  Synchronises the device. */
+/* In-kernel hand-offs (the persistent BiLSTM launch; the experimental three-launch decode step, GSTTACO_MERGED=1) wait with a
+ * bound: a wait that gives up (a producer workgroup that never became resident -- a bug or a starved GPU, never a normal
+ * outcome) raises a word in host-mapped memory instead of hanging the device.  The outputs of that call are invalid, and
+ * EVERY LATER compute call on the context fails with GSTTACO_E_HIP (sticky; gsttaco_last_error says which knob disables the
+ * path).  This function synchronises the device and returns the words now: bit 0 merged decode launch, bit 8 persistent
+ * BiLSTM; 0 = no wait has ever given up. */
 int gsttaco_debug_handoff_error(gsttaco_ctx* ctx, uint32_t* host_out);
+/* Test support: raise the give-up word as a kernel would (bits as above), to exercise the sticky failure. */
+int gsttaco_debug_raise_handoff_error(gsttaco_ctx* ctx, uint32_t bits);
 /* Test support: the prenet keep-masks [steps][mask0 B*P0 | mask1 B*P1] (0/1) and SMA noise [steps][B][Tv] the LAST
  * gsttaco_inference_step / gsttaco_decode of that shape used -- generated from the seed in throughput mode, or the
  * injected tensors -- copied to HOST buffers (either may be NULL).  Synchronises the device. */

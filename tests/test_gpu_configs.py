@@ -270,3 +270,23 @@ def test_rccl_communicator_gather_and_barrier_on_this_gpu(monkeypatch):
         assert got.shape == mel.shape and torch.equal(got, mel) and torch.equal(got2, mel)
     finally:
         dist.destroy_process_group()
+
+
+def test_a_given_up_handoff_fails_the_following_calls_loudly():
+    """The persistent BiLSTM's waits are bounded: a producer that never shows up raises a word in host-mapped memory instead of
+    hanging the GPU.  The outputs of such a call are garbage, so the library must not keep quiet about it: every later compute
+    call on the context fails (sticky) and the message names the knob that disables the path."""
+    from gst_tacotron_amd import synthetic, weights
+    from gst_tacotron_amd.capi import GstTacoError
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, seed=3)
+    m = _model(hp, w, 4, 16, 4)
+    tokens, _ = synthetic.make_tokens(np.random.default_rng(0), 4, 16)
+    enc = m.encode(tokens).cpu().numpy()
+    assert np.isfinite(enc).all() and m.handoff_error() == 0
+    m.ctx.check(m.ctx.lib.gsttaco_debug_raise_handoff_error(m.ctx.handle, 1 << 8))
+    assert m.handoff_error() == 1 << 8
+    with pytest.raises(GstTacoError, match="hand-off"):
+        m.encode(tokens)
+    with pytest.raises(GstTacoError, match="GSTTACO_BILSTM_PERSIST"):
+        m.postnet(np.zeros((4, 8, 80), np.float32))
