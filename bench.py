@@ -238,7 +238,9 @@ def main():
         # dropout / noise streams are indexed by the LOCAL utterance index: fold the rank into the seed so that shards
         # do not draw identical randomness
         mel, stop, _, align = model.Inference_Step(tok, None, None, mels, lens, seed=(1000 + i) * world + rank)
-        return gdist.gather_to_root(mel, n_total=n_total)
+        # the gather runs on RCCL's stream behind this batch's compute; its result is claimed one step later, so that the
+        # next batch's kernels are enqueued behind this batch's COMPUTE, not behind its gather (N = 1: no collective at all)
+        return gdist.gather_to_root(mel, n_total=n_total, async_op=True)
 
     # Two cached graphs: the plain one, and one whose decode launches are bracketed by event-record nodes on every
     # PROFILE_EVERY-th step.  Only the LAST timed step replays the bracketed graph (each bracket costs ~2.5 us, 200 of
@@ -247,22 +249,26 @@ def main():
         model.ctx.check(lib.gsttaco_set_profiling(handle, PROFILE_EVERY if on else 0))
 
     set_prof(True)
-    one_step(-1)                                   # capture + first replay of the bracketed graph (untimed, extra)
+    one_step(-1).result()                          # capture + first replay of the bracketed graph (untimed, extra)
     set_prof(False)
     for i in range(args.warmup):
-        one_step(i)
+        one_step(i).result()
     if args.warmup == 0:
-        one_step(0)                                # the plain graph must exist before the clock starts
+        one_step(0).result()                       # the plain graph must exist before the clock starts
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = None
+    out, pending = None, None
     for i in range(args.steps):
         if i == args.steps - 1:
             set_prof(True)
-        out = one_step(args.warmup + i)
+        nxt = one_step(args.warmup + i)
+        if pending is not None:
+            out = pending.result()
+        pending = nxt
+    out = pending.result()                         # every gather has completed before the clock stops
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
