@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -54,12 +55,20 @@ struct ConvLayer {
 
 struct GraphKey {
     int kind, B, Tv, Tref1, steps, has_mask, has_noise, prof, masked;
+    int solo = 0;       // captured while this was the only live context of the process (filled in by run_cached)
     bool operator<(const GraphKey& o) const {
         return memcmp(this, &o, sizeof(GraphKey)) < 0;
     }
 };
 
 std::string g_create_error;
+
+// Live contexts of this process.  The persistent BiLSTM launch needs the 32 members of each of its groups resident on their
+// XCD AT THE SAME TIME, one per CU; two such launches of two contexts on two streams can split an XCD's CUs between them and
+// wait for each other until the bounded spins give up (measured: four contexts on four streams do).  It is therefore used only
+// while ONE context exists; graphs captured in that state are keyed as such and are not replayed once a second context lives.
+// (Another PROCESS sharing the GPU is not seen here: set GSTTACO_BILSTM_PERSIST=0 there.)
+std::atomic<int> g_live_contexts{0};
 
 }  // namespace
 
@@ -106,6 +115,8 @@ struct gsttaco_ctx {
     GtGranule* w_z0g = nullptr;
     uint32_t* w_err = nullptr;   // device alias of h_err: [0] merged decode launch, [1] persistent BiLSTM
     uint32_t* h_err = nullptr;
+    bool counted = false;        // this context is included in g_live_contexts
+    uint64_t n_persist_enqueued = 0;     // persistent BiLSTM launches enqueued (eagerly or into a captured graph)
     float* w_xa2 = nullptr;
     bool split_rec = true;
     int keep_x_weights = 1;
@@ -113,6 +124,7 @@ struct gsttaco_ctx {
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
     bool wino4 = true;           // ... F(4,5) where its grid still fills the chip (GSTTACO_WINO4=0: F(2,5) only)
+    bool solo_now = true;        // this is the process's only live context (sampled at the start of the current call)
     bool bilstm_persist = true;  // one persistent launch per BiLSTM instead of one per time step (GSTTACO_BILSTM_PERSIST=0: per step)
     bool wino = true;            // Winograd F(2,5) for the 5-tap Conv1D layers that fill the chip (GSTTACO_WINO=0: implicit GEMM only)
     bool proj_helps = true;      // merged launch: projection workgroups take recurrent-half jobs after publishing (GSTTACO_PROJ_HELPS=0 off)
@@ -615,7 +627,7 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
     HIPCHECK(c, launch_conv(c, a, s));
     // One persistent launch for the whole sequence, one (direction, 16 utterances) group per XCD (skinny_gemm.hip
     // gt_bilstm_persist_kernel; same arithmetic, bitwise the same outputs); GSTTACO_BILSTM_PERSIST=0 keeps the launch per step.
-    if (L.ph && c->bilstm_persist && gt_bilstm_persist_supported(H, B, c->n_cu)) {
+    if (L.ph && c->bilstm_persist && c->solo_now && gt_bilstm_persist_supported(H, B, c->n_cu)) {
         HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(L.pflags), (size_t)8 * 2 * 32 + 8, s));
         BiLstmPersistArgs k{};
         k.wp[0] = L.h[0].wp; k.wp[1] = L.h[1].wp;
@@ -623,6 +635,7 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
         k.ldz = (int64_t)Tn * 8 * H; k.ldo = (int64_t)Tn * EO;
         k.M = B; k.MT = MT; k.H = H; k.T = Tn;
         HIPCHECK(c, gt_launch_bilstm_persist(k, s));
+        ++c->n_persist_enqueued;
         return 0;
     }
     for (int d = 0; d < 2; ++d) HIPCHECK(c, gt_launch_zero(L.hb[d][1], (size_t)MT * 16 * H, s));
@@ -1281,7 +1294,10 @@ int check_shape(gsttaco_ctx* c, int B, int Tv, int Tref1, int steps) {
 // Runs `body` either eagerly on `stream` or through a cached hipGraph captured on the internal stream (LRU-bounded,
 // see gsttaco_ctx::graphs).
 template <typename F>
-int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key, F body) {
+int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F body) {
+    GraphKey key = key_in;
+    c->solo_now = g_live_contexts.load() <= 1;
+    key.solo = c->solo_now ? 1 : 0;
     // an in-kernel wait of an EARLIER call gave up (a producer workgroup never became resident): that call's outputs were
     // garbage; say so now rather than never.  Sticky until the context is destroyed.
     if (c->h_err && (c->h_err[0] | c->h_err[1]))
@@ -1439,6 +1455,8 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);
+    c->counted = true;
+    g_live_contexts.fetch_add(1);
     *out = c;
     return 0;
 }
@@ -1453,6 +1471,7 @@ void gsttaco_destroy(gsttaco_ctx* c) {
 
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->counted) g_live_contexts.fetch_sub(1);
     delete c;
 }
 
@@ -2091,6 +2110,13 @@ int gsttaco_debug_handoff_error(gsttaco_ctx* c, uint32_t* host_out) {
     if (!c || !host_out || !c->w_err) return GSTTACO_E_INVALID;
     HIPCHECK(c, hipDeviceSynchronize());
     *host_out = c->h_err[0] | (c->h_err[1] << 8);   // [0] merged decode launch, [1] persistent BiLSTM (sticky)
+    return 0;
+}
+
+int gsttaco_debug_counters(const gsttaco_ctx* c, uint64_t out[2]) {
+    if (!c || !out) return GSTTACO_E_INVALID;
+    out[0] = c->n_persist_enqueued;
+    out[1] = (uint64_t)g_live_contexts.load();
     return 0;
 }
 

@@ -319,6 +319,12 @@ class GST_Tacotron:
         self.ctx.check(self.ctx.lib.gsttaco_debug_handoff_error(self.ctx.handle, ctypes.byref(out)))
         return int(out.value)
 
+    def debug_counters(self):
+        """(persistent BiLSTM launches this context has enqueued, live contexts of the process) -- ``gsttaco_debug_counters``."""
+        out = (ctypes.c_uint64 * 2)()
+        self.ctx.check(self.ctx.lib.gsttaco_debug_counters(self.ctx.handle, out))
+        return int(out[0]), int(out[1])
+
     def graph_cache_size(self):
         return int(self.ctx.lib.gsttaco_graph_cache_size(self.ctx.handle))
 

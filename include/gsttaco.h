@@ -256,6 +256,11 @@ int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
  * path).  This function synchronises the device and returns the words now: bit 0 merged decode launch, bit 8 persistent
  * BiLSTM; 0 = no wait has ever given up. */
 int gsttaco_debug_handoff_error(gsttaco_ctx* ctx, uint32_t* host_out);
+/* Test support: out[0] = persistent BiLSTM launches this context has enqueued (eagerly or into a captured graph), out[1] = live
+ * contexts of the process.  The persistent launch is used only while the process has ONE live context: two such launches on
+ * two streams can split an XCD's CUs between them and wait for each other; with several contexts the BiLSTMs
+ * run one launch per time step.  A second PROCESS on the same GPU is not seen: set GSTTACO_BILSTM_PERSIST=0 there. */
+int gsttaco_debug_counters(const gsttaco_ctx* ctx, uint64_t out[2]);
 /* Test support: raise the give-up word as a kernel would (bits as above), to exercise the sticky failure. */
 int gsttaco_debug_raise_handoff_error(gsttaco_ctx* ctx, uint32_t bits);
 /* Test support: the prenet keep-masks [steps][mask0 B*P0 | mask1 B*P1] (0/1) and SMA noise [steps][B][Tv] the LAST

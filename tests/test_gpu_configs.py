@@ -206,7 +206,7 @@ def test_persistent_bilstm_is_bitwise_the_per_step_bilstm(monkeypatch):
     It is the per-step kernel's arithmetic in the per-step kernel's order, so the encodings must be BITWISE equal -- full
     dimensions, 1 / 5 / 17 / 32 utterances (one and two M-tiles, partial tiles), 3 / 4 / 33 / 128 tokens, reference (unmasked) and
     masked mode with ragged lengths, several calls per model (flags and state are re-used) -- and the wait's give-up flag clear.
-    33 utterances falls back to the per-step kernel by itself."""
+    (33 utterances = three M-tiles per direction = six of the eight groups.)"""
     import torch
     from gst_tacotron_amd import synthetic, weights
     from oracle import oracle_np
@@ -215,9 +215,13 @@ def test_persistent_bilstm_is_bitwise_the_per_step_bilstm(monkeypatch):
     rng = np.random.default_rng(12)
     cases = [(1, 3), (5, 4), (17, 33), (32, 128), (33, 20)]
     enc = {}
+    import gc
     for mode in ("1", "0"):
         monkeypatch.setenv("GSTTACO_BILSTM_PERSIST", mode)
+        m = None
+        gc.collect()                                    # the persistent launch is used only by a process's ONLY live context
         m = _model(hp, w, 33, 128, 4)
+        assert m.debug_counters()[1] == 1
         r = np.random.default_rng(12)
         for B, Tv in cases:
             tokens, tl = synthetic.make_tokens(r, B, Tv)
@@ -227,6 +231,8 @@ def test_persistent_bilstm_is_bitwise_the_per_step_bilstm(monkeypatch):
                 enc[(mode, B, Tv, "masked", rep)] = m.encode(tokens, tl).cpu().numpy()
         torch.cuda.synchronize()
         assert m.handoff_error() == 0
+        # every shape x mask mode takes the persistent launch (each captured once: 5 x 2), none with the knob off
+        assert m.debug_counters()[0] == (10 if mode == "1" else 0)
         if mode == "1":
             ref = oracle_np.encoder(hp, oracle_np.cast_weights(w, np.float64), tokens, np.float64)
             assert np.abs(enc[("1", 33, 20, "ref", 0)] - ref).max() <= TOL
@@ -290,3 +296,50 @@ def test_a_given_up_handoff_fails_the_following_calls_loudly():
         m.encode(tokens)
     with pytest.raises(GstTacoError, match="GSTTACO_BILSTM_PERSIST"):
         m.postnet(np.zeros((4, 8, 80), np.float32))
+
+
+def test_several_contexts_on_several_streams_do_not_deadlock_the_persistent_bilstm():
+    """The persistent BiLSTM launch needs each group's 32 members resident on their XCD at once; two such launches from two
+    contexts on two streams can split an XCD's CUs between them and wait for each other (four contexts on four streams did:
+    every wait ran into its bound).  The library therefore takes the persistent launch only while the process has ONE live
+    context.  Four contexts, four streams, 60 interleaved encodes: the same encodings as a lone context (whose BiLSTM IS the
+    persistent one), no give-up, in bounded time."""
+    import gc
+    import time
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, seed=3)
+    tokens, _ = synthetic.make_tokens(np.random.default_rng(5), 32, 64)
+    gc.collect()
+    solo = _model(hp, w, 32, 64, 4)
+    ref = solo.encode(tokens).cpu().numpy()
+    assert solo.debug_counters() == (1, 1)
+    models = [solo] + [_model(hp, w, 32, 64, 4) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in models]
+    tok = torch.as_tensor(tokens, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = []
+    for i in range(60):
+        with torch.cuda.stream(streams[i % 4]):
+            outs.append(models[i % 4].encode(tok))
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 20.0
+    assert all(np.array_equal(o.cpu().numpy(), ref) for o in outs)
+    assert [m.handoff_error() for m in models] == [0, 0, 0, 0]
+    assert solo.debug_counters() == (1, 4) and all(m.debug_counters()[0] == 0 for m in models[1:])
+    # whole Inference_Steps in flight on the four streams give what one context gives alone
+    from test_gpu_parity import _full_case
+    hp2, w2, tokens2, tl2, mels2, ml2, masks2, noise2 = _full_case(8, 24, 40, 12, seed=4)
+    del models, solo, outs
+    gc.collect()
+    one = _model(hp2, w2, 8, 24, 41)
+    ref_mel = one.Inference_Step(tokens2, None, None, mels2, ml2, seed=7, steps=12)[0].cpu().numpy()
+    many = [one] + [_model(hp2, w2, 8, 24, 41) for _ in range(3)]
+    res = []
+    for i in range(16):
+        with torch.cuda.stream(streams[i % 4]):
+            res.append(many[i % 4].Inference_Step(tokens2, None, None, mels2, ml2, seed=7, steps=12)[0])
+    torch.cuda.synchronize()
+    assert all(np.array_equal(r.cpu().numpy(), ref_mel) for r in res)
