@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > "$OUT/bench_l2.log" 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_l2" -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-serving > "$OUT/bench_l2.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict

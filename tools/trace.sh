@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-serving "$@" > "$OUT/bench_trace.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 out = sys.argv[1]
