@@ -6,7 +6,7 @@ from gst_tacotron_amd import synthetic, weights
 from gst_tacotron_amd.model import GST_Tacotron
 hp, inputs = synthetic.config_inputs("cfg2", batch=32)
 w = weights.synthetic_weights(hp, seed=0)
-for S in (1, 2, 3, 4):
+for S in [int(x) for x in (sys.argv[1:] or ["1", "2", "3", "4"])]:
     models = [GST_Tacotron(hyper_parameters=hp, max_batch=32, max_tokens=128, max_ref_frames=257).Restore(weights=w) for _ in range(S)]
     streams = [torch.cuda.Stream() for _ in range(S)]
     dev = models[0].device
