@@ -5,8 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gst_tacotron_amd import synthetic, weights
 from gst_tacotron_amd.model import GST_Tacotron
 hp = synthetic.config_hp("cfg2"); w = weights.synthetic_weights(hp, seed=0)
+import gc
+m = None
 for mode in ("0", "1", "0", "1"):
     os.environ["GSTTACO_BILSTM_PERSIST"] = mode
+    m = None
+    gc.collect()            # the persistent BiLSTM is taken only by a process's only live context
     m = GST_Tacotron(hyper_parameters=hp, max_batch=32, max_tokens=128, max_ref_frames=4); m.Restore(weights=w)
     tokens, tl = synthetic.make_tokens(np.random.default_rng(1), 32, 128)
     tok = torch.as_tensor(tokens, device="cuda")
