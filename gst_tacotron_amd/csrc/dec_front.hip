@@ -116,22 +116,50 @@ __device__ __forceinline__ float front_wave_incl_scan(float x, int lane) {
 // ---- worker workgroup (blockIdx.x >= B): recurrent half of an LSTM gate GEMM (see DecFrontArgs::rec).
 // Jobs are groups of up to WT adjacent tiles of one layer sharing one pass over that layer's state (skinny_body.h).
 template <int LEAN>
-__device__ __forceinline__ void front_worker(const DecFrontArgs& P, float* smem) {
+__device__ __forceinline__ void front_worker(const DecFrontArgs& P, float* smem, const int slot) {
     const int wt = P.worker_tiles == 1 ? 1 : WT;
     const int j0 = (P.rec_end[0] - P.rec_begin[0] + wt - 1) / wt;
     const int total = j0 + (P.rec_end[1] - P.rec_begin[1] + wt - 1) / wt;
     const int mchunks = (P.B + 31) / 32;
-    const int wslot = (int)blockIdx.x == P.B ? 8 : ((int)blockIdx.x == (int)gridDim.x - 1 ? 10 : -1);   // diagnostics
+    const int wslot = slot == 0 ? 8 : ((int)blockIdx.x == (int)gridDim.x - 1 ? 10 : -1);   // diagnostics
     if (P.dbg && wslot >= 0 && threadIdx.x == 0) P.dbg[wslot] = __builtin_amdgcn_s_memrealtime();
-    for (int job = (int)blockIdx.x - P.B; job < total; job += P.n_workers) {
-        const int layer = job < j0 ? 0 : 1;
-        const int tile = P.rec_begin[layer] + (layer == 0 ? job : job - j0) * wt;
-        const int ntile = min(wt, P.rec_end[layer] - tile);
-        for (int mc = 0; mc < mchunks; ++mc) {
-            if (LEAN == 2) gt_lean_partial<FT / 64, 2, WT, true>(P.lrec[layer], tile, ntile, mc, smem);
-            else if (LEAN == 1) gt_lean_partial<FT / 64, 4, WT>(P.lrec[layer], tile, ntile, mc, smem);
-            else gt_skinny_partial_multi<FT / 64, WT, true>(P.rec[layer], tile, ntile, mc, smem);
+    if (LEAN != 0 && mchunks > 1) {
+        // Batches above 32 rows: a job's weights stay in registers over its chunks (lean_body.h gt_lean_partial_mc).  Schedule
+        // (DecFrontArgs::sched_*): the pure workers take whole jobs [0, pf) round-robin, then pieces of `e` chunks of jobs
+        // [pf, pf + ne); utterance workgroups that have finished their chain take pieces of `y` chunks of jobs [pf + ne, total).
+        auto run = [&](const int job, const int c0, const int c1) {
+            const int layer = job < j0 ? 0 : 1;
+            const int tile = P.rec_begin[layer] + (layer == 0 ? job : job - j0) * wt;
+            const int ntile = min(wt, P.rec_end[layer] - tile);
+            if (LEAN == 2) gt_lean_partial_mc<FT / 64, 2, WT, true>(P.lrec[layer], tile, ntile, c0, c1, smem);
+            else gt_lean_partial_mc<FT / 64, 4, WT>(P.lrec[layer], tile, ntile, c0, c1, smem);
             __syncthreads();
+        };
+        auto pieces = [&](const int first, const int stride, const int base, const int njobs, const int z) {
+            if (z <= 0 || njobs <= 0) return;
+            const int npp = (mchunks + z - 1) / z;
+            for (int q = first; q < njobs * npp; q += stride) {
+                const int c0 = (q % npp) * z;
+                run(base + q / npp, c0, min(mchunks, c0 + z));
+            }
+        };
+        if (slot < P.n_workers) {
+            for (int job = slot; job < P.sched_pf; job += P.n_workers) run(job, 0, mchunks);
+            pieces(slot, P.n_workers, P.sched_pf, P.sched_ne, P.sched_e);
+        } else {
+            pieces(slot - P.n_workers, P.utt_jobs, P.sched_pf + P.sched_ne, total - P.sched_pf - P.sched_ne, P.sched_y);
+        }
+    } else {
+        for (int job = slot; job < total; job += P.n_workers) {
+            const int layer = job < j0 ? 0 : 1;
+            const int tile = P.rec_begin[layer] + (layer == 0 ? job : job - j0) * wt;
+            const int ntile = min(wt, P.rec_end[layer] - tile);
+            for (int mc = 0; mc < mchunks; ++mc) {
+                if (LEAN == 2) gt_lean_partial<FT / 64, 2, WT, true>(P.lrec[layer], tile, ntile, mc, smem);
+                else if (LEAN == 1) gt_lean_partial<FT / 64, 4, WT>(P.lrec[layer], tile, ntile, mc, smem);
+                else gt_skinny_partial_multi<FT / 64, WT, true>(P.rec[layer], tile, ntile, mc, smem);
+                __syncthreads();
+            }
         }
     }
     if (P.dbg && wslot >= 0 && threadIdx.x == 0) P.dbg[wslot + 1] = __builtin_amdgcn_s_memrealtime();
@@ -144,10 +172,14 @@ template <int L, int NP, int LEAN>
 __global__ __launch_bounds__(FT) void gt_dec_front_lean_kernel(DecFrontArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x >= P.B) {
-        front_worker<LEAN>(P, smem);
+        front_worker<LEAN>(P, smem, (int)blockIdx.x - P.B);
         return;
     }
     gt_front_lean<L, NP, false>(P, smem, (int)blockIdx.x, blockIdx.x == 0);
+    if ((int)blockIdx.x < P.utt_jobs) {     // large batches: this workgroup's CU takes recurrent-half jobs once its utterance is done
+        __syncthreads();
+        front_worker<LEAN>(P, smem, P.n_workers + (int)blockIdx.x);
+    }
 }
 
 // ======================================================================================================================
@@ -332,7 +364,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
     constexpr int CPARTS = FT / A;          // row groups of the context pass
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x >= P.B) {
-        front_worker<LEAN>(P, smem);
+        front_worker<LEAN>(P, smem, (int)blockIdx.x - P.B);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63;
@@ -654,6 +686,10 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         P.xa[gt_blk_off(b, P1 + a, P.MT)] = z;      // context, k in [P1, P1+A)
     }
     GT_STAMP(P.dbg, 7);
+    if (b < P.utt_jobs) {       // (see gt_dec_front_lean_kernel)
+        __syncthreads();
+        front_worker<LEAN>(P, smem, P.n_workers + b);
+    }
 }
 
 static size_t front_lds_bytes(const DecFrontArgs& a) {

@@ -120,7 +120,7 @@ struct gsttaco_ctx {
     float* w_xa2 = nullptr;
     bool split_rec = true;
     int keep_x_weights = 1;
-    int co_tiles = 64;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end)
+    int co_tiles = -1;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end); -1 = by batch size
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
     bool wino4 = true;           // ... F(4,5) where its grid still fills the chip (GSTTACO_WINO4=0: F(2,5) only)
@@ -132,6 +132,7 @@ struct gsttaco_ctx {
     int worker_delay = 300;      // merged launch: the pure workers start this many 100 MHz ticks after it (GSTTACO_WORKER_DELAY)
     bool keep_hash = true;       // GSTTACO_KEEP_HASH=0: the front kernel reads the generated masks from HBM like injected ones
     bool lean = true;            // lean_body.h kernels for the decode shapes they cover (GSTTACO_LEAN=0: general kernels only)
+    double sched_unit[2] = {5.8, 3.4}, sched_chain = 9.5;     // plan_front_jobs cost model (us): fp32 / bf16 unit, chain
 
     float *pw0 = nullptr, *pb0 = nullptr, *pw1 = nullptr, *pb1 = nullptr, *pwq = nullptr, *pbq = nullptr;  // plain layouts (fused front)
     bool fused_front = true;
@@ -627,15 +628,21 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
     HIPCHECK(c, launch_conv(c, a, s));
     // One persistent launch for the whole sequence, one (direction, 16 utterances) group per XCD (skinny_gemm.hip
     // gt_bilstm_persist_kernel; same arithmetic, bitwise the same outputs); GSTTACO_BILSTM_PERSIST=0 keeps the launch per step.
-    if (L.ph && c->bilstm_persist && c->solo_now && gt_bilstm_persist_supported(H, B, c->n_cu)) {
-        HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(L.pflags), (size_t)8 * 2 * 32 + 8, s));
-        BiLstmPersistArgs k{};
-        k.wp[0] = L.h[0].wp; k.wp[1] = L.h[1].wp;
-        k.zx = L.z; k.out = out; k.h = L.ph; k.flags = L.pflags; k.row_len = row_len; k.err = c->w_err + 1;
-        k.ldz = (int64_t)Tn * 8 * H; k.ldo = (int64_t)Tn * EO;
-        k.M = B; k.MT = MT; k.H = H; k.T = Tn;
-        HIPCHECK(c, gt_launch_bilstm_persist(k, s));
-        ++c->n_persist_enqueued;
+    if (L.ph && c->bilstm_persist && c->solo_now && gt_bilstm_persist_supported(H, std::min(B, 64), c->n_cu)) {
+        // one launch per slab of 64 utterances (8 groups = 2 directions x 4 M-tiles fill the 8 XCDs); the recurrences of
+        // different utterances are independent, so the slabs simply follow each other on the stream
+        for (int r0 = 0; r0 < B; r0 += 64) {
+            const int Bs = std::min(64, B - r0);
+            HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(L.pflags), (size_t)8 * 2 * 32 + 8, s));
+            BiLstmPersistArgs k{};
+            k.wp[0] = L.h[0].wp; k.wp[1] = L.h[1].wp;
+            k.ldz = (int64_t)Tn * 8 * H; k.ldo = (int64_t)Tn * EO;
+            k.zx = L.z + (size_t)r0 * k.ldz; k.out = out + (size_t)r0 * k.ldo; k.h = L.ph; k.flags = L.pflags;
+            k.row_len = row_len ? row_len + r0 : nullptr; k.err = c->w_err + 1;
+            k.M = Bs; k.MT = (Bs + 15) / 16; k.H = H; k.T = Tn;
+            HIPCHECK(c, gt_launch_bilstm_persist(k, s));
+            ++c->n_persist_enqueued;
+        }
         return 0;
     }
     for (int d = 0; d < 2; ++d) HIPCHECK(c, gt_launch_zero(L.hb[d][1], (size_t)MT * 16 * H, s));
@@ -773,6 +780,36 @@ bool merged_plan(const gsttaco_ctx* c, int B, int Tv) {
     return gt_dec_merged_supported(g.mel_dim, c->P0, c->P1, c->att, Tv, B, c->proj_z.nkb, c->H1, c->H2);
 }
 
+// Front launch, batches above 32 rows: who computes which recurrent-half job (kernels.h DecFrontArgs::sched_*).  A job is a pair
+// of tiles over every 32-row chunk of the batch with the weights held in registers; at large fp32 batches it is MFMA-bound
+// and outlasts the per-utterance chain, so the CUs of finished utterance workgroups are worth more than a second round on the
+// pure workers.  Picks (e, y) -- the piece sizes in chunks for the pure workers' extra share and for the utterance
+// workgroups -- by the makespan of a two-parameter cost model: `unit` = one pair of tiles x one chunk, `chain` = the utterance
+// workgroup's prenet / attention chain (measured on MI355X with in-kernel stamps: 5.8 / 3.4 us per unit in fp32 / bf16 -- fp32
+// MFMA-bound at the ~2.0 GHz the chip sustains, bf16 bound by the CU's load pipe -- and 9.5 us per chain).
+struct FrontSched { int pf, ne, e, y, utt; };
+FrontSched plan_front_jobs(const gsttaco_ctx* c, int jobs, int chunks, int n_workers, int B, bool bf16) {
+    const double unit = c->sched_unit[bf16 ? 1 : 0], chain = c->sched_chain;
+    FrontSched best{jobs, 0, 0, 0, 0};
+    double best_t = 1e30;
+    for (int y = 0; y <= chunks; ++y) {
+        if (y && chunks % y) continue;
+        for (int e = 0; e <= chunks; ++e) {
+            if (e && chunks % e) continue;
+            const int utt = y ? B : 0;
+            const int ny = y ? std::min(jobs, (utt * y + chunks - 1) / chunks) : 0;
+            const int ne = e ? std::min(jobs - ny, (n_workers * e + chunks - 1) / chunks) : 0;
+            const int pf = jobs - ny - ne;
+            const int full_rounds = (pf + n_workers - 1) / n_workers;
+            const int e_rounds = e ? (ne * (chunks / e) + n_workers - 1) / n_workers : 0;
+            const int y_rounds = utt ? (ny * (chunks / y) + utt - 1) / utt : 0;
+            const double t = std::max((full_rounds * chunks + e_rounds * e) * unit, chain + y_rounds * y * unit);
+            if (t < best_t - 1e-9) { best_t = t; best = FrontSched{pf, ne, e, y, utt}; }
+        }
+    }
+    return best;
+}
+
 int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool has_mask, bool has_noise, bool masked) {
     const int32_t* tlen = masked ? c->w_tok_len : nullptr;
     const gsttaco_config& g = c->cfg;
@@ -820,7 +857,9 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         return rce;
     };
     // layer-2 recurrent tiles co-scheduled with the (11-workgroup) projection kernel: one tile per otherwise idle CU
-    const int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, c->co_tiles));
+    // (batches above 32 rows: every launch is throughput-bound, the front launch most of all, and the projection launch has
+    // ~150 CUs to spare: it takes half of layer 2's recurrent tiles instead of a quarter)
+    const int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, c->co_tiles >= 0 ? c->co_tiles : (B > 32 ? 128 : 64)));
     for (int t = 0; t < steps; ++t) {
         const int p = t & 1;
         SkinnyArgs k;
@@ -922,13 +961,21 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 }
                 // one worker workgroup per compute unit the utterance workgroups leave free (a quarter of the chip at least)
                 f.n_workers = B < c->n_cu * 3 / 4 ? c->n_cu - B : c->n_cu / 4;
-                if (getenv("GSTTACO_DEBUG_NO_WORKERS")) f.n_workers = 0;      // timing experiments only: results are WRONG
                 f.worker_tiles = c->worker_tiles;
                 f.lean_rec = (c->lean && f.rec[0].bf16 == f.rec[1].bf16 && f.rec[0].nkb == 64 && f.rec[1].nkb == 64) ? (f.rec[0].bf16 ? 2 : 1) : 0;
                 for (int layer = 0; layer < 2; ++layer)
                     f.lrec[layer] = LeanPartialArgs{f.rec[layer].wp, f.rec[layer].bias, f.rec[layer].seg[0].ptr, f.rec[layer].partial_out, MT};
                 // from step 1 on, the projection kernel of the previous step already did layer-2 tiles [0, co_tiles)
                 if (t > 0 && c->proj.nkb >= 32) f.rec_begin[1] = co_tiles;
+                {
+                    const int wt = f.worker_tiles == 1 ? 1 : 2;
+                    const int jobs = (f.rec_end[0] - f.rec_begin[0] + wt - 1) / wt + (f.rec_end[1] - f.rec_begin[1] + wt - 1) / wt;
+                    f.sched_pf = jobs;
+                    if (f.lean_rec != 0 && B > 32) {
+                        const FrontSched fs = plan_front_jobs(c, jobs, (B + 31) / 32, f.n_workers, B, f.lean_rec == 2);
+                        f.sched_pf = fs.pf; f.sched_ne = fs.ne; f.sched_e = fs.e; f.sched_y = fs.y; f.utt_jobs = fs.utt;
+                    }
+                }
             }
             if (prof) { int rce = prof_begin(2); if (rce) return rce; }
             HIPCHECK(c, gt_launch_dec_front(f, s));
@@ -1452,6 +1499,10 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     if (const char* e = getenv("GSTTACO_WINO")) c->wino = e[0] != '0';
     if (const char* e = getenv("GSTTACO_WINO4")) c->wino4 = e[0] != '0';
     if (const char* e = getenv("GSTTACO_BILSTM_PERSIST")) c->bilstm_persist = e[0] != '0';
+    if (const char* e = getenv("GSTTACO_SCHED")) {      // "unit_fp32,unit_bf16,chain" in microseconds (cost model of plan_front_jobs)
+        double a = 0, b = 0, d = 0;
+        if (sscanf(e, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d >= 0) { c->sched_unit[0] = a; c->sched_unit[1] = b; c->sched_chain = d; }
+    }
     const char* es = getenv("GSTTACO_STAMPS");
     c->stamps = es && es[0] == '1';
     build_manifest(c);
@@ -2146,7 +2197,7 @@ int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int which, int B) {
     const bool fused = c->fused_front && c->split_rec;
     auto gemm = [&](int64_t K, int64_t N, int64_t extra_row_floats) { return 4 * (K * N + N) + 4 * (int64_t)B * (K + extra_row_floats); };
     const int64_t ntile2 = (H2 + 3) / 4;
-    int64_t co_tiles = std::max<int64_t>(0, std::min<int64_t>(ntile2, c->co_tiles));       // same rule as enqueue_decode
+    int64_t co_tiles = std::max<int64_t>(0, std::min<int64_t>(ntile2, c->co_tiles >= 0 ? c->co_tiles : (B > 32 ? 128 : 64)));   // same rule as enqueue_decode
     if (c->proj.nkb < 32) co_tiles = 0;
     switch (which) {
         case 0:     // LSTM layer 1: x-half only when the recurrent half runs in the front launch

@@ -244,6 +244,12 @@ struct DecFrontArgs {
     SkinnyArgs rec[2];
     int rec_begin[2], rec_end[2];   // tile ranges [begin, end) of each layer handled by this launch's workers
     int n_workers;
+    // Batches above 32 rows on the lean bodies (dec_front.hip front_worker): whole jobs [0, sched_pf) go round-robin to the pure
+    // workers, jobs [sched_pf, sched_pf + sched_ne) are cut into pieces of sched_e chunks for them as well, and the remaining
+    // jobs into pieces of sched_y chunks for the first `utt_jobs` utterance workgroups, which take them once their utterance is
+    // done (a job = a pair of tiles over every 32-row chunk of the batch; at 128 rows in fp32 it outlasts the chain).
+    // Otherwise sched_pf = all jobs, the rest 0.
+    int utt_jobs, sched_pf, sched_ne, sched_e, sched_y;
     int worker_tiles;               // tiles per worker job: 1, or 0/2 = pairs sharing one pass over the activations
     LeanPartialArgs lrec[2];        // the same two GEMMs for the lean body (fp32, K = 1024); used when lean_rec != 0
     int lean_rec;                   // 0: general body, 1: lean fp32, 2: lean bf16

@@ -202,3 +202,222 @@ __device__ __forceinline__ void gt_lean_partial(const LeanPartialArgs& A, const 
         }
     }
 }
+
+// ======================================================================================================================
+// Batches above 32 rows.  The bodies above own ONE 32-row chunk per workgroup, so a batch of 128 used to run four
+// workgroups per tile, each streaming the tile's weights again (4 x 58 MB per decode step: the launches were bound by that
+// stream).  Here a workgroup keeps its weight fragments in REGISTERS and loops over chunks [c0, c1) of the batch: weights
+// are read once per step at any batch, per chunk only the activations move.
+//
+// At these sizes the launches are no longer latency-bound: fp32 MFMA time and the activation pull of a CU are of the same
+// order (a 16x16x4 MFMA eats 256 B of A operand in 32 cycles: 32 B/clk per CU when every A fragment is used for one tile,
+// about what a CU takes in from L2), so a workgroup multiplies each activation fragment with NT = 2 tiles where the grid
+// allows it, and the loads run UNDER the MFMAs (see the request order at gt_lean_mc).  Every load is unconditional (the
+// last chunk re-reads itself) so the waits stay counted (front_lean.h explains why that matters).
+//
+// Per chunk the arithmetic is the single-chunk bodies' exactly -- same k-block -> wave assignment, every accumulator sees
+// its k-blocks in the same ascending order, same summation order over waves -- so results stay bitwise those of the
+// general kernels.
+// ======================================================================================================================
+#define GT_PIN_ORDER()                     \
+    do {                                   \
+        asm volatile("" ::: "memory");     \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+// Chunks [c0, c1) of 32 rows for tiles tile0 .. tile0 + NT - 1.  `pre(mc)` requests whatever the epilogue of chunk mc needs
+// (it is called before that chunk's MFMAs), `epi(mc)` runs after the chunk's partial sums are in LDS (gt_lean_spill layout,
+// part[j][wave][32 rows][17]) and a workgroup barrier.  bf16: KPW counts 32-k blocks and nkb32 guards the last ones.
+//
+// Request order (measured with in-kernel stamps at 128 rows, K = 1024: a CU's load pipe moves 64 B/clk, so the 256 KB a
+// workgroup needs before its first chunk is done are ~2.7 us of pipe time, and a wave that requests its whole K range at once
+// makes the LAST wave's first byte wait for all of it): every wave requests k-block by k-block -- weights of k-block i, then the
+// two M-tiles' activations of k-block i -- so all waves' k-block 0 is served first and the MFMAs of k-block i run while k-block
+// i + 1 .. are still arriving; and inside the loop the NEXT chunk's activations of k-block i are requested right behind the
+// MFMAs that consumed k-block i, one request per 8 NT MFMAs instead of a burst that would stall every wave's MFMA issue at once.
+template <int NW, int KPW, int NT, bool BF16, bool NTW, class Pre, class Epi>
+__device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const int tile0, const int ntile, const LeanX X, const int nkb32,
+                                           const int MT, const int c0, const int c1, float* lds, Pre pre, Epi epi,
+                                           unsigned long long* dbg = nullptr) {
+    // diagnostic stamps of block 0 (tools/stamps_batch.py): 0 = first chunk's loads requested, 2 = its MFMAs issued (+ the next
+    // chunk's loads requested), 3 = its partial sums in LDS (barrier passed), 5 = its epilogue done; 6 = end
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (BF16) {
+        uint4 b[KPW][NT];
+        float4 xa[KPW][2], xb[KPW][2];
+        const uint4* wl = reinterpret_cast<const uint4*>(wp) + ((size_t)tile0 * nkb32 + wave) * 64 + lane;
+        auto xptr = [&](const int i, const int hf, const int mt) {
+            const int kb32 = (wave + i * NW < nkb32) ? wave + i * NW : wave;    // wave-uniform; past the end: re-read, never multiplied
+            const int kb = 2 * kb32 + hf;
+            const float* xs = kb < X.nkb_a ? X.xa + (size_t)kb * MT * 256 : X.xb + (size_t)(kb - X.nkb_a) * MT * 256;
+            return reinterpret_cast<const float4*>(xs + mt * 256 + lane * 4);
+        };
+        {
+            const int ma = 2 * c0, mb = min(2 * c0 + 1, MT - 1);
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                const int ic = (wave + i * NW < nkb32) ? i : 0;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const uint4* src = wl + ((size_t)(j < ntile ? j : 0) * nkb32 + ic * NW) * 64;
+                    if (NTW) {
+                        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+                        b[i][j] = make_uint4(t[0], t[1], t[2], t[3]);
+                    } else {
+                        b[i][j] = *src;
+                    }
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) { xa[i][hf] = *xptr(i, hf, ma); xb[i][hf] = *xptr(i, hf, mb); }
+            }
+        }
+        GT_PIN_ORDER();
+        GT_STAMP(dbg, 0);
+        for (int mc = c0; mc < c1; ++mc) {
+            const int mn = min(mc + 1, c1 - 1);
+            const int ma = 2 * mn, mb = min(2 * mn + 1, MT - 1);
+            pre(mc);
+            f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            GT_PIN_ORDER();
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                if (wave + i * NW < nkb32) {
+                    bf16x8 a0, a1;
+                    a0[0] = (__bf16)xa[i][0].x; a0[1] = (__bf16)xa[i][0].y; a0[2] = (__bf16)xa[i][0].z; a0[3] = (__bf16)xa[i][0].w;
+                    a0[4] = (__bf16)xa[i][1].x; a0[5] = (__bf16)xa[i][1].y; a0[6] = (__bf16)xa[i][1].z; a0[7] = (__bf16)xa[i][1].w;
+                    a1[0] = (__bf16)xb[i][0].x; a1[1] = (__bf16)xb[i][0].y; a1[2] = (__bf16)xb[i][0].z; a1[3] = (__bf16)xb[i][0].w;
+                    a1[4] = (__bf16)xb[i][1].x; a1[5] = (__bf16)xb[i][1].y; a1[6] = (__bf16)xb[i][1].z; a1[7] = (__bf16)xb[i][1].w;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        bf16x8 bw;
+                        __builtin_memcpy(&bw, &b[i][j], 16);
+                        acc0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw, acc0[j], 0, 0, 0);
+                        acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw, acc1[j], 0, 0, 0);
+                    }
+                }
+                GT_PIN_ORDER();
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) { xa[i][hf] = *xptr(i, hf, ma); xb[i][hf] = *xptr(i, hf, mb); }
+                GT_PIN_ORDER();
+            }
+            if (mc == c0) GT_STAMP(dbg, 2);
+            gt_lean_spill<NW, NT>(lds, acc0, acc1);
+            __syncthreads();
+            if (mc == c0) GT_STAMP(dbg, 3);
+            epi(mc);
+            if (mc == c0) GT_STAMP(dbg, 5);
+            if (mc + 1 < c1) __syncthreads();
+        }
+        GT_STAMP(dbg, 6);
+    } else {
+        constexpr int NKB = NW * KPW;
+        float4 b[KPW][NT], xa[KPW], xb[KPW];
+        const float4* wl = reinterpret_cast<const float4*>(wp) + ((size_t)tile0 * NKB + wave) * 64 + lane;
+        auto xptr = [&](const int i, const int mt) {
+            const int kb = wave + i * NW;                       // wave-uniform
+            const float* xs = kb < X.nkb_a ? X.xa + (size_t)kb * MT * 256 : X.xb + (size_t)(kb - X.nkb_a) * MT * 256;
+            return reinterpret_cast<const float4*>(xs + mt * 256 + lane * 4);
+        };
+        {
+            const int ma = 2 * c0, mb = min(2 * c0 + 1, MT - 1);
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    // (a pair's second tile beyond the matrix re-reads the first: loaded, multiplied, never stored)
+                    const float4* src = wl + ((size_t)(j < ntile ? j : 0) * NKB + i * NW) * 64;
+                    if (NTW) {
+                        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+                        b[i][j] = make_float4(t[0], t[1], t[2], t[3]);
+                    } else {
+                        b[i][j] = *src;
+                    }
+                }
+                xa[i] = *xptr(i, ma);
+                xb[i] = *xptr(i, mb);
+            }
+        }
+        GT_PIN_ORDER();
+        GT_STAMP(dbg, 0);
+        for (int mc = c0; mc < c1; ++mc) {
+            const int mn = min(mc + 1, c1 - 1);
+            const int ma = 2 * mn, mb = min(2 * mn + 1, MT - 1);
+            pre(mc);
+            f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            GT_PIN_ORDER();
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i].x, b[i][j].x, acc0[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[i].x, b[i][j].x, acc1[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i].y, b[i][j].y, acc0[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[i].y, b[i][j].y, acc1[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i].z, b[i][j].z, acc0[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[i].z, b[i][j].z, acc1[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i].w, b[i][j].w, acc0[j], 0, 0, 0);
+                    acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[i].w, b[i][j].w, acc1[j], 0, 0, 0);
+                }
+                GT_PIN_ORDER();
+                xa[i] = *xptr(i, ma);       // the next chunk's k-block i (the last chunk re-reads its own: no branch, counted waits)
+                xb[i] = *xptr(i, mb);
+                GT_PIN_ORDER();
+            }
+            if (mc == c0) GT_STAMP(dbg, 2);
+            gt_lean_spill<NW, NT>(lds, acc0, acc1);
+            __syncthreads();
+            if (mc == c0) GT_STAMP(dbg, 3);
+            epi(mc);
+            if (mc == c0) GT_STAMP(dbg, 5);
+            if (mc + 1 < c1) __syncthreads();
+        }
+        GT_STAMP(dbg, 6);
+    }
+}
+
+// Recurrent-half worker job over chunks [c0, c1): gt_lean_partial's result for each, the job's weights read once.
+// (bf16: KPW counts 32-k blocks, as in gt_lean_partial.)
+template <int NW, int KPW, int NT, bool BF16 = false>
+__device__ __forceinline__ void gt_lean_partial_mc(const LeanPartialArgs& A, const int tile0, const int ntile, const int c0, const int c1,
+                                                   float* lds) {
+    constexpr int NE = (NT * 32 * 16 + NW * 64 - 1) / (NW * 64);
+    float bias_v[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = threadIdx.x + i * NW * 64;
+        const int j = e / (32 * 16);
+        bias_v[i] = (e < NT * 32 * 16 && j < ntile) ? A.bias[(tile0 + j) * 16 + (e & 15)] : 0.f;
+    }
+    const float (*part)[NW][32][17] = reinterpret_cast<const float (*)[NW][32][17]>(lds);
+    auto epi = [&](const int mc) {
+        const int m0 = mc * 32;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = threadIdx.x + i * NW * 64;
+            const int j = e / (32 * 16), row = (e >> 4) & 31, col = e & 15;
+            if (e < NT * 32 * 16 && j < ntile && m0 + row < A.MT * 16) {
+                float z = bias_v[i];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) z += part[j][w][row][col];
+                A.partial_out[((size_t)(tile0 + j) * A.MT * 16 + m0 + row) * 16 + col] = z;
+            }
+        }
+    };
+    // fp32: default cache policy, bf16: non-temporal -- as in gt_lean_partial
+    gt_lean_mc<NW, KPW, NT, BF16, BF16>(A.wp, tile0, ntile, LeanX{A.x, A.x, BF16 ? 2 * NW * KPW : NW * KPW}, NW * KPW, A.MT, c0, c1, lds,
+                                        [](int) {}, epi);
+}

@@ -235,11 +235,77 @@ __global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
     GT_STAMP(A.dbg, 3);
 }
 
+// Batches above 32 rows (lean_body.h, "Batches above 32 rows"): a workgroup owns a PAIR of tiles (8 hidden units) and half of
+// the batch's 32-row chunks, keeps the pair's weights in registers over its chunks and multiplies every activation fragment
+// with both tiles.  The two workgroups of a pair sit 8 block indices apart = on one XCD under the round-robin block -> XCD
+// deal (speed only), so the pair's weights leave the Infinity Cache once.  Per chunk the arithmetic is gt_lstm_x_kernel's:
+// the states are bitwise the same.
+template <int NW, int KPW, int TAG, bool BF16>
+__global__ __launch_bounds__(NW * 64) void gt_lstm_x_mc_kernel(LstmXArgs A) {
+    static_assert(NW * 64 == 512, "one (row, col) element of each of the two tiles per thread");
+    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 2>::kFloats];
+    const int ntiles = (A.H + 3) / 4, npairs = (ntiles + 1) / 2;
+    const int pair = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), rpart = ((int)blockIdx.x >> 3) & 1;
+    if (pair >= npairs) return;
+    const int tile0 = pair * 2, ntile = min(2, ntiles - tile0), MT = A.MT;
+    const int mchunks = (A.M + 31) / 32, csplit = (mchunks + 1) / 2;
+    const int c0 = rpart == 0 ? 0 : csplit, c1 = rpart == 0 ? csplit : mchunks;
+    if (c0 >= c1) return;
+    GT_STAMP(A.dbg, 4);
+    const float (*part)[NW][32][17] = reinterpret_cast<const float (*)[NW][32][17]>(lds);
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    float pin[2], c_prev[2];
+    auto pre = [&](const int mc) {
+        const int grow = mc * 32 + row;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tile = tile0 + (j < ntile ? j : 0), unit = tile * 4 + col;
+            // (rows / units beyond the matrix read an element that exists and are never used: no load under a branch)
+            pin[j] = A.partial_in[((size_t)tile * MT * 16 + min(grow, MT * 16 - 1)) * 16 + col];
+            c_prev[j] = A.c[(size_t)min(grow, A.M - 1) * A.H + min(unit, A.H - 1)];
+        }
+    };
+    auto epi = [&](const int mc) {
+        const int grow = mc * 32 + row;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float z = pin[j];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) z += part[j][w][row][col];
+            const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+            const int unit = (tile0 + j) * 4 + col;
+            if (j < ntile && col < 4 && grow < A.M && unit < A.H) {
+                if (A.row_len && A.t_index >= A.row_len[grow]) {
+                    A.h[gt_blk_off(grow, unit, MT)] = 0.f;          // masked mode: this step does not exist for this utterance
+                } else {
+                    const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
+                    const float c2 = __builtin_fmaf(gf, c_prev[j], gi * gg);
+                    A.c[(size_t)grow * A.H + unit] = c2;
+                    A.h[gt_blk_off(grow, unit, MT)] = go * gt_tanh(c2);
+                }
+            }
+        }
+    };
+    gt_lean_mc<NW, KPW, 2, BF16, false>(A.wp, tile0, ntile, LeanX{A.x, A.x, BF16 ? A.nkb : NW * KPW}, (A.nkb + 1) >> 1, MT, c0, c1, lds, pre, epi,
+                                        A.dbg);
+}
+
 bool gt_lstm_x_supported(int nkb) { return nkb == 24 || nkb == 64; }
 
 template <int TAG>
 static void launch_lstm_x(const LstmXArgs& a, int nkb, bool bf16, hipStream_t stream) {
     const dim3 grid((a.H + 3) / 4, (a.M + 31) / 32);
+    if (a.M > 32 && a.nslab == 0 && !a.wp_co) {         // weights read once per step at any batch
+        const dim3 g1((((a.H + 3) / 4 + 1) / 2 + 7) / 8 * 16);      // pairs of tiles (rounded up to 8) x 2 halves of the chunks
+        if (nkb == 24) {
+            if (bf16) hipLaunchKernelGGL((gt_lstm_x_mc_kernel<8, 2, TAG, true>), g1, dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((gt_lstm_x_mc_kernel<8, 3, TAG, false>), g1, dim3(512), 0, stream, a);
+        } else {
+            if (bf16) hipLaunchKernelGGL((gt_lstm_x_mc_kernel<8, 4, TAG, true>), g1, dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((gt_lstm_x_mc_kernel<8, 8, TAG, false>), g1, dim3(512), 0, stream, a);
+        }
+        return;
+    }
     if (nkb == 24) {
         // K = 384 on 8 waves x 3 k-blocks (4 x 6 left the reduce + gate epilogue to 256 threads: 2.4 -> 1.7 us in-kernel)
         if (bf16) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 2, TAG, true>), grid, dim3(512), 0, stream, a);
@@ -326,12 +392,61 @@ __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanParti
     GT_STAMP(P.dbg, 3);
 }
 
+// Batches above 32 rows.  Main workgroups own (tile, 32-row chunk); the chunks of a tile sit 8 block indices apart, i.e. on
+// one XCD under the round-robin block -> XCD deal, so a tile's 72 KB of weights leave the Infinity Cache once.  Workers: (pair
+// of layer-2 recurrent tiles, chunk) units.
+template <bool BF16>
+__global__ __launch_bounds__(512) void gt_proj_mc_kernel(ProjArgs P, LeanPartialArgs co, int n_main, int co_begin, int co_end) {
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 2>::kFloats];
+    const int mchunks = (P.M + 31) / 32;
+    if ((int)blockIdx.x >= n_main) {
+        // one workgroup per (pair, chunk): the launch has ~150 CUs to spare for a few microseconds, not 30 of them for the
+        // 25 us a pair takes over four chunks; a pair's chunks sit 8 block indices apart (one XCD: the weights' second read is an L2 hit)
+        const int wi = (int)blockIdx.x - n_main, npairs = (co_end - co_begin + 1) / 2;
+        const int g = wi / (8 * mchunks), r = wi % (8 * mchunks);
+        const int half = min(8, npairs - g * 8);
+        const int tile = co_begin + (g * 8 + r % half) * 2, mc = r / half;
+        gt_lean_partial_mc<NW, BF16 ? 4 : 8, 2, BF16>(co, tile, min(2, co_end - tile), mc, mc + 1, lds);
+        return;
+    }
+    const int ntiles = n_main / mchunks;
+    const int g = (int)blockIdx.x / (8 * mchunks), r = (int)blockIdx.x % (8 * mchunks);
+    const int half = min(8, ntiles - g * 8);
+    const int tile = g * 8 + r % half, mc = r / half;
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const int gcol = tile * 16 + col;
+    const float bias = P.bias[gcol];
+    f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (BF16) gt_lean_core_bf16<NW, 5, 1, false>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mc, 36, acc0, acc1);
+    else gt_lean_core<NW, 9, 1, false>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mc, acc0, acc1);
+    gt_lean_spill<NW, 1>(lds, acc0, acc1);
+    __syncthreads();
+    const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
+    float v = bias;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += part[w][row][col];
+    const int grow = mc * 32 + row;
+    if (grow < P.M && gcol < P.N) {
+        if (P.out3 && gcol >= P.col3) P.out3[(size_t)grow * P.ldo3 + (gcol - P.col3)] = v;
+        else if (gcol < P.n_split) P.out[(size_t)grow * P.ldo + gcol] = v;
+        else if (!P.out3 || gcol < P.n_valid2) P.out2[(size_t)grow * P.ldo2 + (gcol - P.n_split)] = v;
+    }
+}
+
 bool gt_proj_lean_supported(int nkb_main, int nkb_co) { return nkb_main == 72 && (nkb_co == 64 || nkb_co == 0); }
 
 hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp, const float* co_bias, const float* co_x,
                                float* co_out, int co_begin, int co_end, int tiles_per_worker, bool bf16, hipStream_t stream) {
     const int nco = co_end > co_begin ? co_end - co_begin : 0;
     LeanPartialArgs co{co_wp, co_bias, co_x, co_out, m.MT};
+    if (m.M > 32) {
+        const int n_mc = ntiles * ((m.M + 31) / 32);
+        const dim3 g(n_mc + (nco + 1) / 2 * ((m.M + 31) / 32));
+        if (bf16) hipLaunchKernelGGL((gt_proj_mc_kernel<true>), g, dim3(512), 0, stream, m, co, n_mc, co_begin, co_end);
+        else hipLaunchKernelGGL((gt_proj_mc_kernel<false>), g, dim3(512), 0, stream, m, co, n_mc, co_begin, co_end);
+        return hipGetLastError();
+    }
     const int n_main = ntiles * m.MT;
     const dim3 g2(n_main + (nco + 1) / 2), g1(n_main + nco * m.MT);
     if (tiles_per_worker == 2) {

@@ -198,14 +198,16 @@ def test_front_end_variants_match_oracle(monkeypatch, env, att):
         assert m.handoff_error() == 0
 
 
-@pytest.mark.parametrize("mixed,B", [(False, 5), (True, 5), (False, 37), (True, 37)])
+@pytest.mark.parametrize("mixed,B", [(False, 5), (True, 5), (False, 37), (True, 37), (False, 65), (True, 65), (False, 128), (True, 128)])
 def test_lean_and_general_decode_kernels_are_the_same_arithmetic(monkeypatch, mixed, B):
     """csrc/lean_body.h restates the general skinny GEMM body for the decode shapes with K fixed at compile time: same
     k-block-to-wave assignment, same summation order, so the decode loop (LSTM input halves, projection, recurrent-half
     workers) is BITWISE the general kernels' result at full dimensions; the lean encoder BiLSTM hoists its input halves
     into one GEMM (different summation order) and agrees within the parity tolerance."""
     import torch
-    # (B = 37: two 32-row chunks per tile, a partial 16-row M-tile, worker jobs looping over the chunks)
+    # (B = 37: two 32-row chunks per tile, a partial 16-row M-tile, worker jobs looping over the chunks; B = 65 / 128: the
+    # multi-chunk bodies that keep a tile's weights in registers over 3 / 4 chunks, an odd number of M-tiles, at 128 in fp32 the
+    # utterance workgroups taking recurrent-half jobs after their chain, and two slabs of the persistent encoder BiLSTM)
     hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, 40, 90, 12, seed=9)
     hp = dict(hp); hp["Use_Mixed_Precision"] = bool(mixed)        # bf16 operands: the lean bf16 bodies, same claim
     w64 = None
