@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsttaco.so")
 
 MAX_LAYERS = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 ATT_CODES = {"BMA": 0, "SMA": 1, "LSA": 2}
 
 # every symbol include/gsttaco.h declares
@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = (
     "gsttaco_mel_frontend", "gsttaco_mel_basis", "gsttaco_griffin_lim", "gsttaco_crc32c",
     "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_lstm_launch_bytes", "gsttaco_debug_stamps", "gsttaco_decode_plan", "gsttaco_debug_randomness",
     "gsttaco_set_graph_policy", "gsttaco_graph_cache_size", "gsttaco_debug_handoff_error", "gsttaco_debug_raise_handoff_error", "gsttaco_debug_counters",
+    "gsttaco_synchronize",
 )
 
 _I32A = ctypes.c_int32 * MAX_LAYERS
@@ -123,6 +124,8 @@ def load_library(path=None):
     lib.gsttaco_debug_raise_handoff_error.restype = ctypes.c_int
     lib.gsttaco_debug_counters.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.gsttaco_debug_counters.restype = ctypes.c_int
+    lib.gsttaco_synchronize.argtypes = [vp, vp]
+    lib.gsttaco_synchronize.restype = ctypes.c_int
     for fn in ("gsttaco_create", "gsttaco_num_weights", "gsttaco_weight_info", "gsttaco_load_weight",
                "gsttaco_finalize_weights", "gsttaco_encode", "gsttaco_gst", "gsttaco_decode", "gsttaco_postnet", "gsttaco_vocoder",
                "gsttaco_inference_step", "gsttaco_set_profiling", "gsttaco_get_profile", "gsttaco_mel_frontend",

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -55,7 +56,7 @@ struct ConvLayer {
 
 struct GraphKey {
     int kind, B, Tv, Tref1, steps, has_mask, has_noise, prof, masked;
-    int solo = 0;       // captured while this was the only live context of the process (filled in by run_cached)
+    int persist = 0;    // captured with the persistent BiLSTM launches enabled (filled in by run_cached)
     bool operator<(const GraphKey& o) const {
         return memcmp(this, &o, sizeof(GraphKey)) < 0;
     }
@@ -63,12 +64,17 @@ struct GraphKey {
 
 std::string g_create_error;
 
-// Live contexts of this process.  The persistent BiLSTM launch needs the 32 members of each of its groups resident on their
-// XCD AT THE SAME TIME, one per CU; two such launches of two contexts on two streams can split an XCD's CUs between them and
-// wait for each other until the bounded spins give up (measured: four contexts on four streams do).  It is therefore used only
-// while ONE context exists; graphs captured in that state are keyed as such and are not replayed once a second context lives.
-// (Another PROCESS sharing the GPU is not seen here: set GSTTACO_BILSTM_PERSIST=0 there.)
+// The persistent BiLSTM launch needs the 32 members of each of its groups resident on their XCD AT THE SAME TIME, one per CU.
+// Two such launches of two contexts on two streams can split an XCD's CUs between them and wait for each other until the bounded
+// spins give up (measured: four contexts on four streams did).  Ordinary kernels of other streams only delay a member (they
+// drain), so the one thing to exclude is two persistent launches in flight together: every graph segment that contains one is
+// launched between a wait on and a record of ONE process-wide event per device, under a mutex -- the segments of all contexts
+// form a chain on the GPU, everything else (the decode loops above all) still overlaps freely.
+// (Another PROCESS sharing the GPU is not seen here; a give-up is then detected, the call redone is the caller's business
+// (gsttaco_synchronize reports it), and the context falls back to one launch per time step: see run_cached.)
 std::atomic<int> g_live_contexts{0};
+std::mutex g_persist_mu;
+std::map<int, hipEvent_t> g_persist_event;      // device -> completion of the last persistent segment enqueued by this process
 
 }  // namespace
 
@@ -124,7 +130,8 @@ struct gsttaco_ctx {
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
     bool wino4 = true;           // ... F(4,5) where its grid still fills the chip (GSTTACO_WINO4=0: F(2,5) only)
-    bool solo_now = true;        // this is the process's only live context (sampled at the start of the current call)
+    int debug_drop_member = -1;  // fault injection (gsttaco_debug_raise_handoff_error): a member of the next persistent launches never shows up
+    mutable std::string warn;    // last warning (a recovered condition): readable through gsttaco_last_error until the next error
     bool bilstm_persist = true;  // one persistent launch per BiLSTM instead of one per time step (GSTTACO_BILSTM_PERSIST=0: per step)
     bool wino = true;            // Winograd F(2,5) for the 5-tap Conv1D layers that fill the chip (GSTTACO_WINO=0: implicit GEMM only)
     bool proj_helps = true;      // merged launch: projection workgroups take recurrent-half jobs after publishing (GSTTACO_PROJ_HELPS=0 off)
@@ -189,11 +196,11 @@ struct gsttaco_ctx {
     // graph holds ~2 200 kernel nodes; a caller whose shapes vary (the reference's Feeder pads to the batch maximum) would
     // otherwise grow host and device memory without bound.  `graph_capture_after` = n: a key is captured at its n-th use and
     // runs eagerly before (1 = capture at first use; 2 suits variable-shape serving, where most shapes never repeat).
-    struct GraphEntry { hipGraphExec_t exec; uint64_t last_use; };
+    struct GraphEntry { hipGraphExec_t exec; uint64_t last_use; hipStream_t last_stream; };
     std::map<GraphKey, GraphEntry> graphs;
     std::map<GraphKey, std::pair<int, uint64_t>> graph_seen;     // uses so far (not yet captured), last use
     uint64_t graph_clock = 0;
-    int graph_cache_max = 8;
+    int graph_cache_max = 16;
     int graph_capture_after = 1;
     int n_cu = 256;             // compute units of the device (hipDeviceProp_t::multiProcessorCount), queried in ensure_device
 
@@ -628,7 +635,7 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
     HIPCHECK(c, launch_conv(c, a, s));
     // One persistent launch for the whole sequence, one (direction, 16 utterances) group per XCD (skinny_gemm.hip
     // gt_bilstm_persist_kernel; same arithmetic, bitwise the same outputs); GSTTACO_BILSTM_PERSIST=0 keeps the launch per step.
-    if (L.ph && c->bilstm_persist && c->solo_now && gt_bilstm_persist_supported(H, std::min(B, 64), c->n_cu)) {
+    if (L.ph && c->bilstm_persist && gt_bilstm_persist_supported(H, std::min(B, 64), c->n_cu)) {
         // one launch per slab of 64 utterances (8 groups = 2 directions x 4 M-tiles fill the 8 XCDs); the recurrences of
         // different utterances are independent, so the slabs simply follow each other on the stream
         for (int r0 = 0; r0 < B; r0 += 64) {
@@ -640,6 +647,7 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
             k.zx = L.z + (size_t)r0 * k.ldz; k.out = out + (size_t)r0 * k.ldo; k.h = L.ph; k.flags = L.pflags;
             k.row_len = row_len ? row_len + r0 : nullptr; k.err = c->w_err + 1;
             k.M = Bs; k.MT = (Bs + 15) / 16; k.H = H; k.T = Tn;
+            k.debug_drop_member = c->debug_drop_member;
             HIPCHECK(c, gt_launch_bilstm_persist(k, s));
             ++c->n_persist_enqueued;
         }
@@ -1339,17 +1347,42 @@ int check_shape(gsttaco_ctx* c, int B, int Tv, int Tref1, int steps) {
 }
 
 // Runs `body` either eagerly on `stream` or through a cached hipGraph captured on the internal stream (LRU-bounded,
-// see gsttaco_ctx::graphs).
+// see gsttaco_ctx::graphs).  `persist_segment`: the body may enqueue persistent BiLSTM launches (see g_persist_event).
 template <typename F>
-int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F body) {
+int run_cached_inner(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F body);
+
+// A wait of a persistent BiLSTM launch of an EARLIER call gave up (its members never became co-resident: another process
+// on the GPU, a CU mask, a profiler's kernel): that call's encodings were garbage -- gsttaco_synchronize reports it for the
+// call itself.  Here, at the next call: clear the word, stop using the persistent launch on this context (one launch per time
+// step from now on: no co-residency needed) and say so through gsttaco_last_error as a warning.  Nothing stays poisoned.
+void recover_from_give_up(gsttaco_ctx* c) {
+    if (!c->h_err || !c->h_err[1]) return;
+    c->h_err[1] = 0;
+    c->bilstm_persist = false;
+    c->debug_drop_member = -1;
+    c->warn = "warning: a hand-off wait of the persistent BiLSTM launch gave up in an earlier call (its members were not co-resident: is another "
+              "process or a CU mask sharing this GPU?); that call's outputs were invalid.  This context now runs its BiLSTMs with one launch "
+              "per time step (same results, ~0.5 ms slower per call)";
+    c->err = c->warn;
+}
+
+template <typename F>
+int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F body, bool persist_segment = false) {
+    recover_from_give_up(c);
+    if (!(persist_segment && c->bilstm_persist)) return run_cached_inner(c, stream, key_in, body);
+    std::lock_guard<std::mutex> lock(g_persist_mu);
+    hipEvent_t& ev = g_persist_event[c->cfg.device];
+    if (!ev) HIPCHECK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    else HIPCHECK(c, hipStreamWaitEvent(stream, ev, 0));
+    const int rc = run_cached_inner(c, stream, key_in, body);
+    HIPCHECK(c, hipEventRecord(ev, stream));
+    return rc;
+}
+
+template <typename F>
+int run_cached_inner(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F body) {
     GraphKey key = key_in;
-    c->solo_now = g_live_contexts.load() <= 1;
-    key.solo = c->solo_now ? 1 : 0;
-    // an in-kernel wait of an EARLIER call gave up (a producer workgroup never became resident): that call's outputs were
-    // garbage; say so now rather than never.  Sticky until the context is destroyed.
-    if (c->h_err && (c->h_err[0] | c->h_err[1]))
-        return fail(c, GSTTACO_E_HIP, "an in-kernel hand-off of a previous call gave up (persistent BiLSTM / merged decode launch): its outputs are invalid; "
-                                      "set GSTTACO_BILSTM_PERSIST=0 / GSTTACO_MERGED=0 and re-create the context");
+    key.persist = c->bilstm_persist ? 1 : 0;
     if (!c->use_graph || c->graph_cache_max < 1) return body(stream);
     const uint64_t now = ++c->graph_clock;
     auto it = c->graphs.find(key);
@@ -1387,14 +1420,15 @@ int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F bod
             auto old = c->graphs.begin();
             for (auto j = c->graphs.begin(); j != c->graphs.end(); ++j)
                 if (j->second.last_use < old->second.last_use) old = j;
-            // an evicted executable may still be running on the caller's stream from an earlier call
-            HIPCHECK(c, hipStreamSynchronize(stream));
+            // an evicted executable may still be running on the stream it was last launched on (the stream is a per-call argument)
+            HIPCHECK(c, hipStreamSynchronize(old->second.last_stream));
             (void)hipGraphExecDestroy(old->second.exec);
             c->graphs.erase(old);
         }
-        it = c->graphs.emplace(key, gsttaco_ctx::GraphEntry{exec, now}).first;
+        it = c->graphs.emplace(key, gsttaco_ctx::GraphEntry{exec, now, stream}).first;
     }
     it->second.last_use = now;
+    it->second.last_stream = stream;
     HIPCHECK(c, hipGraphLaunch(it->second.exec, stream));
     return 0;
 }
@@ -1857,6 +1891,11 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     HIPCHECK(c, gt_dec_front_init());
     HIPCHECK(c, gt_gst_init());
     HIPCHECK(c, gt_bilstm_persist_init());
+    // the persistent BiLSTM's groups need their 32 members each on a CU of their own: exactly one workgroup per CU must fit
+    if (c->bilstm_persist && gt_bilstm_persist_blocks_per_cu() != 1) {
+        c->bilstm_persist = false;
+        c->warn = c->err = "warning: the persistent BiLSTM kernel does not get one workgroup per compute unit on this device; using one launch per time step";
+    }
     HIPCHECK(c, hipDeviceSynchronize());
     // host copies are no longer needed
     for (auto& t : c->tensors) std::vector<float>().swap(t.data);
@@ -1874,7 +1913,7 @@ int gsttaco_encode(gsttaco_ctx* c, const int32_t* tokens, const int32_t* token_l
     const bool masked = token_lengths != nullptr;
     if (masked) HIPCHECK(c, hipMemcpyAsync(c->w_tok_len, token_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     GraphKey key{1, B, Tv, 0, 0, 0, 0, 0, masked};
-    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv, masked); }))) return rc;
+    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv, masked); }, true))) return rc;
     HIPCHECK(c, hipMemcpyAsync(enc, c->w_enc, (size_t)B * Tv * c->enc_out * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
@@ -1958,7 +1997,7 @@ int gsttaco_vocoder(gsttaco_ctx* c, const float* mel, int B, int Tf, float* spec
     hipStream_t s = (hipStream_t)stream;
     HIPCHECK(c, hipMemcpyAsync(c->w_mel, mel, (size_t)B * Tf * c->cfg.mel_dim * 4, hipMemcpyDeviceToDevice, s));
     GraphKey key{5, B, 0, 0, Tf, 0, 0, 0, 0};
-    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_vocoder(c, st, B, Tf, c->w_mel, c->w_spec); }))) return rc;
+    if ((rc = run_cached(c, s, key, [&](hipStream_t st) { return enqueue_vocoder(c, st, B, Tf, c->w_mel, c->w_spec); }, true))) return rc;
     HIPCHECK(c, hipMemcpyAsync(spectrogram, c->w_spec, (size_t)B * Tf * c->cfg.spec_dim * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
@@ -2054,17 +2093,26 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
     if ((rc = stage_randomness(c, s, mask, noise, seed, B, Tv, steps))) return rc;
     const bool masked = token_lengths != nullptr;
     if (masked) HIPCHECK(c, hipMemcpyAsync(c->w_tok_len, token_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-    GraphKey key{voc ? 6 : 0, B, Tv, Tref1, steps, mask != nullptr, noise != nullptr, c->prof_every, masked};
+    // Three graph segments: the encoder and the vocoder each contain a persistent BiLSTM launch and are chained process-wide
+    // (run_cached, g_persist_event); the segment between them -- GST, value projection, the decode loop, the postnet: 95 % of the
+    // call -- overlaps freely with other contexts' work.  The encoder / vocoder segments share their cached graphs with
+    // gsttaco_encode / gsttaco_vocoder.
+    GraphKey kenc{1, B, Tv, 0, 0, 0, 0, 0, masked};
+    if ((rc = run_cached(c, s, kenc, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv, masked); }, true))) return rc;
+    GraphKey key{0, B, Tv, Tref1, steps, mask != nullptr, noise != nullptr, c->prof_every, masked};
     rc = run_cached(c, s, key, [&](hipStream_t st) {
-        int r2 = enqueue_encoder(c, st, B, Tv, masked);
-        if (!r2 && gst) r2 = enqueue_gst(c, st, B, Tref1);
+        int r2 = 0;
+        if (gst) r2 = enqueue_gst(c, st, B, Tref1);
         if (!r2) r2 = enqueue_value_proj(c, st, B, Tv);
         if (!r2) r2 = enqueue_decode(c, st, B, Tv, steps, mask != nullptr, noise != nullptr, masked);
         if (!r2) r2 = enqueue_postnet(c, st, B, steps * c->r, c->w_pre, c->w_mel);
-        if (!r2 && voc) r2 = enqueue_vocoder(c, st, B, steps * c->r, c->w_mel, c->w_spec);     // Model.py:126-129
         return r2;
     });
     if (rc) return rc;
+    if (voc) {                                                                                 // Model.py:126-129
+        GraphKey kvoc{5, B, 0, 0, steps * c->r, 0, 0, 0, 0};
+        if ((rc = run_cached(c, s, kvoc, [&](hipStream_t st) { return enqueue_vocoder(c, st, B, steps * c->r, c->w_mel, c->w_spec); }, true))) return rc;
+    }
     const size_t nf = (size_t)B * steps * c->r * meld;
     HIPCHECK(c, hipMemcpyAsync(mel, c->w_mel, nf * 4, hipMemcpyDeviceToDevice, s));
     if (pre_mel) HIPCHECK(c, hipMemcpyAsync(pre_mel, c->w_pre, nf * 4, hipMemcpyDeviceToDevice, s));
@@ -2072,6 +2120,16 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
         HIPCHECK(c, hipMemcpyAsync(spectrogram, c->w_spec, (size_t)B * steps * c->r * c->cfg.spec_dim * 4, hipMemcpyDeviceToDevice, s));
     HIPCHECK(c, hipMemcpyAsync(stop, c->w_stop, (size_t)B * steps * 4, hipMemcpyDeviceToDevice, s));
     HIPCHECK(c, hipMemcpyAsync(align, c->w_align, (size_t)B * steps * Tv * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int gsttaco_synchronize(gsttaco_ctx* c, void* stream) {
+    if (!c) return GSTTACO_E_INVALID;
+    HIPCHECK(c, hipStreamSynchronize((hipStream_t)stream));
+    if (c->h_err && c->h_err[1])
+        return fail(c, GSTTACO_E_HIP, "a hand-off wait of the persistent BiLSTM launch gave up (its members were not co-resident: is another process or "
+                                      "a CU mask sharing this GPU?): the outputs of the calls since the last gsttaco_synchronize are invalid.  Repeat "
+                                      "them: the context now uses one launch per time step");
     return 0;
 }
 
@@ -2160,21 +2218,26 @@ int gsttaco_debug_randomness(gsttaco_ctx* c, float* host_masks, float* host_nois
 int gsttaco_debug_handoff_error(gsttaco_ctx* c, uint32_t* host_out) {
     if (!c || !host_out || !c->w_err) return GSTTACO_E_INVALID;
     HIPCHECK(c, hipDeviceSynchronize());
-    *host_out = c->h_err[0] | (c->h_err[1] << 8);   // [0] merged decode launch, [1] persistent BiLSTM (sticky)
+    *host_out = c->h_err[0] | (c->h_err[1] << 8);   // [1] persistent BiLSTM: set until the next compute call recovers from it
     return 0;
 }
 
 int gsttaco_debug_counters(const gsttaco_ctx* c, uint64_t out[2]) {
     if (!c || !out) return GSTTACO_E_INVALID;
     out[0] = c->n_persist_enqueued;
-    out[1] = (uint64_t)g_live_contexts.load();
+    out[1] = c->bilstm_persist ? 1u : 0u;
     return 0;
 }
 
 int gsttaco_debug_raise_handoff_error(gsttaco_ctx* c, uint32_t bits) {
     if (!c || !c->h_err) return GSTTACO_E_INVALID;
     c->h_err[0] |= bits & 0xFFu;
-    c->h_err[1] |= bits >> 8;
+    c->h_err[1] |= (bits >> 8) & 0xFFu;
+    if (bits >> 16) {               // fault injection for real: member (bits >> 16) - 1 of every group of the NEXT persistent launches exits
+        c->debug_drop_member = (int)(bits >> 16) - 1;                // at once, so the launch's waits run into their bound
+        for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // (captured launches carry the old argument)
+        c->graphs.clear();
+    }
     return 0;
 }
 

@@ -123,13 +123,15 @@ struct BiLstmPersistArgs {
     float* h;                   // workspace [8 groups][2 parities][H/16][64][4]: blocked state of the group's 16 rows
     uint32_t* flags;            // workspace [8 groups][2 parities][32 members] + [8] member counters, zeroed before the launch
     const int32_t* row_len;     // masked-mode extension (A12) or NULL
-    uint32_t* err;              // bit 0: a wait gave up
+    uint32_t* err;              // host-mapped; bit 0: a wait gave up (every member then leaves the launch)
     int64_t ldz, ldo;
     int M, MT, H, T;
+    int debug_drop_member;      // -1; >= 0: fault injection, that member rank of every group exits at once (tests)
 };
 bool gt_bilstm_persist_supported(int H, int B, int n_cu);
 hipError_t gt_launch_bilstm_persist(const BiLstmPersistArgs& a, hipStream_t stream);
 hipError_t gt_bilstm_persist_init();       // opt in to >64 KiB dynamic LDS; call once outside stream capture
+int gt_bilstm_persist_blocks_per_cu();     // occupancy of the persistent kernel (must be 1)
 hipError_t gt_launch_bilstm_lean(const BiLstmArgs& a, hipStream_t stream);
 
 // Projection [h2 | ctx] -> mel frames | stop logit | (optional) next step's prenet-0 pre-activations, with co-scheduled

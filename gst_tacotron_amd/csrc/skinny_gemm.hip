@@ -556,6 +556,7 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
     // a group sit on the 32 CUs of their XCD instead of sharing matrix cores in pairs)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int s_slot;
+    __shared__ int s_abort;
     float (*part)[NT][16][17] = reinterpret_cast<float (*)[NT][16][17]>(lds);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -565,10 +566,11 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const int g = (int)(xcc & 7);
     if (g >= 2 * A.MT) return;
-    if (tid == 0) s_slot = (int)atomicAdd(A.flags + 8 * 2 * NM + g, 1u);
+    if (tid == 0) { s_slot = (int)atomicAdd(A.flags + 8 * 2 * NM + g, 1u); s_abort = 0; }
     __syncthreads();
     const int rank = s_slot;
     if (rank >= NM) return;
+    if (rank == A.debug_drop_member) return;                       // fault injection (tests): this member never shows up
     const int d = g & 1, mt = g >> 1, H = A.H;
     // this thread's element of the member's 16 rows x (2 tiles x 16 gate columns)
     const int row = tid >> 5, j_own = (tid >> 4) & 1, col = tid & 15;
@@ -598,11 +600,16 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
         } else {
             const int par = (t - 1) & 1;
             const uint32_t want = (uint32_t)t;                     // step t - 1 publishes tag t
+            // Bounded wait.  A member that gives up raises the (host-mapped) error word; every waiting wave of every group looks
+            // at that word now and then, so the WHOLE launch drains within microseconds of the first give-up instead of every
+            // remaining time step spinning its full bound again.  The workgroup leaves together behind its next barrier.
             uint32_t spins = 0;
             for (;;) {
                 const uint32_t v = lane < NM ? gt_ldu_sc1(fl + par * NM + lane) : want;
                 if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(v >= want))) == 64) break;
-                if (++spins > (1u << 18)) { if (lane == 0) atomicOr(A.err, 1u); break; }
+                ++spins;
+                if (spins > (1u << 18)) { if (lane == 0) { atomicOr(A.err, 1u); s_abort = 1; } break; }
+                if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(gt_ldu_sc1(A.err)) != 0u) { if (lane == 0) s_abort = 1; break; }
             }
             const float* hp = hbuf + (size_t)par * 16 * H + lane * 4;
             gt_ld2x4_sc1(hp + (size_t)wave * 256, hp + (size_t)(wave + NW) * 256, x[0], x[1]);
@@ -631,6 +638,7 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
                 for (int v = 0; v < 4; ++v) part[wave][j][q * 4 + v][r] = acc[j][v];
         }
         __syncthreads();
+        if (s_abort) return;                                        // (uniform: written before the barrier)
         float z = cur;
 #pragma unroll
         for (int w = 0; w < NW; ++w) z += part[w][j_own][row][col];
@@ -663,6 +671,14 @@ hipError_t gt_launch_bilstm_persist(const BiLstmPersistArgs& a, hipStream_t stre
 
 hipError_t gt_bilstm_persist_init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(gt_bilstm_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds);
+}
+
+// workgroups of the persistent kernel one compute unit can hold at once (the design needs exactly 1: the 32 members of a
+// group each on their own CU of the group's XCD); 0 = it does not fit at all
+int gt_bilstm_persist_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(gt_bilstm_persist_kernel), 512, kPersistLds) != hipSuccess) return 0;
+    return n;
 }
 
 bool gt_bilstm_lean_supported(int nkb_h) { return nkb_h == 16; }

@@ -232,6 +232,7 @@ class GST_Tacotron:
         if export:
             kwargs["with_vocoder"] = True
         out = self.Inference_Step(**pattern_Dict, **kwargs)
+        self.synchronize()                     # the reference returns finished arrays; also where a give-up of this call surfaces
         if export:
             self.Export_Inference(sentence_List, out[0], out[1], out[2], out[3],
                                   label or datetime.now().strftime("%Y%m%d.%H%M%S"))
@@ -312,15 +313,27 @@ class GST_Tacotron:
         batch shapes vary from call to call (the reference's Feeder pads to the batch maximum, Feeder.py:175-180)."""
         self.ctx.check(self.ctx.lib.gsttaco_set_graph_policy(self.ctx.handle, int(max_cached), int(capture_after)))
 
+    def synchronize(self):
+        """Synchronises the current stream and raises GstTacoError if a hand-off wait of a persistent BiLSTM launch gave up since
+        the last check (``gsttaco_synchronize``): the outputs of those calls are invalid and should be repeated -- the context
+        then runs its BiLSTMs with one launch per time step.  ``Inference`` calls this before it returns."""
+        with torch.cuda.device(self.device):
+            self.ctx.check(self.ctx.lib.gsttaco_synchronize(self.ctx.handle, self._stream()))
+
+    def last_message(self):
+        """The library's last error or warning text for this context (``gsttaco_last_error``)."""
+        return self.ctx.lib.gsttaco_last_error(self.ctx.handle).decode()
+
     def handoff_error(self):
-        """Non-zero if an in-kernel hand-off wait ever gave up on this context (bit 0: merged decode launch, bit 8: persistent
-        BiLSTM; ``gsttaco_debug_handoff_error``).  The library itself refuses every later compute call once that happens."""
+        """Non-zero while a give-up of a persistent BiLSTM launch is pending on this context (bit 8;
+        ``gsttaco_debug_handoff_error``); the next compute call recovers from it."""
         out = ctypes.c_uint32(0)
         self.ctx.check(self.ctx.lib.gsttaco_debug_handoff_error(self.ctx.handle, ctypes.byref(out)))
         return int(out.value)
 
     def debug_counters(self):
-        """(persistent BiLSTM launches this context has enqueued, live contexts of the process) -- ``gsttaco_debug_counters``."""
+        """(persistent BiLSTM launches this context has enqueued, 1 while the context still uses the persistent launch) --
+        ``gsttaco_debug_counters``."""
         out = (ctypes.c_uint64 * 2)()
         self.ctx.check(self.ctx.lib.gsttaco_debug_counters(self.ctx.handle, out))
         return int(out[0]), int(out[1])

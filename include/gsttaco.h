@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 9
+#define GSTTACO_ABI_VERSION 10
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -231,7 +231,7 @@ int gsttaco_inference_step(gsttaco_ctx* ctx, const int32_t* tokens, const int32_
                            float* mel, float* stop, float* align, float* pre_mel, float* spectrogram, void* stream);
 
 /* hipGraph cache policy.  Every entry point replays one cached graph executable per (entry, B, Tv, Tref1, steps, flags) key.
- * The cache is LRU-bounded to `max_cached` executables (default 8; GSTTACO_GRAPH_CACHE; 0 = no graphs, everything is
+ * The cache is LRU-bounded to `max_cached` executables (default 16 -- an Inference_Step replays two or three: encoder segment, GST + decode + postnet, vocoder; GSTTACO_GRAPH_CACHE; 0 = no graphs, everything is
  * enqueued eagerly on the caller's stream); the least recently used one is destroyed when a new shape is captured.
  * `capture_after` = n >= 1: a key is captured at its n-th use and enqueued eagerly before that (default 1;
  * GSTTACO_GRAPH_CAPTURE_AFTER).  Callers whose shapes vary from batch to batch -- the reference's Feeder pads to the
@@ -249,19 +249,25 @@ int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
 /* Diagnostic (GSTTACO_STAMPS=1): 3 x 16 phase stamps (100 MHz ticks) of workgroup 0 of the fused front kernel
  * and the two decode LSTM kernels at the middle decode step of the last replay.  Synchronises the device. */
 int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
-/* In-kernel hand-offs (the persistent BiLSTM launch; the experimental three-launch decode step, GSTTACO_MERGED=1) wait with a
- * bound: a wait that gives up (a producer workgroup that never became resident -- a bug or a starved GPU, never a normal
- * outcome) raises a word in host-mapped memory instead of hanging the device.  The outputs of that call are invalid, and
- * EVERY LATER compute call on the context fails with GSTTACO_E_HIP (sticky; gsttaco_last_error says which knob disables the
- * path).  This function synchronises the device and returns the words now: bit 0 merged decode launch, bit 8 persistent
- * BiLSTM; 0 = no wait has ever given up. */
+/* The persistent BiLSTM launch (one launch for all time steps of the encoder's / vocoder's Bidirectional LSTM, reference
+ * Taco2.py:39-43, 394-398) hands its state around inside the kernel and needs the 32 workgroups of each of its groups resident
+ * together.  The library arranges that for everything it controls: exactly one workgroup per compute unit is checked at
+ * finalize, and the launches of ALL contexts of the process are chained on the GPU, so two of them never split an XCD.  What
+ * it cannot see -- another process on the GPU, a CU mask -- is caught by BOUNDED waits: a wait that gives up raises a word in
+ * host-mapped memory, the whole launch drains at once, and
+ *   - gsttaco_synchronize(ctx, stream) synchronises the stream and returns GSTTACO_E_HIP if that happened since the last check:
+ *     the outputs of those calls are invalid, repeat them;
+ *   - the NEXT compute call on the context clears the word, switches the context to one BiLSTM launch per time step (same
+ *     results, no co-residency needed), succeeds, and leaves a "warning: ..." text in gsttaco_last_error.
+ * Nothing stays poisoned and nothing hangs.  gsttaco_debug_handoff_error synchronises the device and returns the word now
+ * (bit 8: persistent BiLSTM; 0 = clear). */
+int gsttaco_synchronize(gsttaco_ctx* ctx, void* stream);
 int gsttaco_debug_handoff_error(gsttaco_ctx* ctx, uint32_t* host_out);
-/* Test support: out[0] = persistent BiLSTM launches this context has enqueued (eagerly or into a captured graph), out[1] = live
- * contexts of the process.  The persistent launch is used only while the process has ONE live context: two such launches on
- * two streams can split an XCD's CUs between them and wait for each other; with several contexts the BiLSTMs
- * run one launch per time step.  A second PROCESS on the same GPU is not seen: set GSTTACO_BILSTM_PERSIST=0 there. */
+/* Test support: out[0] = persistent BiLSTM launches this context has enqueued (eagerly or into a captured graph), out[1] = 1
+ * while the context uses the persistent launch, 0 once it has fallen back to one launch per time step. */
 int gsttaco_debug_counters(const gsttaco_ctx* ctx, uint64_t out[2]);
-/* Test support: raise the give-up word as a kernel would (bits as above), to exercise the sticky failure. */
+/* Test support (fault injection).  bits 8..15: raise the give-up word as a kernel would.  bits 16..: n > 0 makes member n - 1
+ * of every group of the NEXT persistent launches exit at once, so that their waits really run into the bound. */
 int gsttaco_debug_raise_handoff_error(gsttaco_ctx* ctx, uint32_t bits);
 /* Test support: the prenet keep-masks [steps][mask0 B*P0 | mask1 B*P1] (0/1) and SMA noise [steps][B][Tv] the LAST
  * gsttaco_inference_step / gsttaco_decode of that shape used -- generated from the seed in throughput mode, or the
