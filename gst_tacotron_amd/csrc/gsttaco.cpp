@@ -727,9 +727,10 @@ int enqueue_gst(gsttaco_ctx* c, hipStream_t s, int B, int Tref1) {
         a.k = c->ref_conv[i].k; a.stride = c->ref_conv[i].stride;
         a.pad_h = same_pad_before(H, a.k, a.stride, &a.Ho);
         a.pad_w = same_pad_before(W, a.k, a.stride, &a.Wo);
-        if (a.Cin % 4 == 0 && a.Cin >= 16 && !g.mixed_precision) {
+        if (a.Cin % 4 == 0 && a.Cin >= 16) {
             // implicit GEMM on the fp32 MFMA path (M = B*Ho*Wo rows, K = 9*Cin): the direct kernel's late layers have a
-            // few thousand threads with K = 576..1152 serial loads each (124 us for the last one)
+            // few thousand threads with K = 576..1152 serial loads each (124 us for the last one).  Under Use_Mixed_Precision
+            // too: the GST branch stays fp32 there (gt_launch_conv_gemm directly, not launch_conv's bf16 operands)
             ConvGemmArgs ga{};
             ga.x = a.x; ga.xb = a.xb; ga.w = a.w; ga.scale = a.scale; ga.shift = a.shift;
             ga.out = a.out; ga.ldo = a.Cout;

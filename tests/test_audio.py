@@ -35,6 +35,24 @@ def test_oracle_reproduces_real_speech_fixture():
     assert g["mel_60"].shape == (115, 80) and np.abs(g["mel_60"]).max() <= 4.0      # 115 frames for this wav
 
 
+def test_oracle_reproduces_the_seven_fastvox_references():
+    """tests/golden/audio_fv_all.npz (oracle/gen_golden_audio_fv.py): the reference repo's seven FastVox reference wavs as int16
+    PCM, the multi-speaker references BASELINE configs[4] names (Inference_Wav_for_Training.txt:1-7), with the oracle's
+    top_db = 15 mels (Feeder.py:204-209).  The KSP wav is also the older single-wav fixture: both must agree."""
+    g = np.load(os.path.join(GOLD, "audio_fv_all.npz"))
+    ksp = np.load(os.path.join(GOLD, "audio_fv_ksp.npz"))
+    snd = hparams.load_hp()["Sound"]
+    assert int(g["n"]) == 7 and int(g["top_db"]) == 15 and int(g["sample_rate"]) == snd["Sample_Rate"]
+    names = [str(g["name%d" % i]) for i in range(7)]
+    assert [n.split(".")[1] for n in names] == ["AWB", "BDL", "CLB", "JMK", "KSP", "RMS", "SLT"]
+    for i in range(7):
+        y = g["pcm%d" % i].astype(np.float32) / 32768.0
+        assert tuple(A.trim_bounds(A.preemphasis(y), 15, 32, 16)) == tuple(g["bounds%d" % i])
+        mel = A.mel_generate(y, snd, 15)
+        np.testing.assert_allclose(mel, g["mel%d" % i], atol=F32_STORE, rtol=0)
+    assert np.array_equal(g["pcm4"], ksp["pcm"]) and np.array_equal(g["mel4"], ksp["mel_15"])
+
+
 @pytest.mark.parametrize("name", ["tiny", "full"])
 def test_oracle_reproduces_synthetic_fixtures(name):
     g, snd = _sound(name)

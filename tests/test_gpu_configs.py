@@ -52,36 +52,50 @@ def test_config3_full_size_all_500_steps_with_padding_masks():
 
 def _cfg5_shard(B, seed=4):
     """One GPU's shard of BASELINE configs[4] (SURVEY 8(d) cfg 5): Use_Mixed_Precision, Max_Step 1000, 128-token utterances,
-    7 synthetic "speakers" (seeded reference mels of 115-250 frames, about the 1.8-4.0 s of the 7 FastVox wavs at hop 256 /
-    16 kHz) assigned round-robin."""
+    and the reference repo's seven FastVox reference wavs (Inference_Wav_for_Training.txt:1-7; committed as int16 PCM by
+    oracle/gen_golden_audio_fv.py) as the style references, assigned round-robin.  The mels come from the product's own wav ->
+    mel front end (gsttaco_mel_frontend, top_db 15 as Feeder.py:204-209 uses for several references) and are checked here
+    against the oracle's: trimmed lengths exactly, values within the audio tolerance.  Returns the model too."""
+    import os
+    import torch
     from gst_tacotron_amd import synthetic, weights
     hp = synthetic.config_hp("cfg2")
     hp["Use_Mixed_Precision"] = True
     w = weights.synthetic_weights(hp, seed=0)
-    rng = np.random.default_rng(seed)
-    spk_len = rng.integers(115, 251, 7)
-    spk = [np.clip(rng.normal(0.0, 1.5, (int(n), 80)), -4.0, 4.0).astype(np.float32) for n in spk_len]
-    Tref = int(spk_len.max())
-    mels = np.zeros((B, Tref + 1, 80), np.float32)
+    fv = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "audio_fv_all.npz"))
+    n_spk = int(fv["n"])
+    sigs = [fv["pcm%d" % i].astype(np.float32) / 32768.0 for i in range(n_spk)]
+    m = _model(hp, w, max(B, n_spk), 128, 2 + max(s.shape[0] for s in sigs) // 256)
+    spk_mels, spk_len = m.Mel_Generate(sigs, top_db=int(fv["top_db"]))
+    torch.cuda.synchronize()
+    spk_mels, spk_len = spk_mels.cpu().numpy(), spk_len.cpu().numpy()
+    for i in range(n_spk):
+        ref = fv["mel%d" % i]
+        assert spk_len[i] == ref.shape[0], (str(fv["name%d" % i]), spk_len[i], ref.shape)       # the trim decision is exact
+        assert not spk_mels[i, 0].any() and not spk_mels[i, spk_len[i] + 1:].any()             # zero frame 0, zero padding
+        err = np.abs(spk_mels[i, 1:spk_len[i] + 1] - ref).max()
+        assert err <= 2e-3 * 4.0, (str(fv["name%d" % i]), err)                               # 2e-3 of the +-4 range (tests/test_audio.py)
+    Tref1 = spk_mels.shape[1]
+    mels = np.zeros((B, Tref1, 80), np.float32)
     ml = np.zeros((B,), np.int32)
     for b in range(B):
-        s = spk[b % 7]
-        mels[b, 1:s.shape[0] + 1] = s
-        ml[b] = s.shape[0]
+        mels[b] = spk_mels[b % n_spk]
+        ml[b] = spk_len[b % n_spk]
+    rng = np.random.default_rng(seed)
     tokens, tl = synthetic.make_tokens(rng, B, 128)
     masks, noise = synthetic.make_randomness(rng, 500, B, 128, [256, 256])
-    return hp, w, tokens, tl, mels, ml, masks, noise
+    return hp, w, tokens, tl, mels, ml, masks, noise, m
 
 
 def test_config5_shard_bf16_batch64_max_step_1000_round_robin_speakers():
-    """The configs[4] per-GPU shard at full size: bf16 mixed precision, 64 utterances, Max_Step 1000 (500 steps x r = 2), 7
-    reference mels round-robin.  Properties: shapes / finiteness / alignment invariants; utterances b and b + 7 share a
+    """The configs[4] per-GPU shard at full size: bf16 mixed precision, 64 utterances, Max_Step 1000 (500 steps x r = 2), the
+    seven real FastVox reference wavs through the GPU wav -> mel front end, round-robin.  Properties: shapes / finiteness / alignment invariants; utterances b and b + 7 share a
     speaker, so their style embeddings are bitwise equal; utterance b inside the batch of 64 equals the same utterance
     decoded alone; the mode stays within MIXED_VS_FP32-like distance of the fp32 path."""
     import torch
     B = 64
-    hp, w, tokens, tl, mels, ml, masks, noise = _cfg5_shard(B)
-    m = _model(hp, w, B, 128, mels.shape[1])
+    hp, w, tokens, tl, mels, ml, masks, noise, m = _cfg5_shard(B)
+    assert sorted(set(ml.tolist())) == [88, 103, 126, 150, 191, 204, 209]     # the seven wavs' trimmed lengths in frames
     mel, stop, _, align = m.Inference_Step(tokens, None, None, mels, ml, prenet_masks=masks, attn_noise=noise)
     torch.cuda.synchronize()
     mel, align = mel.cpu().numpy(), align.cpu().numpy()
@@ -114,8 +128,7 @@ def test_config5_two_utterances_against_the_bf16_emulating_oracle():
     import time
     import torch
     from oracle import oracle_np
-    hp, w, tokens, tl, mels, ml, masks, noise = _cfg5_shard(2)
-    m = _model(hp, w, 2, 128, mels.shape[1])
+    hp, w, tokens, tl, mels, ml, masks, noise, m = _cfg5_shard(2)
     mel, stop, _, align, pre = m.Inference_Step(tokens, None, None, mels, ml, prenet_masks=masks, attn_noise=noise,
                                                 return_pre_mel=True)
     torch.cuda.synchronize()
