@@ -47,7 +47,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, debug=False):
+    """debug=True adds -DGSTTACO_DEBUG: the experiment knobs are compiled in.  Never the default."""
+    global FLAGS
+    if debug and "-DGSTTACO_DEBUG" not in FLAGS:
+        FLAGS = FLAGS + ["-DGSTTACO_DEBUG"]
     os.makedirs(LIBDIR, exist_ok=True)
     hdrs = _headers()
     if _flags_changed():
@@ -80,4 +84,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, debug="--debug" in sys.argv))

@@ -175,181 +175,10 @@ __global__ __launch_bounds__(FT) void gt_dec_front_lean_kernel(DecFrontArgs P) {
         front_worker<LEAN>(P, smem, (int)blockIdx.x - P.B);
         return;
     }
-    gt_front_lean<L, NP, false>(P, smem, (int)blockIdx.x, blockIdx.x == 0);
+    gt_front_lean<L, NP>(P, smem, (int)blockIdx.x, blockIdx.x == 0);
     if ((int)blockIdx.x < P.utt_jobs) {     // large batches: this workgroup's CU takes recurrent-half jobs once its utterance is done
         __syncthreads();
         front_worker<LEAN>(P, smem, P.n_workers + (int)blockIdx.x);
-    }
-}
-
-// ======================================================================================================================
-// Merged launch: projection of step t-1  +  front end of step t  +  recurrent halves of step t   (DecMergedArgs)
-//
-// The four-launch step spends ~2 us per dependent kernel boundary and, inside the front launch, ~4 us before the first
-// prenet FMA (argument loads, then the utterance workgroup's 256 KB of weights and memory rows through one CU's 64 B/clk load
-// pipe).  None of those loads depends on the previous step's frame: only prenet-0's pre-activations z0 do, and the projection
-// launch produces them (composed weights, DecFrontArgs::z0).  So the projection tiles run as workgroups of the SAME launch
-// and hand z0 over as tagged granules (front_lean.h): while they compute, the utterance workgroups pull their weights, and
-// the wait that remains is the projection's own ~2.7 us + a 0.45 us hand-off (tools/handoff2.hip) instead of a kernel
-// boundary + a cold start.  Producers have the lowest block indices and never wait for anything, so the launch cannot
-// deadlock whatever the residency; the consumers' spin is bounded all the same.
-// ======================================================================================================================
-
-__device__ __forceinline__ void gt_st16_sc1(float* p, f32x4 v) {
-    // write-through: the slabs are consumed by the NEXT launch, and 4 MB of dirty lines would be flushed at the kernel
-    // boundary otherwise (boundary + B / 6 TB/s)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-
-// ---- projection workgroup (tile, 16-row M-tile): K = nkb k-blocks, wave w owns k-blocks w, w + 16, ...
-template <int KPW>
-__device__ __forceinline__ void merged_proj(const DecMergedArgs& M, float* lds) {
-    const ProjArgs& P = M.proj;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = (int)blockIdx.x / P.MT, mt = (int)blockIdx.x % P.MT;
-    const int nkb = M.proj_nkb;
-    const bool st = P.dbg && blockIdx.x == 0 && tid == 0;
-    if (st) P.dbg[0] = __builtin_amdgcn_s_memrealtime();
-    const auto rs_w = gt_rsrc(P.wp + (size_t)tile * nkb * 256, (uint32_t)nkb * 1024u);
-    float4 b[KPW], x[KPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        const int kb = wave + i * (FT / 64);                    // wave-uniform
-        const int kc = min(kb, nkb - 1);                        // (a k-block past the end multiplies a zero weight block)
-        b[i] = gt_bload4(rs_w, kb < nkb ? (uint32_t)lane * 16u : GT_OOB, (uint32_t)kc * 1024u);
-        const float* xs = kc < P.nkb_a ? P.xa + ((size_t)kc * P.MT + mt) * 256 : P.xb + ((size_t)(kc - P.nkb_a) * P.MT + mt) * 256;
-        x[i] = *reinterpret_cast<const float4*>(xs + lane * 4);
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].x, b[i].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].y, b[i].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].z, b[i].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].w, b[i].w, acc, 0, 0, 0);
-    }
-    if (st) P.dbg[1] = __builtin_amdgcn_s_memrealtime();
-    // accumulators -> LDS part[wave][16 rows][17] (C/D layout: col = lane & 15, row = (lane >> 4) * 4 + reg)
-    float (*part)[16][17] = reinterpret_cast<float (*)[16][17]>(lds);
-    {
-        const int r = lane & 15, q = lane >> 4;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) part[wave][q * 4 + v][r] = acc[v];
-    }
-    __syncthreads();
-    if (st) P.dbg[2] = __builtin_amdgcn_s_memrealtime();
-    if (tid < 256) {
-        const int row = tid >> 4, col = tid & 15;
-        const int gcol = tile * 16 + col, grow = mt * 16 + row;
-        float v = P.bias[gcol];
-#pragma unroll
-        for (int w = 0; w < FT / 64; ++w) v += part[w][row][col];
-        if (grow < P.M && gcol < P.N) {
-            if (gcol >= P.col3) gt_st_granule(M.z0g + (size_t)grow * M.front.P0 + (gcol - P.col3), v, M.front.tag);
-            else if (gcol < P.n_split) P.out[(size_t)grow * P.ldo + gcol] = v;
-            else if (gcol < P.n_valid2) P.out2[(size_t)grow * P.ldo2 + (gcol - P.n_split)] = v;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (st) P.dbg[3] = __builtin_amdgcn_s_memrealtime();
-}
-
-// ---- recurrent-half worker (KSliceArgs): ONE WAVE PER TILE over a quarter of K, the slice's state rows staged in LDS
-// `slot`: this workgroup's index among the launch's job takers -- the pure workers first, then the projection workgroups, which
-// take jobs once they have published their tile.  `delay_ticks` (100 MHz): the pure workers start that long after the launch:
-// until z0 is out, the projection is the critical path and is bound by the same memory system the workers would flood;
-// afterwards the utterance workgroups touch no memory and the chip's bandwidth is free.
-__device__ __forceinline__ void merged_worker(const DecMergedArgs& M, float* lds, const int slot, const int delay_ticks) {
-    const KSliceArgs& W = M.work;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int MT = W.MT;
-    const bool st = M.front.dbg && slot == 0 && tid == 0;
-    if (st) M.front.dbg[8] = __builtin_amdgcn_s_memrealtime();
-    if (delay_ticks > 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < (long long)delay_ticks) __builtin_amdgcn_s_sleep(8);
-    }
-    const int n_slots = M.n_workers + (W.proj_helps ? M.n_proj : 0);
-    for (int job = slot; job < W.n_jobs; job += n_slots) {
-        const int per_layer = 4 * W.jobs_per_ls;
-        const int layer = W.first_layer + job / per_layer, rem = job % per_layer;
-        const int slice = rem / W.jobs_per_ls, g = rem % W.jobs_per_ls;
-        const int t0 = g * W.tiles_per_job;
-        const int nt = min(W.tiles_per_job, W.ntiles[layer] - t0);
-        const int nkb = W.ntiles[layer] / 4;                    // K / 16 = H / 16 (tiles = H / 4)
-        const int ks = nkb / 4;                                  // k-blocks per slice (16 at H = 1024)
-        const bool active = wave < nt;
-        const int tile = t0 + min(wave, nt - 1);
-        // The shared state rows (L2-served, 32 KB) are staged FIRST and waited for on their own; only then do this wave's 16
-        // weight blocks go out, and the barrier behind the staging does not wait for them: the MFMAs below start as the
-        // blocks arrive.  (Requesting both together left the compiler copying the staged registers behind a vmcnt(0).)
-        {
-            const float4* xs = reinterpret_cast<const float4*>(W.x[layer]) + (size_t)slice * ks * MT * 64;
-            const int nx = ks * MT * 64;
-            float4* xl = reinterpret_cast<float4*>(lds);
-            float4 xv[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) xv[i] = xs[min(tid + i * FT, nx - 1)];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) xl[min(tid + i * FT, nx - 1)] = xv[i];     // (clamped duplicates write the same value)
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        float4 b[16];
-        const float4* wl = reinterpret_cast<const float4*>(W.wp[layer]) + ((size_t)tile * nkb + (size_t)slice * ks) * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) b[i] = wl[(size_t)i * 64];
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (active) {
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            const float4* xl = reinterpret_cast<const float4*>(lds) + lane;
-            const int m1 = MT > 1 ? 64 : 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float4 x0 = xl[(size_t)i * MT * 64], x1 = xl[(size_t)i * MT * 64 + m1];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.x, b[i].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.x, b[i].x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.y, b[i].y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.y, b[i].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.z, b[i].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.z, b[i].z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0.w, b[i].w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1.w, b[i].w, acc1, 0, 0, 0);
-            }
-            if (slice == 0) {
-                const float bv = W.bias[layer][tile * 16 + (lane & 15)];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { acc0[v] += bv; acc1[v] += bv; }
-            }
-            float* o = W.out[layer] + (((size_t)slice * W.ntiles[layer] + tile) * MT) * 256 + lane * 4;
-            gt_st16_sc1(o, acc0);
-            if (MT > 1) gt_st16_sc1(o + 256, acc1);
-        }
-        __syncthreads();                // the next job overwrites the staged rows
-    }
-    if (st) M.front.dbg[9 + 0] = __builtin_amdgcn_s_memrealtime();
-}
-
-template <int L, int NP>
-__global__ __launch_bounds__(FT) void gt_dec_merged_kernel(DecMergedArgs M) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int bx = blockIdx.x;
-    if (bx < M.n_proj) {
-        merged_proj<5>(M, smem);
-        if (M.work.proj_helps) {
-            __syncthreads();                        // the tile's partial sums in LDS have been read
-            merged_worker(M, smem, M.n_workers + bx, 0);
-        }
-    } else if (bx < M.n_proj + M.B) {
-        gt_front_lean<L, NP, true>(M.front, smem, bx - M.n_proj, bx == M.n_proj);
-    } else {
-        merged_worker(M, smem, bx - M.n_proj - M.B, M.work.start_delay);
     }
 }
 
@@ -727,14 +556,12 @@ static bool front_exact(const DecFrontArgs& a) {
         const int kparts = FT / (N / 4);
         return (kparts <= K && K % kparts == 0) ? K / kparts : -1;
     };
-    static const bool on = !(getenv("GSTTACO_FRONT_EXACT") && getenv("GSTTACO_FRONT_EXACT")[0] == '0');
-    return on && rows(a.P0, a.P1) == 16 && rows(a.P1, a.A) == 8;
+    return rows(a.P0, a.P1) == 16 && rows(a.P1, a.A) == 8;
 }
 
 // the lean utterance path's preconditions (front_lean.h)
 static bool front_lean_ok(const DecFrontArgs& a) {
-    const bool on = !(getenv("GSTTACO_FRONT_LEAN") && getenv("GSTTACO_FRONT_LEAN")[0] == '0');
-    if (!on || !a.z0 || !front_exact(a)) return false;
+    if (!a.lean_front || !a.z0 || !front_exact(a)) return false;
     if (a.P0 > FT || a.P1 > FT || a.A > FT || a.Tv > FT) return false;
     if (a.drop_rate > 0.f && !(a.mask0 && a.mask1) && !a.keep_hash) return false;
     if (a.sigmoid_noise > 0.f && !a.noise) return false;
@@ -777,28 +604,6 @@ hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-bool gt_dec_merged_supported(int mel, int P0, int P1, int A, int Tv, int B, int nkb_proj, int H1, int H2) {
-    // OFF by default: measured on MI355X the three-launch step is no faster than the four-launch one --
-    // what the merged launch saves (a kernel boundary, the front end's weight pull hidden behind the projection: -5.3 us
-    // without workers) it loses again because the 33.6 MB of recurrent-half weights no longer have the old front launch's
-    // 9 us window and 224 + 128 workgroup slots to hide in.  GSTTACO_MERGED=1 enables it (a GPU test keeps it correct).
-    const bool on = getenv("GSTTACO_MERGED") && getenv("GSTTACO_MERGED")[0] == '1';
-    if (!on || A != 128 || B > 32 || Tv > FT || P0 > FT || P1 > FT) return false;
-    if (nkb_proj > 5 * (FT / 64) || H1 != 1024 || H2 != 1024) return false;       // KPW = 5 projection, 16-k-block slices
-    DecFrontArgs t{};
-    t.mel = mel; t.P0 = P0; t.P1 = P1; t.A = A; t.Tv = Tv;
-    return gt_dec_front_supported(mel, P0, P1, A, Tv) && front_exact(t);
-}
-
-hipError_t gt_launch_dec_merged(const DecMergedArgs& a, hipStream_t s) {
-    DecFrontArgs t{};
-    t.mel = a.front.mel; t.P0 = a.front.P0; t.P1 = a.front.P1; t.A = 128; t.Tv = a.front.Tv;
-    const size_t lds = front_lds_bytes(t);          // >= the projection's 17 KB and the workers' 32 KB
-    const dim3 grid(a.n_proj + a.B + a.n_workers), block(FT);
-    hipLaunchKernelGGL((gt_dec_merged_kernel<8, 4>), grid, block, lds, s, a);
-    return hipGetLastError();
-}
-
 hipError_t gt_dec_front_init() {
     hipError_t e;
 #define FRONT_ATTR1(L, NP, Z, LN, EX)                                                                 \
@@ -812,8 +617,6 @@ hipError_t gt_dec_front_init() {
     if (e != hipSuccess) return e;
 #define FRONT_ATTR(L, NP) FRONT_ATTR2(L, NP, false) FRONT_ATTR2(L, NP, true) FRONT_ATTRL(L, NP, 0) FRONT_ATTRL(L, NP, 1) FRONT_ATTRL(L, NP, 2)
     FRONT_ATTR(4, 1) FRONT_ATTR(8, 1) FRONT_ATTR(8, 2) FRONT_ATTR(8, 4) FRONT_ATTR(8, 8)
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_dec_merged_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
 #undef FRONT_ATTR
 #undef FRONT_ATTRL
 #undef FRONT_ATTR1

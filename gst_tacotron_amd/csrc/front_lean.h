@@ -30,42 +30,17 @@ __device__ __forceinline__ float4 gt_bload4(__amdgpu_buffer_rsrc_t rs, uint32_t 
     return r;
 }
 
-// 8-byte {value, tag} granule: one naturally aligned write-through store, so a reader sees either the old pair or the new
-// one (MI355X_MICROARCH.md, hand-off price list, 'handoff-1to1').  Measured for this use in tools/handoff2.hip: last
-// publish -> every consumer workgroup has its row 0.44 us (max 0.6), no wrong value and no give-up in 1 200 launches.
-__device__ __forceinline__ void gt_st_granule(GtGranule* p, float v, uint32_t tag) {
-    const unsigned long long bits = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
-    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(bits) : "memory");
-}
-__device__ __forceinline__ unsigned long long gt_ld_granule(const GtGranule* p) {
-    unsigned long long bits;
-    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(bits) : "v"(p) : "memory");
-    return bits;
-}
-
-// argument-block accessors: DecFrontArgs (general launch) has z0, FrontLeanArgs (merged launch) the granules
-__device__ __forceinline__ const float* gt_z0_ptr(const DecFrontArgs& P, int b) { return P.z0 + (size_t)b * P.P0; }
-__device__ __forceinline__ const GtGranule* gt_z0g_ptr(const DecFrontArgs&, int) { return nullptr; }
-__device__ __forceinline__ uint32_t gt_tag(const DecFrontArgs&) { return 0u; }
-__device__ __forceinline__ void gt_flag_error(const DecFrontArgs&) {}
-__device__ __forceinline__ const float* gt_z0_ptr(const FrontLeanArgs& P, int) { return P.v; }
-__device__ __forceinline__ const GtGranule* gt_z0g_ptr(const FrontLeanArgs& P, int b) { return P.z0g + (size_t)b * P.P0; }
-__device__ __forceinline__ uint32_t gt_tag(const FrontLeanArgs& P) { return P.tag; }
-__device__ __forceinline__ void gt_flag_error(const FrontLeanArgs& P) { if (P.err) atomicOr(P.err, 1u); }
-
 #define GT_LSTAMP(slot)                                                                         \
     do {                                                                                        \
         if (P.dbg && stamp_wg && threadIdx.x == 0) P.dbg[slot] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 
-// Preconditions (checked on the host, front_lean_ok): P.z0 != NULL (or GRAN); FT % (P1/4) == 0, P0 == 16 * FT / (P1/4);
+// Preconditions (checked on the host, front_lean_ok): P.z0 != NULL; FT % (P1/4) == 0, P0 == 16 * FT / (P1/4);
 // FT % (A/4) == 0, P1 == 8 * FT / (A/4); P0, P1, A, T_v <= FT; drop_rate == 0 or (both masks given) or keep_hash;
 // sigmoid_noise == 0 or noise given.
-// `b`: utterance (row) of this workgroup.  GRAN: the prenet-0 pre-activations of this step are produced by the projection
-// workgroups of the SAME launch (dec_front.hip gt_dec_merged_kernel) and arrive as granules tagged with the step number;
-// everything that does not depend on them -- every weight, the processed memory -- is requested before the wait.
-template <int L, int NP, bool GRAN, class Args>
-__device__ __forceinline__ void gt_front_lean(const Args& P, float* smem, const int b, const bool stamp_wg) {
+// `b`: utterance (row) of this workgroup.
+template <int L, int NP>
+__device__ __forceinline__ void gt_front_lean(const DecFrontArgs& P, float* smem, const int b, const bool stamp_wg) {
     constexpr int A = 4 * L * NP;
     constexpr int ROWS = FT / L;
     constexpr int LD = A + 4;
@@ -105,7 +80,7 @@ __device__ __forceinline__ void gt_front_lean(const Args& P, float* smem, const 
     float* tile = partial + 4 * FT;
 
     // ---- descriptors (wave-uniform: kernel arguments and blockIdx only); absent operands get an empty one
-    const auto rs_z0 = gt_rsrc(gt_z0_ptr(P, b), GRAN ? 0u : (uint32_t)P0 * 4u);
+    const auto rs_z0 = gt_rsrc(P.z0 + (size_t)b * P0, (uint32_t)P0 * 4u);
     const auto rs_v = gt_rsrc(P.v, (uint32_t)A * 4u);
     const auto rs_pv = gt_rsrc(P.prev ? P.prev + (size_t)b * P.ldprev : P.v, P.prev ? (uint32_t)Tv * 4u : 0u);
     const auto rs_b1 = gt_rsrc(P.b1, (uint32_t)P1 * 4u);
@@ -121,7 +96,7 @@ __device__ __forceinline__ void gt_front_lean(const Args& P, float* smem, const 
 
     // ---- small operands first (loads return in issue order); indices past an operand's end are out of range = 0
     const uint32_t t4 = (uint32_t)tid * 4u;
-    float in_x = gt_bload1(rs_z0, t4);         // (GRAN: empty descriptor, the value arrives through the granules below)
+    const float in_x = gt_bload1(rs_z0, t4);
     const float in_v = gt_bload1(rs_v, t4);
     float in_p = gt_bload1(rs_pv, t4);
     const float t_b1 = gt_bload1(rs_b1, t4);
@@ -147,17 +122,6 @@ __device__ __forceinline__ void gt_front_lean(const Args& P, float* smem, const 
     const uint32_t off1 = (uint32_t)((g1.kp * 16 * P1 + g1.cg * 4) * 4);
     const int row = tid / L, li = tid % L;
     float4 rq[8], v0[NP];
-    if (GRAN) {
-        // merged launch: z0 is several microseconds away (the projection runs meanwhile), so EVERYTHING else is pulled before
-        // the wait -- this utterance's processed-memory rows (requested first: they go to the LDS tile with the small
-        // operands and hand their registers to the query weights), W1, then the query weights; after the wait the chain
-        // touches no memory
-        const uint32_t offr = (uint32_t)((row * A + 4 * li) * 4);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) v0[j] = gt_bload4(rs_pm, offr, (uint32_t)(16 * L * j));
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-    }
     float4 r1[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) r1[i] = gt_bload4(rs_w1, ((rb1 >> i) & 1u) ? off1 : GT_OOB, (uint32_t)(i * P1 * 4));
@@ -176,29 +140,6 @@ __device__ __forceinline__ void gt_front_lean(const Args& P, float* smem, const 
     if (tid < P1) { sb1[tid] = t_b1; sk1[tid] = t_k1; }
     if (tid < A) { sbq[tid] = t_bq; vs[tid] = in_v; }
     if (tid < Tv) { snz[tid] = P.sigmoid_noise * t_nz; pv[tid] = in_p; }
-    if (GRAN) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) *reinterpret_cast<float4*>(tile + row * LD + 4 * (li + L * j)) = v0[j];
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const uint32_t offq = (uint32_t)((g2.kp * 8 * A + g2.cg * 4) * 4);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rq[i] = gt_bload4(rs_wq, ((rbq >> i) & 1u) ? offq : GT_OOB, (uint32_t)(i * A * 4));
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // this utterance's row of z0: poll each granule until it carries this step's tag (bounded: a producer that never
-        // publishes sets the error word instead of hanging the GPU)
-        GT_LSTAMP(9);
-        if (tid < P0) {
-            const GtGranule* g = gt_z0g_ptr(P, b) + tid;
-            uint32_t spins = 0;
-            for (;;) {
-                const unsigned long long bits = gt_ld_granule(g);
-                if ((uint32_t)(bits >> 32) == gt_tag(P)) { in_x = __uint_as_float((uint32_t)bits); break; }
-                if (++spins > (1u << 20)) { gt_flag_error(P); in_x = 0.f; break; }
-            }
-        }
-    }
     if (tid < P0) y0[tid] = fmaxf(in_x, 0.f) * t_k0;
     GT_LSTAMP(0);
     __syncthreads();
@@ -219,7 +160,7 @@ __device__ __forceinline__ void gt_front_lean(const Args& P, float* smem, const 
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (!GRAN) {
+        {
             const uint32_t offq = (uint32_t)((g2.kp * 8 * A + g2.cg * 4) * 4);
 #pragma unroll
             for (int i = 0; i < 8; ++i) rq[i] = gt_bload4(rs_wq, ((rbq >> i) & 1u) ? offq : GT_OOB, (uint32_t)(i * A * 4));
@@ -234,7 +175,7 @@ __device__ __forceinline__ void gt_front_lean(const Args& P, float* smem, const 
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (!GRAN) {
+    {
         const uint32_t offr = (uint32_t)((row * A + 4 * li) * 4);
 #pragma unroll
         for (int j = 0; j < NP; ++j) v0[j] = gt_bload4(rs_pm, offr, (uint32_t)(16 * L * j));
@@ -263,10 +204,8 @@ __device__ __forceinline__ void gt_front_lean(const Args& P, float* smem, const 
     }
     __syncthreads();
     if (tid < A) qs[tid] = reduce_partial(partial, g2.kparts, A, tid) + sbq[tid];
-    if (!GRAN) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) *reinterpret_cast<float4*>(tile + row * LD + 4 * (li + L * j)) = v0[j];
-    }
+    for (int j = 0; j < NP; ++j) *reinterpret_cast<float4*>(tile + row * LD + 4 * (li + L * j)) = v0[j];
     __syncthreads();
     GT_LSTAMP(4);
 

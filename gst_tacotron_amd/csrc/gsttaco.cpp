@@ -115,35 +115,28 @@ struct gsttaco_ctx {
     PackedLinear prenet0, prenet1, query, val_gst, lstm0, lstm1, proj;
     PackedLinear lstm_x[2], lstm_h[2];   // split packs: input half (critical path) / recurrent half + bias (front-kernel workers)
     float* w_part[2] = {nullptr, nullptr};
-    // merged "projection + front + recurrent halves" launch (kernels.h DecMergedArgs): K-slice slabs, z0 granules, second
-    // [prenet | context] buffer (the front end of step t writes it while the projection of step t-1 still reads the other)
-    float* w_slab[2] = {nullptr, nullptr};
-    GtGranule* w_z0g = nullptr;
-    uint32_t* w_err = nullptr;   // device alias of h_err: [0] merged decode launch, [1] persistent BiLSTM
+    uint32_t* w_err = nullptr;   // device alias of h_err: [1] persistent BiLSTM give-up word ([0] unused)
     uint32_t* h_err = nullptr;
     bool counted = false;        // this context is included in g_live_contexts
     uint64_t n_persist_enqueued = 0;     // persistent BiLSTM launches enqueued (eagerly or into a captured graph)
-    float* w_xa2 = nullptr;
-    bool split_rec = true;
+    bool split_rec = true;       // recurrent halves of the decode LSTMs computed beside the front end / projection (GSTTACO_DEBUG: SPLIT_REC=0)
     int keep_x_weights = 1;
     int co_tiles = -1;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end); -1 = by batch size
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
-    bool wino4 = true;           // ... F(4,5) where its grid still fills the chip (GSTTACO_WINO4=0: F(2,5) only)
+    int wino = 4;                // Winograd for the 5-tap Conv1D layers that fill the chip: 4 = F(4,5) where its grid fills the chip and F(2,5)
+                                 // otherwise, 2 = F(2,5) only, 0 = implicit GEMM only (GSTTACO_WINO)
+    bool bilstm_persist = true;  // one persistent launch per BiLSTM instead of one per time step (GSTTACO_BILSTM_PERSIST=0: per step)
+    bool keep_hash = true;       // throughput mode: hashed keep decisions, dropped weight rows not requested (GSTTACO_DEBUG: KEEP_HASH=0)
     int debug_drop_member = -1;  // fault injection (gsttaco_debug_raise_handoff_error): a member of the next persistent launches never shows up
     mutable std::string warn;    // last warning (a recovered condition): readable through gsttaco_last_error until the next error
-    bool bilstm_persist = true;  // one persistent launch per BiLSTM instead of one per time step (GSTTACO_BILSTM_PERSIST=0: per step)
-    bool wino = true;            // Winograd F(2,5) for the 5-tap Conv1D layers that fill the chip (GSTTACO_WINO=0: implicit GEMM only)
-    bool proj_helps = true;      // merged launch: projection workgroups take recurrent-half jobs after publishing (GSTTACO_PROJ_HELPS=0 off)
-    bool co_lstm2 = false;       // merged plan: layer 1's recurrent half computed by the layer-2 LSTM launch (GSTTACO_CO_LSTM2=0 off)
-    int worker_delay = 300;      // merged launch: the pure workers start this many 100 MHz ticks after it (GSTTACO_WORKER_DELAY)
-    bool keep_hash = true;       // GSTTACO_KEEP_HASH=0: the front kernel reads the generated masks from HBM like injected ones
     bool lean = true;            // lean_body.h kernels for the decode shapes they cover (GSTTACO_LEAN=0: general kernels only)
     double sched_unit[2] = {5.8, 3.4}, sched_chain = 9.5;     // plan_front_jobs cost model (us): fp32 / bf16 unit, chain
 
     float *pw0 = nullptr, *pb0 = nullptr, *pw1 = nullptr, *pb1 = nullptr, *pwq = nullptr, *pbq = nullptr;  // plain layouts (fused front)
     bool fused_front = true;
-    bool fuse_prenet0 = true;   // prenet-0 pre-activations computed by the previous step's projection launch (GSTTACO_FUSE_PRENET0=0 off)
+    int front_mode = 2;         // GSTTACO_FUSED_FRONT: 0 = four-kernel front end, 1 = the general fused kernel, 2 = + the lean utterance path
+    bool fuse_prenet0 = true;   // prenet-0 pre-activations computed by the previous step's projection launch (GSTTACO_DEBUG: FUSE_PRENET0=0)
     PackedLinear proj_z;        // projection columns | padding to a tile | (Wp_last . W0) columns
     int z_col0 = 0;
     float* w_z0 = nullptr;
@@ -513,7 +506,7 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
     if (!rc) rc = add_bf16(c, L->w, k.data.data(), L->taps * L->cin, L->cout, L->cout);
     if (!rc) rc = upload(c, &L->scale, sc.data(), sc.size());
     if (!rc) rc = upload(c, &L->shift, sh.data(), sh.size());
-    if (!rc && c->wino && L->taps == 5 && L->cin % 4 == 0 && L->cout % 4 == 0) {
+    if (!rc && c->wino != 0 && L->taps == 5 && L->cin % 4 == 0 && L->cout % 4 == 0) {
         // U_xi = sum_k G[xi][k] w[k]  (Cook-Toom F(2,5), points 0, +-1, +-1/2, infinity), formed in float64
         static const double G[6][5] = {{4, 0, 0, 0, 0},
                                        {2.0 / 3, 2.0 / 3, 2.0 / 3, 2.0 / 3, 2.0 / 3},
@@ -532,7 +525,7 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
                 u[xi * cnp + i] = (float)acc;
             }
         rc = upload(c, &L->wino_u, u.data(), u.size());
-        if (!rc && c->wino4) {
+        if (!rc && c->wino >= 4) {
             // F(4,5), points 0, +-1, +-1/2, +-2, infinity
             static const double G4[8][5] = {{-1, 0, 0, 0, 0},
                                             {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
@@ -779,16 +772,6 @@ int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
     return 0;
 }
 
-// Is the 3-launch decode step (merged projection + front + recurrent halves, kernels.h DecMergedArgs) used for this shape?
-bool merged_plan(const gsttaco_ctx* c, int B, int Tv) {
-    const gsttaco_config& g = c->cfg;
-    if (!(c->fused_front && c->split_rec && c->lean && c->fuse_prenet0 && c->keep_x_weights) || g.att_type == GSTTACO_ATT_LSA) return false;
-    if (c->proj_z.wp == nullptr || c->proj_z.bf16 || c->lstm_h[0].bf16 || c->lstm_x[0].bf16) return false;
-    if (!gt_lstm_x_supported(c->lstm_x[0].nkb) || !gt_lstm_x_supported(c->lstm_x[1].nkb)) return false;
-    if (c->lstm_h[0].nkb != 64 || c->lstm_h[1].nkb != 64) return false;
-    return gt_dec_merged_supported(g.mel_dim, c->P0, c->P1, c->att, Tv, B, c->proj_z.nkb, c->H1, c->H2);
-}
-
 // Front launch, batches above 32 rows: who computes which recurrent-half job (kernels.h DecFrontArgs::sched_*).  A job is a pair
 // of tiles over every 32-row chunk of the batch with the weights held in registers; at large fp32 batches it is MFMA-bound
 // and outlasts the per-utterance chain, so the CUs of finished utterance workgroups are worth more than a second round on the
@@ -834,12 +817,6 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     if (g.att_type == GSTTACO_ATT_LSA) HIPCHECK(c, gt_launch_zero(c->w_lsa_state, (size_t)B * Tv, s));   // Layers.py:356
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
-    // merged launch (3 launches per step): fp32 lean shapes, B <= 32, prenet 0 folded into the projection
-    const bool merged_ok = merged_plan(c, B, Tv);
-    if (merged_ok) {
-        // tags of an earlier call must not match this call's step numbers
-        HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_z0g), (size_t)MT * 16 * P0 * 2, s));
-    }
     // throughput mode: the whole decode's dropout masks and sigmoid noise are generated up front (same Philox streams the
     // step kernels would draw) into the buffers injected tensors use, so no step spends time on random numbers
     const bool injected_mask = has_mask;
@@ -881,59 +858,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         const bool fused = c->fused_front && g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv);
         const bool split = fused && c->split_rec;
         const bool use_z0 = split && c->proj_z.wp != nullptr;        // prenet-0 rides in the projection launch
-        const bool merged = merged_ok && t > 0;
-        // [prenet | context] of step t: ping-pong when the merged launch is in use (see w_xa2)
-        float* xa_t = merged_ok ? ((t & 1) ? c->w_xa2 : c->w_xa) : c->w_xa;
-        float* xa_prev = merged_ok ? ((t & 1) ? c->w_xa : c->w_xa2) : c->w_xa;
-        if (merged) {
-            DecMergedArgs m{};
-            const PackedLinear& PJ = c->proj_z;
-            m.n_proj = PJ.ntiles * MT; m.B = B;
-            m.n_workers = std::max(1, c->n_cu - m.n_proj - B);
-            m.proj = ProjArgs{PJ.wp, PJ.bias, c->w_h2[p ^ 1], xa_prev + (size_t)(P1 / 16) * BLK, H2 / 16, B, MT, c->z_col0 + P0, mel * r,
-                              c->proj_out, c->z_col0, c->w_pre + (size_t)(t - 1) * r * mel, ld_pre, c->w_stop + (t - 1), (int64_t)steps,
-                              nullptr, 0, (c->stamps && t == steps / 2) ? c->w_dbg + 40 : nullptr};
-            m.proj_nkb = PJ.nkb;
-            m.z0g = c->w_z0g;
-            FrontLeanArgs& f = m.front;
-            f.w1 = c->pw1; f.b1 = c->pb1; f.wq = c->pwq; f.bq = c->pbq;
-            f.mask0 = mask0; f.mask1 = mask1; f.keep_hash = 0;
-            if (!injected_mask && g.prenet_rate == 0.5f && c->keep_hash) { f.mask0 = f.mask1 = nullptr; f.keep_hash = 1; }
-            f.pm = c->w_pm; f.v = c->att_v; f.score_bias = c->att_sb;
-            f.prev = c->w_align + (size_t)(t - 1) * Tv; f.ldprev = (int64_t)steps * Tv;
-            f.noise = has_noise ? c->w_noise + (size_t)t * B * Tv : nullptr; f.ldnoise = Tv;
-            f.align = c->w_align + (size_t)t * Tv; f.ldalign = (int64_t)steps * Tv;
-            f.xa = xa_t; f.seed_ptr = c->w_seed; f.tok_len = tlen;
-            f.dbg = (c->stamps && t == steps / 2) ? c->w_dbg : nullptr;
-            f.z0g = c->w_z0g; f.err = c->w_err;
-            f.MT = MT; f.B = B; f.Tv = Tv; f.mel = mel; f.P0 = P0; f.P1 = P1; f.type = g.att_type;
-            f.rng_step = (uint32_t)t; f.tag = (uint32_t)t;
-            f.drop_rate = g.prenet_rate; f.drop_scale = drop_scale; f.sigmoid_noise = g.sigmoid_noise;
-            KSliceArgs& w = m.work;
-            for (int layer = 0; layer < 2; ++layer) {
-                const PackedLinear& L = c->lstm_h[layer];
-                w.wp[layer] = L.wp; w.bias[layer] = L.bias; w.ntiles[layer] = L.ntiles;
-                w.x[layer] = layer == 0 ? c->w_h1[p ^ 1] : c->w_h2[p ^ 1];
-                w.out[layer] = c->w_slab[layer];
-            }
-            w.MT = MT;
-            // layer 1's recurrent half rides in the previous step's layer-2 LSTM launch (same input h1, LstmXArgs::wp_co)
-            w.first_layer = c->co_lstm2 ? 1 : 0;
-            const int nlay = 2 - w.first_layer;
-            const int ntl = std::max(w.ntiles[0], w.ntiles[1]);
-            w.proj_helps = c->proj_helps ? 1 : 0;
-            const int slots = m.n_workers + (w.proj_helps ? m.n_proj : 0);
-            const int want = std::max(1, slots / (4 * nlay));              // jobs per (layer, slice) if every taker gets one
-            w.tiles_per_job = std::min(16, std::max(1, (ntl + want - 1) / want));
-            if (const char* e = getenv("GSTTACO_TILES_PER_JOB")) w.tiles_per_job = std::min(16, std::max(1, atoi(e)));
-            w.jobs_per_ls = (ntl + w.tiles_per_job - 1) / w.tiles_per_job;
-            w.n_jobs = nlay * 4 * w.jobs_per_ls;
-            if (getenv("GSTTACO_DEBUG_NO_WORKERS")) w.n_jobs = 0;          // timing experiments only: results are WRONG
-            w.start_delay = c->worker_delay;
-            if (prof) { int rce = prof_begin(2); if (rce) return rce; }
-            HIPCHECK(c, gt_launch_dec_merged(m, s));
-            if (prof) { int rce = prof_end(2); if (rce) return rce; }
-        } else if (fused) {
+        float* xa_t = c->w_xa;
+        if (fused) {
             // 1-4 fused: prenet x2, query projection, score / alignment / context (dec_front.hip)
             DecFrontArgs f{};
             f.frame = frame_ptr; f.ldframe = frame_ld;
@@ -956,6 +882,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             f.sigmoid_noise = g.sigmoid_noise;
             f.tok_len = tlen;
             f.dbg = (c->stamps && t == steps / 2) ? c->w_dbg : nullptr;
+            f.lean_front = c->front_mode >= 2 ? 1 : 0;
             if (split) {
                 for (int layer = 0; layer < 2; ++layer) {
                     SkinnyArgs& rk = f.rec[layer];
@@ -1042,7 +969,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 k.wp = L.wp; k.bf16 = L.bf16; k.bias = L.bias; k.nkb = L.nkb;
                 if (layer == 0) k.seg[0] = SkinnySeg{xa_t, 0, XA / 16, 1};
                 else k.seg[0] = SkinnySeg{c->w_h1[p], 0, H1 / 16, 1};
-                k.partial_in = merged ? c->w_slab[layer] : c->w_part[layer];
+                k.partial_in = c->w_part[layer];
                 k.keep_weights = c->keep_x_weights;
             } else {
                 const PackedLinear& L = layer == 0 ? c->lstm0 : c->lstm1;
@@ -1060,13 +987,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             k.dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
             if (prof) { int rce = prof_begin(layer); if (rce) return rce; }
             if (split && c->lean && c->keep_x_weights && gt_lstm_x_supported(k.nkb)) {
-                // merged plan with co_lstm2: layer 1 takes the old-layout partial the previous step's layer-2 launch wrote,
-                // layer 2 the workers' slabs and (not at the last step) produces layer 1's partial for the next step
-                const bool co = merged_ok && c->co_lstm2;
-                LstmXArgs la{k.wp, k.seg[0].ptr, k.partial_in, k.c, k.h, nullptr, k.dbg, B, MT, H, 0, k.nkb, merged ? 4 : 0,
-                             nullptr, nullptr, nullptr};
-                if (co && layer == 0 && merged) { la.partial_in = c->w_part[0]; la.nslab = 0; }
-                if (co && layer == 1 && t + 1 < steps) { la.wp_co = c->lstm_h[0].wp; la.bias_co = c->lstm_h[0].bias; la.partial_out = c->w_part[0]; }
+                LstmXArgs la{k.wp, k.seg[0].ptr, k.partial_in, k.c, k.h, nullptr, k.dbg, B, MT, H, 0, k.nkb};
                 HIPCHECK(c, gt_launch_lstm_x(la, k.nkb, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2, k.bf16 != 0, s));
             } else
             HIPCHECK(c, launch_skinny(c, EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));
@@ -1077,7 +998,6 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             int rce = prof_begin(4); if (rce) return rce;
             rce = prof_end(4); if (rce) return rce;
         }
-        if (merged_ok && t + 1 < steps) continue;       // it runs inside the NEXT step's merged launch
         memset(&k, 0, sizeof(k));
         const PackedLinear& PJ = (use_z0 && t + 1 < steps) ? c->proj_z : c->proj;
         k.wp = PJ.wp; k.bf16 = PJ.bf16; k.bias = PJ.bias;
@@ -1511,35 +1431,31 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->proj_out = g.mel_dim * g.step_reduction + 1;
     c->conv_c = g.enc_filters[g.n_enc_conv - 1];
     c->P0 = g.prenet[0]; c->P1 = g.prenet[1]; c->H1 = g.dec_rnn[0]; c->H2 = g.dec_rnn[1]; c->att = g.att_size;
-    const char* eg = getenv("GSTTACO_GRAPH");
-    c->use_graph = !(eg && eg[0] == '0');
-    const char* ef = getenv("GSTTACO_FUSED_FRONT");
-    c->fused_front = !(ef && ef[0] == '0');
-    const char* er = getenv("GSTTACO_SPLIT_REC");
-    c->split_rec = !(er && er[0] == '0');
-    const char* ez = getenv("GSTTACO_FUSE_PRENET0");
-    c->fuse_prenet0 = !(ez && ez[0] == '0');
-    const char* ek = getenv("GSTTACO_KEEP_X");
-    if (ek) c->keep_x_weights = atoi(ek);
-    if (const char* e = getenv("GSTTACO_CO_TILES")) c->co_tiles = std::max(0, atoi(e));
-    if (const char* e = getenv("GSTTACO_WORKER_TILES")) c->worker_tiles = atoi(e);
-    if (const char* e = getenv("GSTTACO_CO_WORKER_TILES")) c->co_worker_tiles = atoi(e);
-    if (const char* e = getenv("GSTTACO_LEAN")) c->lean = e[0] != '0';
-    if (const char* e = getenv("GSTTACO_GRAPH_CACHE")) c->graph_cache_max = std::max(0, atoi(e));
-    if (const char* e = getenv("GSTTACO_GRAPH_CAPTURE_AFTER")) c->graph_capture_after = std::max(1, atoi(e));
-    if (const char* e = getenv("GSTTACO_KEEP_HASH")) c->keep_hash = e[0] != '0';
-    if (const char* e = getenv("GSTTACO_WORKER_DELAY")) c->worker_delay = std::max(0, atoi(e));
-    if (const char* e = getenv("GSTTACO_CO_LSTM2")) c->co_lstm2 = e[0] != '0';
-    if (const char* e = getenv("GSTTACO_PROJ_HELPS")) c->proj_helps = e[0] != '0';
-    if (const char* e = getenv("GSTTACO_WINO")) c->wino = e[0] != '0';
-    if (const char* e = getenv("GSTTACO_WINO4")) c->wino4 = e[0] != '0';
-    if (const char* e = getenv("GSTTACO_BILSTM_PERSIST")) c->bilstm_persist = e[0] != '0';
+    // The environment is read ONCE, here (INTEGRATION.md section 6 documents these nine; GSTTACO_LIB is the Python binding's).
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
+    c->use_graph = env_int("GSTTACO_GRAPH", 1) != 0;
+    c->graph_cache_max = std::max(0, env_int("GSTTACO_GRAPH_CACHE", c->graph_cache_max));
+    c->graph_capture_after = std::max(1, env_int("GSTTACO_GRAPH_CAPTURE_AFTER", c->graph_capture_after));
+    c->front_mode = std::min(2, std::max(0, env_int("GSTTACO_FUSED_FRONT", 2)));
+    c->fused_front = c->front_mode != 0;
+    c->lean = env_int("GSTTACO_LEAN", 1) != 0;
+    c->bilstm_persist = env_int("GSTTACO_BILSTM_PERSIST", 1) != 0;
+    c->wino = env_int("GSTTACO_WINO", 4);
+    c->stamps = env_int("GSTTACO_STAMPS", 0) == 1;
+#ifdef GSTTACO_DEBUG
+    // experiment knobs, compiled only into -DGSTTACO_DEBUG builds (python -m gst_tacotron_amd.build --debug)
+    c->split_rec = env_int("GSTTACO_SPLIT_REC", 1) != 0;
+    c->fuse_prenet0 = env_int("GSTTACO_FUSE_PRENET0", 1) != 0;
+    c->keep_x_weights = env_int("GSTTACO_KEEP_X", 1);
+    c->co_tiles = env_int("GSTTACO_CO_TILES", -1);
+    c->worker_tiles = env_int("GSTTACO_WORKER_TILES", 2);
+    c->co_worker_tiles = env_int("GSTTACO_CO_WORKER_TILES", 1);
+    c->keep_hash = env_int("GSTTACO_KEEP_HASH", 1) != 0;
     if (const char* e = getenv("GSTTACO_SCHED")) {      // "unit_fp32,unit_bf16,chain" in microseconds (cost model of plan_front_jobs)
         double a = 0, b = 0, d = 0;
         if (sscanf(e, "%lf,%lf,%lf", &a, &b, &d) == 3 && a > 0 && b > 0 && d >= 0) { c->sched_unit[0] = a; c->sched_unit[1] = b; c->sched_chain = d; }
     }
-    const char* es = getenv("GSTTACO_STAMPS");
-    c->stamps = es && es[0] == '1';
+#endif
     build_manifest(c);
     c->counted = true;
     g_live_contexts.fetch_add(1);
@@ -1854,12 +1770,6 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     }
     if ((rc = fa(&c->w_part[0], Bp * 4 * c->H1))) return rc;
     if ((rc = fa(&c->w_part[1], Bp * 4 * c->H2))) return rc;
-    if ((rc = fa(&c->w_slab[0], 4 * Bp * 4 * c->H1))) return rc;
-    if ((rc = fa(&c->w_slab[1], 4 * Bp * 4 * c->H2))) return rc;
-    if ((rc = fa(&c->w_xa2, Bp * (c->P1 + c->att)))) return rc;
-    HIPCHECK(c, hipMemset(c->w_xa2, 0, Bp * (c->P1 + c->att) * sizeof(float)));
-    if ((rc = dev_alloc(c, (void**)&c->w_z0g, Bp * c->P0 * sizeof(GtGranule)))) return rc;
-    HIPCHECK(c, hipMemset(c->w_z0g, 0, Bp * c->P0 * sizeof(GtGranule)));
     // the give-up words of the in-kernel hand-offs live in host-mapped memory: the device raises them with a system-scope
     // atomic (failure path only), the host reads them without a synchronisation at the start of the next call
     HIPCHECK(c, hipHostMalloc((void**)&c->h_err, 16, hipHostMallocMapped));
@@ -2270,13 +2180,10 @@ int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int which, int B) {
             return fused ? gemm(H1, 4 * H2, 4 * H2 + 3 * H2) : gemm(H1 + H2, 4 * H2, 3 * H2);
         case 2: {   // front: prenet x2 + query weights, processed memory, alignments; + workers' recurrent halves
             int64_t b = 4 * (mel * P0 + P0 + P0 * P1 + P1 + P1 * A + A) + 4 * (int64_t)B * (Tv * A + mel + 2 * Tv + P1 + A);
-            if (merged_plan(c, B, (int)Tv))     // merged launch: + the projection of the previous step and ALL recurrent tiles
-                return b + gemm(H2 + A, c->proj_out + P0, c->proj_out + P0) + gemm(H1, 4 * H1, 4 * H1) + gemm(H2, 4 * H2, 4 * H2);
             if (fused) b += gemm(H1, 4 * H1, 4 * H1) + (ntile2 - co_tiles) * (4 * (H2 * 16 + 16) + 4 * (int64_t)B * 16) + 4 * (int64_t)B * H2;
             return b;
         }
         default: {  // projection (+ co-scheduled layer-2 recurrent tiles)
-            if (merged_plan(c, B, (int)Tv)) return 0;      // inside the merged launch (which = 2)
             int64_t b = gemm(H2 + A, c->proj_out, c->proj_out);
             if (fused) b += co_tiles * (4 * (H2 * 16 + 16) + 4 * (int64_t)B * 16);
             return b;

@@ -85,11 +85,6 @@ struct LstmXArgs {
     unsigned long long* dbg;
     int M, MT, H, t_index;
     int nkb;                    // K / 16 (the bf16 variant's 32-k blocks need not fill NW x KPW)
-    int nslab;                  // > 0: partial_in is `nslab` K-slice slabs [slice][tile][MT][64][4] (KSliceArgs), summed here
-    // optional second GEMM over the SAME input (fp32, K = 1024): x . W_co + b_co -> partial_out [tile][MT*16][16]
-    const float* wp_co;
-    const float* bias_co;
-    float* partial_out;
 };
 bool gt_lstm_x_supported(int nkb);
 hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, bool bf16, hipStream_t stream);
@@ -257,53 +252,8 @@ struct DecFrontArgs {
     int lean_rec;                   // 0: general body, 1: lean fp32, 2: lean bf16
     int keep_hash;                  // throughput mode at dropout rate 0.5 and the reference's prenet / attention sizes: rows of
                                     // the prenet-1 / query weights that the (hashed) keep decisions zero are not requested
+    int lean_front;                 // 1: the lean utterance path (front_lean.h) where its preconditions hold; 0: the general kernel
 };
-// ---- merged "projection of step t-1 + front end of step t + recurrent halves of step t" launch (dec_front.hip
-// gt_dec_merged_kernel): three launches per decode step instead of four.  fp32, B <= 32, the lean shapes only.
-struct GtGranule { float v; uint32_t tag; };
-
-struct FrontLeanArgs {          // compact argument block of the lean utterance path (front_lean.h)
-    const float *w1, *b1, *wq, *bq, *mask0, *mask1, *pm, *v, *score_bias, *prev, *noise;
-    float *align, *xa;
-    const uint64_t* seed_ptr;
-    const int32_t* tok_len;
-    unsigned long long* dbg;
-    const GtGranule* z0g;       // [rows][P0] prenet-0 pre-activations of this step as {value, tag = step} granules
-    uint32_t* err;              // set to 1 when a wait gives up (a bug, never a normal outcome)
-    int64_t ldprev, ldnoise, ldalign;
-    int MT, B, Tv, mel, P0, P1, type, keep_hash;
-    uint32_t rng_step, tag;
-    float drop_rate, drop_scale, sigmoid_noise;
-};
-
-// Recurrent halves h . W_h (+ b) as K-slice jobs: a job = up to 16 adjacent tiles x one quarter of K, ONE WAVE PER TILE (no
-// cross-wave reduction), the slice's state rows staged once in LDS.  Output: slabs [slice][tile][M-tile][lane][4] in the
-// MFMA accumulator layout (16-byte write-through stores); gt_lstm_x_kernel adds the four slabs.
-struct KSliceArgs {
-    const float* wp[2];         // packed W_h [H/4 tiles][H/16 k-blocks][64][4] of the two decode LSTM layers
-    const float* bias[2];       // [tiles*16], added by slice 0
-    const float* x[2];          // blocked state [H/16][MT][64][4] of the previous step
-    float* out[2];              // [4 slices][tiles][MT][64][4]
-    int ntiles[2];
-    int first_layer;            // jobs cover layers [first_layer, 2)
-    int MT, tiles_per_job, jobs_per_ls, n_jobs;
-    int start_delay;            // the pure workers start this many 100 MHz ticks after the launch (see merged_worker)
-    int proj_helps;             // the projection workgroups take jobs too once they have published their tile
-};
-
-struct DecMergedArgs {
-    int n_proj;                 // blockIdx [0, n_proj): projection workgroups (tile, 16-row M-tile)
-    int B;                      // blockIdx [n_proj, n_proj + B): utterance workgroups
-    int n_workers;              // the rest
-    ProjArgs proj;              // out3 unused: the columns >= col3 go to z0g as granules
-    int proj_nkb;               // K / 16 of the projection (k-blocks [0, nkb_a) from proj.xa, the rest from proj.xb)
-    GtGranule* z0g;
-    FrontLeanArgs front;
-    KSliceArgs work;
-};
-bool gt_dec_merged_supported(int mel, int P0, int P1, int A, int Tv, int B, int nkb_proj, int H1, int H2);
-hipError_t gt_launch_dec_merged(const DecMergedArgs& a, hipStream_t stream);
-
 bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv);
 hipError_t gt_dec_front_init();
 hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t stream);

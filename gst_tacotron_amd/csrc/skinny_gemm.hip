@@ -100,123 +100,39 @@ hipError_t gt_launch_skinny(int epi, const SkinnyArgs& a0, const SkinnyArgs* a1,
 // of hidden unit tile*4+u (Appendix A.6; reference Taco2.py:79-85 via StackedRNNCells).  The 16 columns of a row sit in
 // 16 adjacent lanes, so the lanes with column < 4 collect their unit's four gates with three lane shifts -- no second LDS
 // round trip or barrier.
-// Two GEMM tiles with DIFFERENT weight arrays over ONE pass of the same activations: tile `tile` of wpA (acc*[0]) and of
-// wpB (acc*[1]).  Used by the layer-2 decode LSTM launch, whose input h1_t is also what layer 1's recurrent half of the
-// NEXT step multiplies: the second array rides along for its weights only (no extra activation traffic).
-template <int NW, int KPW>
-__device__ __forceinline__ void gt_lean_core_two(const float* __restrict__ wpA, const float* __restrict__ wpB, const int tile,
-                                                 const float* __restrict__ x, const int MT, const int mchunk, f32x4 (&acc0)[2],
-                                                 f32x4 (&acc1)[2]) {
-    constexpr int NKB = NW * KPW;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mt0 = mchunk * 2, mt1 = min(mt0 + 1, MT - 1);
-    const float4* wa = reinterpret_cast<const float4*>(wpA) + ((size_t)tile * NKB + wave) * 64 + lane;
-    const float4* wb = reinterpret_cast<const float4*>(wpB) + ((size_t)tile * NKB + wave) * 64 + lane;
-    float4 ba[KPW], bb[KPW], x0[KPW], x1[KPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        ba[i] = wa[(size_t)i * NW * 64];
-        const float* xs = x + (size_t)(wave + i * NW) * MT * 256;
-        x0[i] = *reinterpret_cast<const float4*>(xs + mt0 * 256 + lane * 4);
-        x1[i] = *reinterpret_cast<const float4*>(xs + mt1 * 256 + lane * 4);
-    }
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) bb[i] = wb[(size_t)i * NW * 64];        // behind the critical tile's requests
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, ba[i].x, acc0[0], 0, 0, 0);
-        acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, ba[i].x, acc1[0], 0, 0, 0);
-        acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, ba[i].y, acc0[0], 0, 0, 0);
-        acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, ba[i].y, acc1[0], 0, 0, 0);
-        acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, ba[i].z, acc0[0], 0, 0, 0);
-        acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, ba[i].z, acc1[0], 0, 0, 0);
-        acc0[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, ba[i].w, acc0[0], 0, 0, 0);
-        acc1[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, ba[i].w, acc1[0], 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, bb[i].x, acc0[1], 0, 0, 0);
-        acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, bb[i].x, acc1[1], 0, 0, 0);
-        acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, bb[i].y, acc0[1], 0, 0, 0);
-        acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, bb[i].y, acc1[1], 0, 0, 0);
-        acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, bb[i].z, acc0[1], 0, 0, 0);
-        acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, bb[i].z, acc1[1], 0, 0, 0);
-        acc0[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, bb[i].w, acc0[1], 0, 0, 0);
-        acc1[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, bb[i].w, acc1[1], 0, 0, 0);
-    }
-}
-
-// CO: the launch also computes tile `blockIdx.x` of  x . W_co + b_co  (LstmXArgs::wp_co) and writes it as a pre-activation
-// partial [tile][rows][16] -- the NEXT step's recurrent half of the other LSTM layer, whose state is this launch's input.
-template <int NW, int KPW, int TAG, bool BF16, int SLABS = 0, bool CO = false>
+template <int NW, int KPW, int TAG, bool BF16>
 __global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
-    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, CO ? 2 : 1>::kFloats];
+    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 1>::kFloats];
     constexpr int NE = 512 / (NW * 64);
     const int tile = blockIdx.x, mchunk = blockIdx.y;
     const int m0 = mchunk * 32, MT = A.MT;
     GT_STAMP(A.dbg, 4);
     float pin[NE], c_prev[NE];
-    float pslab[NE][SLABS > 0 ? SLABS : 1];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = threadIdx.x + i * NW * 64;
         const int row = e >> 4, col = e & 15;
         const int grow = m0 + row, unit = tile * 4 + col;
-        if (SLABS > 0) {
-            // recurrent half as SLABS K-slice slabs [slice][tile][M-tile][lane][4] in the MFMA accumulator layout (KSliceArgs):
-            // element (row, col) of an M-tile sits at lane (row % 16 / 4) * 16 + col, register row % 4.  A compile-time
-            // count: the loads stay unconditional, so they are not waited for before the weight requests go out.
-            const int gr = min(grow, MT * 16 - 1);
-            const size_t base = (((size_t)tile * MT + (gr >> 4)) * 64 + (((gr & 15) >> 2) * 16 + col)) * 4 + (gr & 3);
-            const size_t stride = (size_t)((A.H + 3) / 4) * MT * 256;
-#pragma unroll
-            for (int sl = 0; sl < SLABS; ++sl) pslab[i][sl] = A.partial_in[(size_t)sl * stride + base];
-            pin[i] = 0.f;
-        } else {
-            pin[i] = (grow < MT * 16) ? A.partial_in[((size_t)tile * MT * 16 + grow) * 16 + col] : 0.f;
-        }
+        pin[i] = (grow < MT * 16) ? A.partial_in[((size_t)tile * MT * 16 + grow) * 16 + col] : 0.f;
         c_prev[i] = (col < 4 && grow < A.M && unit < A.H) ? A.c[(size_t)grow * A.H + unit] : 0.f;
     }
     GT_STAMP(A.dbg, 0);
-    constexpr int NTL = CO ? 2 : 1;
-    f32x4 acc0[NTL], acc1[NTL];
-#pragma unroll
-    for (int j = 0; j < NTL; ++j) { acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    float bias_co = 0.f;
-    if constexpr (CO) {
-        bias_co = A.bias_co[tile * 16 + (threadIdx.x & 15)];
-        gt_lean_core_two<NW, KPW>(A.wp, A.wp_co, tile, A.x, MT, mchunk, acc0, acc1);
-    } else if constexpr (BF16) {
+    f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    if constexpr (BF16) {
         gt_lean_core_bf16<NW, KPW, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, A.nkb}, MT, mchunk, (A.nkb + 1) >> 1, acc0, acc1);
     } else {
         gt_lean_core<NW, KPW, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, NW * KPW}, MT, mchunk, acc0, acc1);
     }
     GT_STAMP(A.dbg, 1);
-    gt_lean_spill<NW, NTL>(lds, acc0, acc1);
+    gt_lean_spill<NW, 1>(lds, acc0, acc1);
     __syncthreads();
     GT_STAMP(A.dbg, 2);
-    const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);     // tile 0 = [NW][32][17]
-    if constexpr (CO) {
-        static_assert(NW * 64 == 512, "one (row, col) element per thread");
-        const float (*pco)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds + NW * 32 * 17);
-        const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
-        float zc = bias_co;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) zc += pco[w][row][col];
-        if (m0 + row < MT * 16) A.partial_out[((size_t)tile * MT * 16 + m0 + row) * 16 + col] = zc;
-    }
+    const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);     // [NW][32][17]
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = threadIdx.x + i * NW * 64;
         const int row = e >> 4, col = e & 15;
         float z = pin[i];
-        if (SLABS > 0) {
-#pragma unroll
-            for (int sl = 0; sl < SLABS; ++sl) z += pslab[i][sl];
-        }
 #pragma unroll
         for (int w = 0; w < NW; ++w) z += part[w][row][col];
         const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
@@ -294,8 +210,7 @@ bool gt_lstm_x_supported(int nkb) { return nkb == 24 || nkb == 64; }
 
 template <int TAG>
 static void launch_lstm_x(const LstmXArgs& a, int nkb, bool bf16, hipStream_t stream) {
-    const dim3 grid((a.H + 3) / 4, (a.M + 31) / 32);
-    if (a.M > 32 && a.nslab == 0 && !a.wp_co) {         // weights read once per step at any batch
+    if (a.M > 32) {         // weights read once per step at any batch
         const dim3 g1((((a.H + 3) / 4 + 1) / 2 + 7) / 8 * 16);      // pairs of tiles (rounded up to 8) x 2 halves of the chunks
         if (nkb == 24) {
             if (bf16) hipLaunchKernelGGL((gt_lstm_x_mc_kernel<8, 2, TAG, true>), g1, dim3(512), 0, stream, a);
@@ -306,23 +221,19 @@ static void launch_lstm_x(const LstmXArgs& a, int nkb, bool bf16, hipStream_t st
         }
         return;
     }
+    const dim3 grid((a.H + 3) / 4, 1);
     if (nkb == 24) {
         // K = 384 on 8 waves x 3 k-blocks (4 x 6 left the reduce + gate epilogue to 256 threads: 2.4 -> 1.7 us in-kernel)
         if (bf16) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 2, TAG, true>), grid, dim3(512), 0, stream, a);
-        else if (a.nslab == 4) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 3, TAG, false, 4>), grid, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((gt_lstm_x_kernel<8, 3, TAG, false>), grid, dim3(512), 0, stream, a);
     } else {
         if (bf16) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 4, TAG, true>), grid, dim3(512), 0, stream, a);
-        else if (a.nslab == 4 && a.wp_co) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG, false, 4, true>), grid, dim3(512), 0, stream, a);
-        else if (a.wp_co) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG, false, 0, true>), grid, dim3(512), 0, stream, a);
-        else if (a.nslab == 4) hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG, false, 4>), grid, dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((gt_lstm_x_kernel<8, 8, TAG, false>), grid, dim3(512), 0, stream, a);
     }
 }
 
 hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, bool bf16, hipStream_t stream) {
-    if (!gt_lstm_x_supported(nkb) || (a.nslab != 0 && (a.nslab != 4 || bf16))) return hipErrorInvalidValue;
-    if (a.wp_co && (bf16 || nkb != 64)) return hipErrorInvalidValue;
+    if (!gt_lstm_x_supported(nkb)) return hipErrorInvalidValue;
     if (tag == TAG_DEC_LSTM1) launch_lstm_x<TAG_DEC_LSTM1>(a, nkb, bf16, stream);
     else launch_lstm_x<TAG_DEC_LSTM2>(a, nkb, bf16, stream);
     return hipGetLastError();

@@ -200,8 +200,7 @@ def test_winograd_postnet_matches_the_oracle_and_the_implicit_gemm(monkeypatch):
     for B, T in ((8, 1024), (9, 999), (16, 1022)):
         x = np.clip(np.random.default_rng(T).normal(0, 1.5, (B, T, 80)), -4, 4).astype(np.float32)
         outs = {}
-        for name, env in (("F(4,5)|F(2,5)", {"GSTTACO_WINO": "1", "GSTTACO_WINO4": "1"}), ("F(2,5)", {"GSTTACO_WINO": "1", "GSTTACO_WINO4": "0"}),
-                          ("implicit GEMM", {"GSTTACO_WINO": "0"})):
+        for name, env in (("F(4,5)|F(2,5)", {"GSTTACO_WINO": "4"}), ("F(2,5)", {"GSTTACO_WINO": "2"}), ("implicit GEMM", {"GSTTACO_WINO": "0"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             hpv = dict(hp); hpv["Max_Step"] = 1024

@@ -149,7 +149,7 @@ def test_eager_graph_and_unfused_paths_agree(monkeypatch):
     import torch
     hp, w, tokens, tl, mels, ml, masks, noise = _full_case(4, 33, 90, 8, seed=5)
     outs = []
-    for env in ({}, {"GSTTACO_GRAPH": "0"}, {"GSTTACO_FUSED_FRONT": "0"}):
+    for env in ({}, {"GSTTACO_GRAPH": "0"}, {"GSTTACO_FUSED_FRONT": "0"}):      # (FUSED_FRONT: 0 = four kernels, 1 = general fused, 2 = lean)
         for k in ("GSTTACO_GRAPH", "GSTTACO_FUSED_FRONT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -162,16 +162,12 @@ def test_eager_graph_and_unfused_paths_agree(monkeypatch):
     assert np.abs(outs[0][0] - outs[2][0]).max() <= TOL and np.abs(outs[0][1] - outs[2][1]).max() <= TOL
 
 
-@pytest.mark.parametrize("env", [{"GSTTACO_FRONT_LEAN": "0"}, {"GSTTACO_MERGED": "1"}, {"GSTTACO_MERGED": "1", "GSTTACO_CO_LSTM2": "1"},
-                                 {"GSTTACO_MERGED": "1", "GSTTACO_PROJ_HELPS": "0", "GSTTACO_WORKER_DELAY": "0"}])
+@pytest.mark.parametrize("env", [{"GSTTACO_FUSED_FRONT": "1"}, {"GSTTACO_FUSED_FRONT": "2"}])
 @pytest.mark.parametrize("att", ["SMA", "BMA"])
 def test_front_end_variants_match_oracle(monkeypatch, env, att):
-    """The decode step exists in variants that must all be the same function: the general fused front kernel vs the lean one
-    (front_lean.h, buffer loads with counted waits; the default), and the experimental three-launch step (GSTTACO_MERGED=1:
-    projection of step t-1 + front end of step t + recurrent halves in ONE launch, prenet-0 pre-activations handed over as
-    tagged granules; optionally layer 1's recurrent half fused into the layer-2 LSTM launch).  Each against the float64
-    oracle over 40 steps at full dimensions, injected and hashed (throughput-mode) dropout, 5 and 32 utterances; and the
-    hand-off's give-up flag must stay clear."""
+    """The fused front kernel exists as the general kernel (GSTTACO_FUSED_FRONT=1) and with the lean utterance path
+    (front_lean.h, buffer loads with counted waits; 2 = the default): the same function.  Each against the float64 oracle over
+    40 steps at full dimensions, injected and hashed (throughput-mode) dropout, 5 and 32 utterances."""
     import torch
     from oracle import oracle_np
     for k, v in env.items():
@@ -195,7 +191,6 @@ def test_front_end_variants_match_oracle(monkeypatch, env, att):
                                         steps=steps, dt=np.float64)
         assert np.abs(mel2.cpu().numpy() - ref2[0]).max() <= TOL
         assert np.abs(align2.cpu().numpy() - ref2[3]).max() <= TOL
-        assert m.handoff_error() == 0
 
 
 @pytest.mark.parametrize("mixed,B", [(False, 5), (True, 5), (False, 37), (True, 37), (False, 65), (True, 65), (False, 128), (True, 128)])
@@ -245,20 +240,21 @@ def test_throughput_mode_randomness_matches_oracle(att, rate, monkeypatch):
     """Throughput mode (nothing injected): the prenet keep decisions and the SMA noise come from the seed on the device.  The
     front kernel derives the decisions itself (a counter hash at rate 0.5, Philox otherwise) and -- at rate 0.5 and the
     reference's sizes -- never requests the prenet-1 / query weight rows they zero.  The tensors it used are read back
-    (gsttaco_debug_randomness) and fed to the oracle: same mels, and the same result with the row skipping switched off."""
+    (gsttaco_debug_randomness) and fed to the oracle: same mels; and the four-kernel front end (GSTTACO_FUSED_FRONT=0), which reads
+    the pre-generated masks from HBM and skips nothing, uses the same tensors and gives the same result."""
     import torch
     from oracle import oracle_np
     B, Tv, Tref, steps = 3, 24, 70, 9
     hp, w, tokens, tl, mels, ml, _, _ = _full_case(B, Tv, Tref, steps, seed=31, att=att, rate=rate)
     outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("GSTTACO_KEEP_HASH", flag)
+    for flag in ("2", "0"):
+        monkeypatch.setenv("GSTTACO_FUSED_FRONT", flag)
         m = _model(hp, w, B, Tv, Tref + 1)
         mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, seed=1234, steps=steps)
         torch.cuda.synchronize()
         masks, noise = m.debug_randomness(steps, B, Tv)
         outs.append((mel.cpu().numpy(), align.cpu().numpy(), masks, noise))
-    monkeypatch.delenv("GSTTACO_KEEP_HASH")
+    monkeypatch.delenv("GSTTACO_FUSED_FRONT")
     mel, align, masks, noise = outs[0]
     assert set(np.unique(masks)) <= {0.0, 1.0} and abs(masks.mean() - (1.0 - rate)) < 0.03
     from gst_tacotron_amd import hparams
