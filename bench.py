@@ -32,6 +32,7 @@ from gst_tacotron_amd import synthetic, weights  # noqa: E402
 from gst_tacotron_amd.model import GST_Tacotron  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}      # dense MFMA peaks (same guide; fp32-input MFMA = 1/16 of bf16)
 BATCH_PER_GPU = 32
 PROFILE_EVERY = 20             # bracket every 20th decode step's LSTM launches with HIP events
 
@@ -97,21 +98,26 @@ def cpu_baseline(hp, w, inputs, budget_s=15.0, runs=5):
 
     cpu = host_cpu_info()
     ncpu = os.cpu_count() or 1
-    best = None
-    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
+    # The whole protocol at BOTH candidate thread counts (eager per-op dispatch does not scale to every core, and which of
+    # 16 / 32 wins differs from box to box and from run to run: a single calibration used to move the quoted GPU / CPU ratio by
+    # 1.5x).  `value` is the better median; both are reported.
+    per_thread = {}
+    for nt in sorted({min(ncpu, n) for n in (16, 32)}):
         torch.set_num_threads(nt)
         run(1)
         t1 = min(run(1), run(1))
         t9 = min(run(9), run(9))
         per_step = max((t9 - t1) / 8.0, 1e-4)
-        if best is None or per_step < best[1]:
-            best = (nt, per_step, t1)
-    nt, per_step, t_fixed = best
-    torch.set_num_threads(nt)
-    per_run = budget_s / runs
-    steps_sample = int(max(10, min(total_steps, (per_run - t_fixed) / per_step)))
-    run(steps_sample)                                                   # warm-up
-    times = [run(steps_sample) for _ in range(runs)]
+        per_run = budget_s / (2 * runs)
+        steps_sample = int(max(10, min(total_steps, (per_run - t1) / per_step)))
+        run(steps_sample)                                                   # warm-up
+        times = [run(steps_sample) for _ in range(runs)]
+        frames = B * steps_sample * d_r
+        per_thread[nt] = {"value": frames / _median(times), "value_best_run": frames / min(times), "decode_steps": steps_sample,
+                          "run_seconds": [round(t, 3) for t in times]}
+    nt = max(per_thread, key=lambda k: per_thread[k]["value"])
+    steps_sample = per_thread[nt]["decode_steps"]
+    times = per_thread[nt]["run_seconds"]
     frames = B * steps_sample * d_r
     med, mn = _median(times), min(times)
 
@@ -141,9 +147,10 @@ def cpu_baseline(hp, w, inputs, budget_s=15.0, runs=5):
     torch.set_num_threads(nt)
     return {"value": frames / med, "unit": "mel-frames/s", "cores": nt, "kind": "port",
             "value_best_run": frames / mn, "runs": runs, "run_seconds": [round(t, 3) for t in times],
+            "by_threads": {str(k): v for k, v in per_thread.items()},
             "cpu_model": cpu["model"], "host_logical_cpus": cpu["logical_cpus"], "host_physical_cores": cpu["physical_cores"],
             "sample": "configs[1] batch {} x {} tokens: encoder+GST once, {} of {} decode steps, postnet on those {} frames; "
-                      "median of {} runs after 1 warm-up, {:.2f} s per run on {} threads (fastest of 8/16/32/64) of {}; "
+                      "median of {} runs after 1 warm-up, {:.2f} s per run on {} threads (the better of 16 and 32, both in by_threads) of {}; "
                       "torch-CPU eager restatement of the TF2 graph (TF not installable)".format(
                           B, Tv, steps_sample, total_steps, steps_sample * d_r, runs, med, nt, cpu["model"]),
             "configs0": {"value": frames0 / _median(times0), "value_best_run": frames0 / min(times0), "unit": "mel-frames/s",
@@ -225,7 +232,7 @@ def main():
                     "configs[4]); NOT the headline metric -- dtype is then reported as bf16")
     ap.add_argument("--batch-per-gpu", type=int, default=BATCH_PER_GPU, help="utterances per GPU (default 32 = the headline "
                     "configuration; BASELINE configs[4] uses 64 with --mixed).  Any other value is NOT the headline metric")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall-time budget of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="wall-time budget of the bounded CPU-baseline sample (both thread counts)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -309,10 +316,14 @@ def main():
 
     # per-kernel timing of the decode step: HIP event-record nodes inside the replayed graph (on the stream the
     # kernels run on), every PROFILE_EVERY-th decode step of the last timed replay
-    KNAMES = {0: "gt_lstm_x_kernel<8,3> LSTM layer 1 (input half + gates)", 1: "gt_lstm_x_kernel<8,8> LSTM layer 2 (input half + gates)",
+    big = B > 32            # batches above 32 rows run the multi-chunk kernels (weights resident over the chunks)
+    lx = "gt_lstm_x_mc_kernel" if big else "gt_lstm_x_kernel"
+    pj = "gt_proj_mc_kernel" if big else "gt_proj_lean_kernel"
+    k1, k2 = ("2", "4") if args.mixed else ("3", "8")
+    KNAMES = {0: lx + "<8," + k1 + "> LSTM layer 1 (input half + gates)", 1: lx + "<8," + k2 + "> LSTM layer 2 (input half + gates)",
               2: "gt_dec_front_lean_kernel (prenet + query + attention per utterance; workers: recurrent halves W_h.h+b)",
-              3: "gt_proj_lean_kernel (projection + next prenet-0; workers: layer-2 recurrent half)"}
-    KPMC = {0: "gt_lstm_x_kernel<8, 3, 1", 1: "gt_lstm_x_kernel<8, 8, 2", 2: "gt_dec_front_lean_kernel<8, 4, 1", 3: "gt_proj_lean_kernel"}
+              3: pj + " (projection + next prenet-0; workers: layer-2 recurrent half)"}
+    KPMC = {0: lx + "<8, " + k1 + ", 1", 1: lx + "<8, " + k2 + ", 2", 2: "gt_dec_front_lean_kernel<8, 4, " + ("2" if args.mixed else "1"), 3: pj}
     prof = {}
     for which in range(4):
         ms, cnt = ctypes.c_float(), ctypes.c_int()
@@ -325,6 +336,32 @@ def main():
     model.ctx.check(lib.gsttaco_get_profile(handle, 4, ctypes.byref(ms), ctypes.byref(cnt)))
     bracket_ms = ms.value
 
+    # the postnet alone (its own C-ABI entry point on this stream), timed with events after the clock has stopped: its
+    # direct-equivalent FLOP rate against the MFMA peak of the precision it runs in
+    post = None
+    if rank == 0:
+        d = model.dims
+        pre = torch.randn((B, d.steps * d.r, d.mel), device=dev).clamp_(-4, 4)
+        model.postnet(pre)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            model.postnet(pre)
+        e1.record()
+        torch.cuda.synchronize()
+        post_ms = e0.elapsed_time(e1) / 5
+        cin, fl = d.mel, 0
+        for f, kk in zip(d.post_filters, d.post_kernels):           # Taco2.py:131-149
+            fl += 2 * B * d.steps * d.r * kk * cin * f
+            cin = f
+        peak = MFMA_PEAK_TFLOPS["bf16" if args.mixed else "f32"]
+        post = {"ms": post_ms, "direct_equivalent_flop": fl, "TFLOP/s": fl / (post_ms * 1e-3) / 1e12, "peak_TFLOP/s": peak,
+                "frac": fl / (post_ms * 1e-3) / 1e12 / peak,
+                "note": "5 Conv1D(k=5) layers as Winograd F(4,5)/F(2,5) (0.4x / 0.6x the multiplications of the direct form) in fp32, "
+                        "implicit GEMM on bf16 MFMA under --mixed; FLOP counted for the DIRECT form, so the fraction can exceed the "
+                        "share of issued MFMAs"}
+
     if rank == 0:
         assert out is not None and tuple(out.shape) == (n_total, model.dims.steps * model.dims.r, model.dims.mel)
         assert bool(torch.isfinite(out).all())
@@ -336,6 +373,15 @@ def main():
         rp_us, rp_src = rocprof_avg_us(KPMC[dom])
         step_us = sum(v[0] for v in prof.values()) * 1e3
         step_bytes = sum(v[2] for v in prof.values())
+        # the decode step's GEMM work (prenet-1, query, both LSTM cells, projection + fused prenet-0): what bounds it at batches
+        # above 32 rows, where fp32 MFMA time overtakes the weight stream
+        dd = model.dims
+        P0, P1, A_ = dd.prenet[0], dd.prenet[1], dd.att
+        H1, H2 = dd.dec_rnn[0], dd.dec_rnn[1]
+        step_flop = 2 * B * (P0 * P1 + P1 * A_ + (P1 + A_ + H1) * 4 * H1 + (H1 + H2) * 4 * H2 + (H2 + A_) * (dd.mel * dd.r + 1 + P0))
+        mfma_peak = MFMA_PEAK_TFLOPS["bf16" if args.mixed else "f32"]
+        step_frac_hbm = (step_bytes / step_us / 1e3) / HBM_PEAK_GBS if step_us > 0 else 0.0
+        step_frac_mfma = (step_flop / (step_us * 1e-6) / 1e12) / mfma_peak if step_us > 0 else 0.0
         line = {
             "metric": "mel-frames/s", "value": frames / elapsed, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -360,8 +406,16 @@ def main():
                          "bytes_per_launch": bytes1,
                          "avg_launch_us": ms1 * 1e3, "launches_timed": cnt1, "empty_event_bracket_us": bracket_ms * 1e3,
                          "avg_launch_us_rocprofv3": rp_us, "rocprofv3_source": rp_src,
+                         "step_frac": max(step_frac_hbm, step_frac_mfma),
+                         "step_bound": "mfma" if step_frac_mfma > step_frac_hbm else "hbm",
+                         "step_frac_note": "whole decode step (4 launches; x 500 = 88 % of the run): algorithmic bytes / sum of the bracketed "
+                                           "launch times / 8 TB/s, or GEMM FLOP / the same time / the dense MFMA peak of the compute "
+                                           "dtype, whichever is larger (fp32 MFMA overtakes the weight stream above 32 rows)",
+                         "postnet": post,
                          "decode_step": {"us": step_us, "algorithmic_bytes": step_bytes,
                                          "GB/s": step_bytes / step_us / 1e3 if step_us > 0 else 0.0,
+                                         "frac_hbm": step_frac_hbm, "gemm_flop": step_flop,
+                                         "TFLOP/s": step_flop / (step_us * 1e-6) / 1e12 if step_us > 0 else 0.0, "frac_mfma": step_frac_mfma,
                                          "kernels": {str(k): {"name": KNAMES[k], "avg_us": prof[k][0] * 1e3, "bytes": prof[k][2]}
                                                      for k in prof}}},
         }
