@@ -25,9 +25,78 @@ def inv_preemphasis(x, coef=0.97):
 
 
 # ----------------------------------------------------------------------------------------- librosa.core.load
-def load_wav(path, sample_rate):
+# librosa.core.load(path, sr) resamples a file at another rate with librosa.core.resample(res_type='kaiser_best'), i.e.
+# resampy.resample(y, sr_orig, sr, filter='kaiser_best') followed by util.fix_length(., ceil(n * ratio)) (librosa 0.7.2
+# core/audio.py).  resampy (0.2.x; an un-vendored dependency of librosa, absent here like librosa itself) is band-limited
+# sinc interpolation (J. O. Smith, "Digital Audio Resampling Home Page") with a pre-computed, linearly interpolated filter
+# table.  Its published 'kaiser_best' design: 64 zero crossings, 2^9 table entries per crossing, Kaiser window beta =
+# 14.769656459379492, roll-off 0.9475937167399596 (resampy/filters.py sinc_window + the parameters resampy documents for
+# kaiser_best).  PARITY UNPINNED like the rest of this module: restated from the published algorithm, never run against
+# resampy itself.
+KAISER_BEST = {"num_zeros": 64, "precision": 9, "beta": 14.769656459379492, "rolloff": 0.9475937167399596}
+
+
+def kaiser_best_filter():
+    """resampy.filters.sinc_window(num_zeros, precision, window=kaiser(beta), rolloff): the right half of the windowed sinc,
+    float64, 64 * 512 + 1 entries.  Returns (interp_win, num_table = 2^precision)."""
+    nz, bits = KAISER_BEST["num_zeros"], 2 ** KAISER_BEST["precision"]
+    n = bits * nz
+    sinc_win = KAISER_BEST["rolloff"] * np.sinc(KAISER_BEST["rolloff"] * np.linspace(0, nz, num=n + 1, endpoint=True))
+    taper = signal.windows.kaiser(2 * n + 1, KAISER_BEST["beta"])[n:]
+    return taper * sinc_win, bits
+
+
+def resample_kaiser_best(x, sr_orig, sr_new, t_begin=0, t_end=None):
+    """resampy.resample(x, sr_orig, sr_new, filter='kaiser_best') restated loop for loop (resampy/core.py + interpn.py
+    resample_f): output samples [t_begin, t_end) of the int(len(x) * ratio) it produces.  The output array has x's dtype
+    and every `y[t] += weight * x[.]` rounds to it (float32 here), which is reproduced."""
+    x = np.asarray(x)
+    ratio = float(sr_new) / float(sr_orig)
+    n_out = int(x.shape[0] * ratio)
+    t_end = n_out if t_end is None else min(t_end, n_out)
+    interp_win, num_table = kaiser_best_filter()
+    if ratio < 1:
+        interp_win = interp_win * ratio
+    interp_delta = np.zeros_like(interp_win)
+    interp_delta[:-1] = np.diff(interp_win)
+    scale = min(1.0, ratio)
+    time_increment = 1.0 / ratio
+    index_step = int(scale * num_table)
+    nwin, n_orig = interp_win.shape[0], x.shape[0]
+    y = np.zeros(t_end - t_begin, dtype=x.dtype)
+    time_register = 0.0
+    for t in range(t_end):
+        if t >= t_begin:
+            n = int(time_register)
+            frac = scale * (time_register - n)
+            index_frac = frac * num_table
+            offset = int(index_frac)
+            eta = index_frac - offset
+            acc = x.dtype.type(0)
+            for i in range(min(n + 1, (nwin - offset) // index_step)):           # left wing
+                weight = interp_win[offset + i * index_step] + eta * interp_delta[offset + i * index_step]
+                acc = x.dtype.type(acc + weight * x[n - i])
+            frac = scale - frac
+            index_frac = frac * num_table
+            offset = int(index_frac)
+            eta = index_frac - offset
+            for k in range(min(n_orig - n - 1, (nwin - offset) // index_step)):  # right wing
+                weight = interp_win[offset + k * index_step] + eta * interp_delta[offset + k * index_step]
+                acc = x.dtype.type(acc + weight * x[n + k + 1])
+            y[t - t_begin] = acc
+        time_register += time_increment          # (accumulated, as resampy does: not t * increment)
+    return y
+
+
+def fix_length(y, n):
+    """librosa.util.fix_length: crop or zero-pad to n samples."""
+    return y[:n] if y.shape[0] >= n else np.pad(y, (0, n - y.shape[0]))
+
+
+def load_wav(path, sample_rate, max_out=None):
     """librosa.core.load(path, sr) for PCM wav files (Pattern_Generator.py:40-43): float32 in [-1, 1) = int / 2^(bits-1),
-    channel mean.  Resampling (librosa 'kaiser_best' = resampy) is NOT restated: a different file rate raises."""
+    channel mean, and for a file at another rate resample(res_type='kaiser_best') + fix_length(ceil(n * ratio)).
+    (`max_out` bounds the resampled part for tests: the restatement is a Python loop.)"""
     from scipy.io import wavfile
     sr, data = wavfile.read(path)
     if data.dtype == np.int16:
@@ -41,7 +110,10 @@ def load_wav(path, sample_rate):
     if y.ndim > 1:
         y = y.mean(axis=1)
     if sr != sample_rate:
-        raise NotImplementedError("wav is {} Hz, Sound.Sample_Rate is {}: resampling is not restated".format(sr, sample_rate))
+        n = int(np.ceil(y.shape[0] * float(sample_rate) / sr))
+        y = resample_kaiser_best(y, sr, sample_rate, 0, max_out)
+        if max_out is None:
+            y = fix_length(y, n)
     return y
 
 

@@ -175,7 +175,32 @@ def test_load_wav_matches_librosa_load_conventions(tmp_path):
     wavfile.write(p, 16000, np.stack([pcm, -pcm], 1))       # stereo -> channel mean
     assert np.abs(load_wav(p, 16000)).max() == 0.0
     wavfile.write(p, 8000, pcm)                              # other rate: resampled to Sound.Sample_Rate
-    assert abs(load_wav(p, 16000).shape[0] - 8000) <= 1
+    y2 = load_wav(p, 16000)
+    assert y2.dtype == np.float32 and y2.shape[0] == 8000      # fix_length(ceil(n * ratio))
+    np.testing.assert_allclose(y2[:600], A.load_wav(p, 16000, max_out=600), atol=2e-7, rtol=0)
+
+
+def test_kaiser_best_resampling_of_the_22khz_reference_wav():
+    """librosa.core.load resamples a file at another rate with resampy's 'kaiser_best' (Pattern_Generator.py:40-43; the
+    reference's LJ wav, Inference_Wav_for_Training.txt:8, is 22.05 kHz).  The product's vectorised restatement
+    (gst_tacotron_amd/audio.py) against the fixture the oracle's loop-for-loop restatement produced, and the oracle's loop
+    itself on a slice of it; the filter's published design numbers; a pure tone comes out as the same tone."""
+    from gst_tacotron_amd.audio import resample_kaiser_best
+    g = np.load(os.path.join(GOLD, "audio_lj_excerpt.npz"))
+    x = g["pcm"].astype(np.float32) / 32768.0
+    y = resample_kaiser_best(x, int(g["sample_rate"]), int(g["target_rate"]))
+    assert y.dtype == np.float32 and y.shape == g["resampled"].shape == (24000,)
+    np.testing.assert_allclose(y, g["resampled"], atol=1e-6, rtol=0)        # float64 sums vs resampy's per-tap float32 rounding
+    sl = A.resample_kaiser_best(x, int(g["sample_rate"]), int(g["target_rate"]), 11000, 11400)
+    assert np.array_equal(sl, g["resampled"][11000:11400])
+    win, bits = A.kaiser_best_filter()
+    assert bits == 512 and win.shape == (64 * 512 + 1,) and abs(win[0] - A.KAISER_BEST["rolloff"]) < 1e-12 and abs(win[-1]) < 1e-9
+    t = np.arange(22050) / 22050.0
+    tone = resample_kaiser_best((0.5 * np.sin(2 * np.pi * 3000.0 * t)).astype(np.float32), 22050, 16000)
+    ref = 0.5 * np.sin(2 * np.pi * 3000.0 * np.arange(tone.shape[0]) / 16000.0)
+    assert np.abs(tone - ref)[1000:-1000].max() < 2e-3
+    above = resample_kaiser_best((0.5 * np.sin(2 * np.pi * 9000.0 * t)).astype(np.float32), 22050, 16000)   # beyond the new Nyquist
+    assert np.abs(above)[1000:-1000].max() < 2e-3
 
 
 # ------------------------------------------------------------------------------------------------ GPU
