@@ -194,7 +194,7 @@ def test_kaiser_best_resampling_of_the_22khz_reference_wav():
     sl = A.resample_kaiser_best(x, int(g["sample_rate"]), int(g["target_rate"]), 11000, 11400)
     assert np.array_equal(sl, g["resampled"][11000:11400])
     win, bits = A.kaiser_best_filter()
-    assert bits == 512 and win.shape == (64 * 512 + 1,) and abs(win[0] - A.KAISER_BEST["rolloff"]) < 1e-12 and abs(win[-1]) < 1e-9
+    assert bits == 512 and win.shape == (64 * 512 + 1,) and abs(win[0] - A.KAISER_BEST["rolloff"]) < 1e-12 and abs(win[-1]) < 1e-7
     t = np.arange(22050) / 22050.0
     tone = resample_kaiser_best((0.5 * np.sin(2 * np.pi * 3000.0 * t)).astype(np.float32), 22050, 16000)
     ref = 0.5 * np.sin(2 * np.pi * 3000.0 * np.arange(tone.shape[0]) / 16000.0)
