@@ -98,6 +98,36 @@ __device__ __forceinline__ float gt_drop_keep(uint64_t seed, uint32_t step, uint
     return (gt_u01(gt_philox(seed, row * ncols + col, step, 0u, GT_RNG_PRENET0 + layer).x) > rate) ? 1.f : 0.f;
 }
 
+// ---- raw buffer loads (unconditional, bounds-checked by the descriptor; see front_lean.h for why the decode loop uses them)
+#define GT_OOB 0x80000000u      // voffset beyond any descriptor's num_records: the load returns 0 and accesses nothing
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gt_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float gt_bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff) {
+    const unsigned int t = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0);
+    return __builtin_bit_cast(float, t);
+}
+__device__ __forceinline__ float4 gt_bload4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    // (NOT __builtin_bit_cast(float, t[i]): on a vector ELEMENT clang 20 reads element 0 for every i)
+    const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+    float4 r;
+    __builtin_memcpy(&r, &t, 16);
+    return r;
+}
+
+// 16-byte load with the sc1 (agent-scope, L2-bypassing) cache policy, tracked by the compiler's wait counting (cpol bit 4 = sc1
+// on gfx940+).  For activations another XCD has just written: measured with tools/persist_phase.hip, a 256-workgroup launch in
+// which every workgroup reads the same 128 KB the previous launch wrote is 0.6 us shorter with sc1 loads than with plain ones
+// (6.29 vs 6.88 us) -- 32 CUs of an XCD missing the same fresh lines serialise in that XCD's L2; bypassing it, each request goes
+// to the Infinity Cache on its own.
+__device__ __forceinline__ float4 gt_bload4_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 16);
+    float4 r;
+    __builtin_memcpy(&r, &t, 16);
+    return r;
+}
+
 // diagnostic: phase stamp (constant 100 MHz counter) written by thread 0 of block 0 when dbg != NULL
 #define GT_STAMP(dbg, slot)                                                                    \
     do {                                                                                       \

@@ -13,23 +13,6 @@
 // the hardware returns zero without touching memory.  Loads are counted exactly, waits are `vmcnt(N)`, nothing is copied.
 #pragma once
 
-#define GT_OOB 0x80000000u      // voffset beyond any descriptor's num_records: the load returns 0 and accesses nothing
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t gt_rsrc(const void* p, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float gt_bload1(__amdgpu_buffer_rsrc_t rs, uint32_t voff) {
-    const unsigned int t = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0);
-    return __builtin_bit_cast(float, t);
-}
-__device__ __forceinline__ float4 gt_bload4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
-    // (NOT __builtin_bit_cast(float, t[i]): on a vector ELEMENT clang 20 reads element 0 for every i)
-    const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
-    float4 r;
-    __builtin_memcpy(&r, &t, 16);
-    return r;
-}
-
 #define GT_LSTAMP(slot)                                                                         \
     do {                                                                                        \
         if (P.dbg && stamp_wg && threadIdx.x == 0) P.dbg[slot] = __builtin_amdgcn_s_memrealtime(); \

@@ -580,8 +580,10 @@ int record_event(gsttaco_ctx* c, hipEvent_t ev, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------ lean BiLSTM
 // x_t . W_x + b of both directions for all time steps in one GEMM, output columns already in the recurrent kernel's tile
 // order (direction d, tile, gate*4 + unit%4), and recurrent-only packs for gt_bilstm_lean_kernel.
+// Under Use_Mixed_Precision the hoisted GEMM runs on the bf16 conv-GEMM path and the recurrent packs are bf16: only the persistent
+// kernel has that variant, so the lean form is then used exactly when the persistent launch is (lean_bilstm_usable).
 int build_lean_bilstm(gsttaco_ctx* c, gsttaco_ctx::LeanBiLstm* L, const std::string& prefix, int H) {
-    if (!c->lean || c->cfg.mixed_precision || H % 16 || !gt_bilstm_lean_supported(H / 16)) return 0;
+    if (!c->lean || H % 16 || !gt_bilstm_lean_supported(H / 16)) return 0;
     const int C = (int)T(c, prefix + ".fwd.kernel").shape[0];
     std::vector<float> xw((size_t)C * 8 * H), xb((size_t)8 * H);
     int d = 0, rc = 0;
@@ -594,10 +596,11 @@ int build_lean_bilstm(gsttaco_ctx* c, gsttaco_ctx::LeanBiLstm* L, const std::str
                 xb[dst] = b.data[src];
                 for (int kk = 0; kk < C; ++kk) xw[(size_t)kk * 8 * H + dst] = k.data[(size_t)kk * 4 * H + src];
             }
-        if ((rc = pack_linear(c, &L->h[d], {{u.data.data(), (int)u.shape[0]}}, 4 * H, nullptr, H, false))) return rc;
+        if ((rc = pack_linear(c, &L->h[d], {{u.data.data(), (int)u.shape[0]}}, 4 * H, nullptr, H, c->cfg.mixed_precision != 0))) return rc;
         ++d;
     }
     if ((rc = upload(c, &L->xw, xw.data(), xw.size()))) return rc;
+    if ((rc = add_bf16(c, L->xw, xw.data(), C, 8 * H, 8 * H))) return rc;
     if ((rc = upload(c, &L->xb, xb.data(), xb.size()))) return rc;
     L->H = H; L->C = C;
     return 0;
@@ -615,6 +618,12 @@ int alloc_lean_bilstm(gsttaco_ctx* c, gsttaco_ctx::LeanBiLstm* L, size_t B, size
         if ((rc = dev_alloc(c, (void**)&L->pflags, (size_t)(8 * 2 * 32 + 8) * sizeof(uint32_t)))) return rc;
     }
     return 0;
+}
+
+bool lean_bilstm_usable(const gsttaco_ctx* c, const gsttaco_ctx::LeanBiLstm& L, int B) {
+    if (!L.xw) return false;
+    if (!c->cfg.mixed_precision) return true;
+    return L.ph && c->bilstm_persist && gt_bilstm_persist_supported(L.H, std::min(B, 64), c->n_cu);
 }
 
 // x: [B*T, C] rows; cstate: [2, B, H] (zeroed by the caller); out: [B, T, 2H]
@@ -641,7 +650,7 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
             k.row_len = row_len ? row_len + r0 : nullptr; k.err = c->w_err + 1;
             k.M = Bs; k.MT = (Bs + 15) / 16; k.H = H; k.T = Tn;
             k.debug_drop_member = c->debug_drop_member;
-            HIPCHECK(c, gt_launch_bilstm_persist(k, s));
+            HIPCHECK(c, gt_launch_bilstm_persist(k, L.h[0].bf16 != 0, s));
             ++c->n_persist_enqueued;
         }
         return 0;
@@ -683,7 +692,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked) {
     // BiLSTM: one launch per time step, both directions in grid.z; h is written straight into enc_out.
     const int H = g.enc_rnn, C = c->conv_c, EO = c->enc_out;
     HIPCHECK(c, gt_launch_zero(c->w_cenc, (size_t)2 * B * H, s));
-    if (c->enc_lean.xw) return enqueue_lean_bilstm(c, s, c->enc_lean, x, B, Tv, c->w_cenc, c->w_enc, tlen);
+    if (lean_bilstm_usable(c, c->enc_lean, B)) return enqueue_lean_bilstm(c, s, c->enc_lean, x, B, Tv, c->w_cenc, c->w_enc, tlen);
     for (int t = 0; t < Tv; ++t) {
         SkinnyArgs a[2];
         for (int d = 0; d < 2; ++d) {
@@ -1221,7 +1230,7 @@ int enqueue_vocoder(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* m
     // Bidirectional LSTM over the Tf frames: one launch per time step, both directions in grid.z (:353-361)
     const int H = g.voc_rnn, EO = 2 * H;
     HIPCHECK(c, gt_launch_zero(c->w_vc, (size_t)2 * B * H, s));
-    if (c->voc_lean.xw) {
+    if (lean_bilstm_usable(c, c->voc_lean, B)) {
         int rl = enqueue_lean_bilstm(c, s, c->voc_lean, x, B, Tf, c->w_vc, c->w_vrnn, nullptr);
         if (rl) return rl;
     } else

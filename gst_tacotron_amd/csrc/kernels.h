@@ -112,7 +112,7 @@ bool gt_bilstm_lean_supported(int nkb_h);
 // Persistent BiLSTM: every time step of both directions in one launch (skinny_gemm.hip gt_bilstm_persist_kernel).
 // Group g = direction + 2 * M-tile lives on XCD g.
 struct BiLstmPersistArgs {
-    const float* wp[2];         // packed W_h per direction [H/4 tiles][H/16][64][4]
+    const float* wp[2];         // packed W_h per direction [H/4 tiles][H/16][64][4] (bf16 pack [tiles][H/32][64][8] in mixed precision)
     const float* zx;            // hoisted input halves: (row, time tt, direction d, tile, col) at zx[row*ldz + tt*8H + d*4H + tile*16 + col]
     float* out;                 // (row, tt, d, unit) at out[row*ldo + tt*2H + d*H + unit]
     float* h;                   // workspace [8 groups][2 parities][H/16][64][4]: blocked state of the group's 16 rows
@@ -124,7 +124,7 @@ struct BiLstmPersistArgs {
     int debug_drop_member;      // -1; >= 0: fault injection, that member rank of every group exits at once (tests)
 };
 bool gt_bilstm_persist_supported(int H, int B, int n_cu);
-hipError_t gt_launch_bilstm_persist(const BiLstmPersistArgs& a, hipStream_t stream);
+hipError_t gt_launch_bilstm_persist(const BiLstmPersistArgs& a, bool bf16, hipStream_t stream);
 hipError_t gt_bilstm_persist_init();       // opt in to >64 KiB dynamic LDS; call once outside stream capture
 int gt_bilstm_persist_blocks_per_cu();     // occupancy of the persistent kernel (must be 1)
 hipError_t gt_launch_bilstm_lean(const BiLstmArgs& a, hipStream_t stream);

@@ -27,6 +27,37 @@ struct LeanX {
     int nkb_a;
 };
 
+// Activation fragment of k-block `kb` (wave-uniform), M-tile `mt`: one 16-byte load per lane.  GT_X_SC1 (default): as sc1
+// buffer loads -- the activations were written by the previous launch's workgroups all over the chip, and 32 CUs of an XCD
+// missing the same fresh lines serialise in that XCD's L2; bypassing it is 0.6 us per launch at 128 KB (device_utils.h
+// gt_bload4_sc1, tools/persist_phase.hip).  Build with -DGT_X_SC1=0 for plain loads (same values either way).
+#ifndef GT_X_SC1
+#define GT_X_SC1 1
+#endif
+struct LeanXR {
+#if GT_X_SC1
+    __amdgpu_buffer_rsrc_t a, b;
+#endif
+};
+__device__ __forceinline__ LeanXR gt_x_rsrc(const LeanX& X) {
+#if GT_X_SC1
+    return LeanXR{gt_rsrc(X.xa, 0x7FFFF000u), gt_rsrc(X.xb, 0x7FFFF000u)};
+#else
+    return LeanXR{};
+#endif
+}
+__device__ __forceinline__ float4 gt_xload(const LeanXR& R, const LeanX& X, const int kb, const int MT, const int mt) {
+    const int lane = threadIdx.x & 63;
+#if GT_X_SC1
+    const bool first = kb < X.nkb_a;
+    const uint32_t soff = (uint32_t)(((first ? kb : kb - X.nkb_a) * MT + mt) * 1024);
+    return first ? gt_bload4_sc1(R.a, (uint32_t)lane * 16u, soff) : gt_bload4_sc1(R.b, (uint32_t)lane * 16u, soff);
+#else
+    const float* xs = kb < X.nkb_a ? X.xa + (size_t)kb * MT * 256 : X.xb + (size_t)(kb - X.nkb_a) * MT * 256;
+    return *reinterpret_cast<const float4*>(xs + mt * 256 + lane * 4);
+#endif
+}
+
 // acc0[j] / acc1[j]: rows m0..m0+15 / m0+16..m0+31 of tile (tile0 + j).  All NW*64 threads must call.
 // ONE_M: `mchunk` counts 16-row M-tiles and only acc0 (rows mchunk*16 .. +15) is computed -- for GEMMs with fewer tiles
 // than CUs (the projection), where a second workgroup per tile halves each one's activation pull and MFMA chain.
@@ -38,6 +69,7 @@ __device__ __forceinline__ void gt_lean_core(const float* __restrict__ wp, const
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mt0 = ONE_M ? mchunk : mchunk * 2, mt1 = min(mt0 + 1, MT - 1);
     const float4* wl = reinterpret_cast<const float4*>(wp) + ((size_t)tile0 * NKB + wave) * 64 + lane;
+    const LeanXR XR = gt_x_rsrc(X);
     float4 b[KPW][NT], x0[KPW], x1[KPW];
 #pragma unroll
     for (int i = 0; i < KPW; ++i) {
@@ -55,9 +87,8 @@ __device__ __forceinline__ void gt_lean_core(const float* __restrict__ wp, const
                 }
             }
         }
-        const float* xs = kb < X.nkb_a ? X.xa + (size_t)kb * MT * 256 : X.xb + (size_t)(kb - X.nkb_a) * MT * 256;
-        x0[i] = *reinterpret_cast<const float4*>(xs + mt0 * 256 + lane * 4);
-        if (!ONE_M) x1[i] = *reinterpret_cast<const float4*>(xs + mt1 * 256 + lane * 4);
+        x0[i] = gt_xload(XR, X, kb, MT, mt0);
+        if (!ONE_M) x1[i] = gt_xload(XR, X, kb, MT, mt1);
     }
     // every load above is requested before the first MFMA (without this the scheduler sinks each load next to its use
     // to save registers, and the wave pays one memory latency per k-block instead of one in all)
@@ -91,6 +122,7 @@ __device__ __forceinline__ void gt_lean_core_bf16(const float* __restrict__ wp, 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mt0 = ONE_M ? mchunk : mchunk * 2, mt1 = min(mt0 + 1, MT - 1);
     const uint4* wl = reinterpret_cast<const uint4*>(wp) + ((size_t)tile0 * nkb32 + wave) * 64 + lane;
+    const LeanXR XR = gt_x_rsrc(X);
     uint4 b[KPW32][NT];
     float4 x0[KPW32][2], x1[KPW32][2];
 #pragma unroll
@@ -116,9 +148,8 @@ __device__ __forceinline__ void gt_lean_core_bf16(const float* __restrict__ wp, 
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const int kb = 2 * kb32 + hf;
-                const float* xs = kb < X.nkb_a ? X.xa + (size_t)kb * MT * 256 : X.xb + (size_t)(kb - X.nkb_a) * MT * 256;
-                x0[i][hf] = *reinterpret_cast<const float4*>(xs + mt0 * 256 + lane * 4);
-                if (!ONE_M) x1[i][hf] = *reinterpret_cast<const float4*>(xs + mt1 * 256 + lane * 4);
+                x0[i][hf] = gt_xload(XR, X, kb, MT, mt0);
+                if (!ONE_M) x1[i][hf] = gt_xload(XR, X, kb, MT, mt1);
             }
         }
     }
@@ -247,11 +278,10 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
         uint4 b[KPW][NT];
         float4 xa[KPW][2], xb[KPW][2];
         const uint4* wl = reinterpret_cast<const uint4*>(wp) + ((size_t)tile0 * nkb32 + wave) * 64 + lane;
-        auto xptr = [&](const int i, const int hf, const int mt) {
+        const LeanXR XR = gt_x_rsrc(X);
+        auto xld = [&](const int i, const int hf, const int mt) {
             const int kb32 = (wave + i * NW < nkb32) ? wave + i * NW : wave;    // wave-uniform; past the end: re-read, never multiplied
-            const int kb = 2 * kb32 + hf;
-            const float* xs = kb < X.nkb_a ? X.xa + (size_t)kb * MT * 256 : X.xb + (size_t)(kb - X.nkb_a) * MT * 256;
-            return reinterpret_cast<const float4*>(xs + mt * 256 + lane * 4);
+            return gt_xload(XR, X, 2 * kb32 + hf, MT, mt);
         };
         {
             const int ma = 2 * c0, mb = min(2 * c0 + 1, MT - 1);
@@ -269,7 +299,7 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
                     }
                 }
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) { xa[i][hf] = *xptr(i, hf, ma); xb[i][hf] = *xptr(i, hf, mb); }
+                for (int hf = 0; hf < 2; ++hf) { xa[i][hf] = xld(i, hf, ma); xb[i][hf] = xld(i, hf, mb); }
             }
         }
         GT_PIN_ORDER();
@@ -300,7 +330,7 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
                 }
                 GT_PIN_ORDER();
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) { xa[i][hf] = *xptr(i, hf, ma); xb[i][hf] = *xptr(i, hf, mb); }
+                for (int hf = 0; hf < 2; ++hf) { xa[i][hf] = xld(i, hf, ma); xb[i][hf] = xld(i, hf, mb); }
                 GT_PIN_ORDER();
             }
             if (mc == c0) GT_STAMP(dbg, 2);
@@ -316,11 +346,8 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
         constexpr int NKB = NW * KPW;
         float4 b[KPW][NT], xa[KPW], xb[KPW];
         const float4* wl = reinterpret_cast<const float4*>(wp) + ((size_t)tile0 * NKB + wave) * 64 + lane;
-        auto xptr = [&](const int i, const int mt) {
-            const int kb = wave + i * NW;                       // wave-uniform
-            const float* xs = kb < X.nkb_a ? X.xa + (size_t)kb * MT * 256 : X.xb + (size_t)(kb - X.nkb_a) * MT * 256;
-            return reinterpret_cast<const float4*>(xs + mt * 256 + lane * 4);
-        };
+        const LeanXR XR = gt_x_rsrc(X);
+        auto xld = [&](const int i, const int mt) { return gt_xload(XR, X, wave + i * NW, MT, mt); };
         {
             const int ma = 2 * c0, mb = min(2 * c0 + 1, MT - 1);
 #pragma unroll
@@ -336,8 +363,8 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
                         b[i][j] = *src;
                     }
                 }
-                xa[i] = *xptr(i, ma);
-                xb[i] = *xptr(i, mb);
+                xa[i] = xld(i, ma);
+                xb[i] = xld(i, mb);
             }
         }
         GT_PIN_ORDER();
@@ -373,8 +400,8 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
                     acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb[i].w, b[i][j].w, acc1[j], 0, 0, 0);
                 }
                 GT_PIN_ORDER();
-                xa[i] = *xptr(i, ma);       // the next chunk's k-block i (the last chunk re-reads its own: no branch, counted waits)
-                xb[i] = *xptr(i, mb);
+                xa[i] = xld(i, ma);       // the next chunk's k-block i (the last chunk re-reads its own: no branch, counted waits)
+                xb[i] = xld(i, mb);
                 GT_PIN_ORDER();
             }
             if (mc == c0) GT_STAMP(dbg, 2);

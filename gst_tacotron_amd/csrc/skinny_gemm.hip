@@ -461,6 +461,10 @@ __device__ __forceinline__ void gt_ld2x4_sc1(const float* p0, const float* p1, f
 }
 
 constexpr int kPersistLds = 96 * 1024;
+// BF16 (Use_Mixed_Precision): W_h as the bf16 pack [tile][32-k block][lane][8], the state rounded to bf16 on its way into
+// v_mfma_f32_16x16x32_bf16 (wave w owns 32-k block w = the 16-blocks 2w, 2w + 1) -- the operand roundings of the general bf16
+// step kernel; accumulation, gates and state stay fp32.
+template <bool BF16>
 __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArgs A) {
     constexpr int NW = 8, KPW = 2, NT = 2, NM = 32;                // waves, k-blocks per wave, tiles per member, members per group
     // (launched with kPersistLds bytes of dynamic LDS, more than half a CU's: one workgroup per CU, so that the 32 members of
@@ -488,13 +492,19 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
     const int grow = mt * 16 + row, tile0 = rank * NT, unit = (tile0 + j_own) * 4 + col;
     const bool owner = col < 4;                                    // lanes that own a hidden unit (rows beyond M publish zeros)
     const bool real = grow < A.M;
-    // weights: k-blocks wave and wave + 8 of both tiles, resident for the whole sequence
+    // weights: k-blocks wave and wave + 8 of both tiles (bf16: 32-k block `wave`), resident for the whole sequence
     float4 b[KPW][NT];
+    uint4 b32[NT];
+    if constexpr (BF16) {
 #pragma unroll
-    for (int i = 0; i < KPW; ++i)
+        for (int j = 0; j < NT; ++j) b32[j] = (reinterpret_cast<const uint4*>(A.wp[d]) + ((size_t)(tile0 + j) * NW + wave) * 64)[lane];
+    } else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            b[i][j] = (reinterpret_cast<const float4*>(A.wp[d]) + ((size_t)(tile0 + j) * (NW * KPW) + wave + i * NW) * 64)[lane];
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                b[i][j] = (reinterpret_cast<const float4*>(A.wp[d]) + ((size_t)(tile0 + j) * (NW * KPW) + wave + i * NW) * 64)[lane];
+    }
     float* hbuf = A.h + (size_t)g * 2 * 16 * H;                     // [2 parities][H/16 k-blocks][64 lanes][4]
     uint32_t* fl = A.flags + (size_t)g * 2 * NM;                   // [2 parities][32 members]
     // (rows beyond M read the group's first row, which exists, and are never used: no load under a branch, no wait at its join)
@@ -523,7 +533,8 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
                 if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(gt_ldu_sc1(A.err)) != 0u) { if (lane == 0) s_abort = 1; break; }
             }
             const float* hp = hbuf + (size_t)par * 16 * H + lane * 4;
-            gt_ld2x4_sc1(hp + (size_t)wave * 256, hp + (size_t)(wave + NW) * 256, x[0], x[1]);
+            if constexpr (BF16) gt_ld2x4_sc1(hp + (size_t)(2 * wave) * 256, hp + (size_t)(2 * wave + 1) * 256, x[0], x[1]);
+            else gt_ld2x4_sc1(hp + (size_t)wave * 256, hp + (size_t)(wave + NW) * 256, x[0], x[1]);
         }
         // the next step's hoisted input half: requested now, needed after the next wait
         const float cur = pin;
@@ -532,15 +543,27 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
             pin = zrow[(size_t)(d == 0 ? tn : A.T - 1 - tn) * 8 * H];
         }
         f32x4 acc[NT] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int i = 0; i < KPW; ++i)
+        if constexpr (BF16) {
+            bf16x8 a;
+            a[0] = (__bf16)x[0].x; a[1] = (__bf16)x[0].y; a[2] = (__bf16)x[0].z; a[3] = (__bf16)x[0].w;
+            a[4] = (__bf16)x[1].x; a[5] = (__bf16)x[1].y; a[6] = (__bf16)x[1].z; a[7] = (__bf16)x[1].w;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].x, b[i][j].x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].y, b[i][j].y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].z, b[i][j].z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].w, b[i][j].w, acc[j], 0, 0, 0);
+                bf16x8 bw;
+                __builtin_memcpy(&bw, &b32[j], 16);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[j], 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPW; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].x, b[i][j].x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].y, b[i][j].y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].z, b[i][j].z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].w, b[i][j].w, acc[j], 0, 0, 0);
+                }
+        }
         {   // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
             const int r = lane & 15, q = lane >> 4;
 #pragma unroll
@@ -575,20 +598,23 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
 // which must be able to hold its 32 members at once.
 bool gt_bilstm_persist_supported(int H, int B, int n_cu) { return H == 256 && B <= 64 && n_cu >= 256; }
 
-hipError_t gt_launch_bilstm_persist(const BiLstmPersistArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(gt_bilstm_persist_kernel, dim3(512), dim3(512), kPersistLds, stream, a);
+hipError_t gt_launch_bilstm_persist(const BiLstmPersistArgs& a, bool bf16, hipStream_t stream) {
+    if (bf16) hipLaunchKernelGGL(gt_bilstm_persist_kernel<true>, dim3(512), dim3(512), kPersistLds, stream, a);
+    else hipLaunchKernelGGL(gt_bilstm_persist_kernel<false>, dim3(512), dim3(512), kPersistLds, stream, a);
     return hipGetLastError();
 }
 
 hipError_t gt_bilstm_persist_init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gt_bilstm_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_bilstm_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gt_bilstm_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kPersistLds);
 }
 
 // workgroups of the persistent kernel one compute unit can hold at once (the design needs exactly 1: the 32 members of a
 // group each on their own CU of the group's XCD); 0 = it does not fit at all
 int gt_bilstm_persist_blocks_per_cu() {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(gt_bilstm_persist_kernel), 512, kPersistLds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(gt_bilstm_persist_kernel<false>), 512, kPersistLds) != hipSuccess) return 0;
     return n;
 }
 
