@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[A_F4];
-    uint4 rb[B_U4];
+    u32x4 rb[B_U4];       // (ext_vector_type, NOT HIP's uint4 struct: an array of those is not promoted to registers here -- it went through scratch)
     const __bf16* wt = reinterpret_cast<const __bf16*>(A.wt_bf16);
     auto load_slice = [&](int k0) {
 #pragma unroll
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
         for (int i = 0; i < B_U4; ++i) {
             const int f = tid + i * 256;
             const int n = f >> 3, kq = f & 7;           // 8 pieces of 8 k per column
-            rb[i] = *reinterpret_cast<const uint4*>(wt + (size_t)(n0 + n) * A.ldk + k0 + kq * 8);   // padded: always in range
+            rb[i] = *reinterpret_cast<const u32x4*>(wt + (size_t)(n0 + n) * A.ldk + k0 + kq * 8);   // padded: always in range
         }
     };
     auto store_slice = [&]() {
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
         for (int i = 0; i < B_U4; ++i) {
             const int f = tid + i * 256;
             const int n = f >> 3, kq = f & 7;
-            *reinterpret_cast<uint4*>(&Bs[n * LDH + kq * 8]) = rb[i];
+            *reinterpret_cast<u32x4*>(&Bs[n * LDH + kq * 8]) = rb[i];
         }
     };
 
@@ -314,6 +314,157 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------- five-tap Conv1D on bf16 MFMA
+// The implicit GEMM above treats K = taps x Cin as one axis, so every input row is gathered again for each of the five taps
+// (and for each 128-column block): at 64 utterances x 1000 frames a 512 -> 512 postnet layer pulled 2.6 GB through the CUs'
+// load pipes and ran at 252 TF, a tenth of the bf16 MFMA rate.  Here a workgroup owns 256 output frames of ONE utterance x
+// 256 (or 128) output channels, stages the 260 input rows a 64-channel slice needs ONCE (fp32 -> bf16 on their way into LDS)
+// and runs the five taps from it -- tap j of output frame i reads staged row i + j -- so only the 32 KB weight slab of a
+// (tap, slice) step moves per 2048 MFMA-cycles.  Both LDS operands are double-buffered: one barrier per step, the next
+// step's weights and the next slice's rows are in flight under the MFMAs.  Same operand roundings and the same fp32
+// accumulation as gt_conv_gemm_bf16_kernel (the order of the K terms differs: tap-major inside a slice).
+constexpr int C5_BM = 256, C5_BK = 64, C5_LD = C5_BK + 8, C5_AR = C5_BM + 4;
+template <int RN>       // 32-column tiles per wave: the workgroup tile is 256 frames x (2 * RN * 32) channels
+constexpr int c5_lds_bytes() { return 2 * (C5_AR + 2 * RN * 32) * C5_LD * 2; }
+
+template <int RN>
+__global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
+    constexpr int BN = 2 * RN * 32, RM = 2;
+    constexpr int A_F4 = (C5_AR * (C5_BK / 4) + 511) / 512;      // float4 pieces (4 channels of one row) per thread per slice
+    constexpr int B_U4 = BN * (C5_BK / 8) / 512;                 // 16-byte pieces (8 k of one column) per thread per step
+    extern __shared__ __attribute__((aligned(16))) __bf16 c5_lds[];
+    __bf16* As = c5_lds;                                         // [2][C5_AR][C5_LD]
+    __bf16* Bs = c5_lds + 2 * C5_AR * C5_LD;                     // [2][BN][C5_LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves: 64 frames x (RN * 32) channels each
+    const int tiles_t = (A.T + C5_BM - 1) / C5_BM;
+    const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * C5_BM;
+    const int n0 = blockIdx.y * BN;
+    const int len = A.row_len ? min(A.T, A.row_len[b]) : A.T;    // masked mode: input rows >= len read as zero
+    const float* xb = A.x + (int64_t)b * A.T * A.Cin;
+    const __bf16* wt = reinterpret_cast<const __bf16*>(A.wt_bf16);
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // (the next slice's 260 rows are staged in two halves -- requested at taps 0 / 2, stored at taps 1 / 3 -- so that only five
+    // float4 of them are ever live beside the 128 accumulator registers: with all nine the weight staging registers went
+    // through scratch, and a scratch store waits for the loads it saves)
+    constexpr int A_H0 = (A_F4 + 1) / 2;
+    float4 ra[A_H0];
+    u32x4 rb[B_U4];
+    auto load_a = [&](const int k0, const int half) {
+#pragma unroll
+        for (int i = 0; i < A_H0; ++i) {
+            const int f = tid + (half * A_H0 + i) * 512;
+            const int row = f >> 4, t = t0 - A.pad_before + row;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < C5_AR && t >= 0 && t < len) ra[i] = *reinterpret_cast<const float4*>(xb + (int64_t)t * A.Cin + k0 + (f & 15) * 4);
+        }
+    };
+    auto store_a = [&](const int buf, const int half) {
+#pragma unroll
+        for (int i = 0; i < A_H0; ++i) {
+            const int f = tid + (half * A_H0 + i) * 512;
+            const int row = f >> 4;
+            if (row < C5_AR) {
+                bf16x4 h;
+                h[0] = (__bf16)ra[i].x; h[1] = (__bf16)ra[i].y; h[2] = (__bf16)ra[i].z; h[3] = (__bf16)ra[i].w;
+                *reinterpret_cast<bf16x4*>(&As[(buf * C5_AR + row) * C5_LD + (f & 15) * 4]) = h;
+            }
+        }
+    };
+    auto load_b = [&](const int tap, const int k0) {
+#pragma unroll
+        for (int i = 0; i < B_U4; ++i) {
+            const int f = tid + i * 512;
+            rb[i] = *reinterpret_cast<const u32x4*>(wt + (size_t)(n0 + (f >> 3)) * A.ldk + tap * A.Cin + k0 + (f & 7) * 8);   // padded rows: in range
+        }
+    };
+    auto store_b = [&](const int buf) {
+#pragma unroll
+        for (int i = 0; i < B_U4; ++i) {
+            const int f = tid + i * 512;
+            *reinterpret_cast<u32x4*>(&Bs[(buf * BN + (f >> 3)) * C5_LD + (f & 7) * 8]) = rb[i];
+        }
+    };
+
+    const int nslices = A.Cin / C5_BK, nsteps = nslices * 5;
+    load_a(0, 0);
+    store_a(0, 0);
+    load_a(0, 1);
+    store_a(0, 1);
+    load_b(0, 0);
+    store_b(0);
+    __syncthreads();
+    const int kh = lane >> 5, l31 = lane & 31;
+    for (int s = 0; s < nsteps; ++s) {
+        const int sl = s / 5, tap = s - sl * 5;
+        // requests for the NEXT step's weight slab (the last step re-requests its own: no load under a branch, so the staging
+        // registers stay registers and the waits stay counted), and at tap 0 for the next slice's input rows (stored at tap 1:
+        // the other A buffer was last read in the previous slice)
+        const int sn = min(s + 1, nsteps - 1);
+        load_b(sn % 5, (sn / 5) * C5_BK);
+        if (tap == 0 || tap == 2) load_a(min(sl + 1, nslices - 1) * C5_BK, tap >> 1);
+        const __bf16* Ab = As + ((sl & 1) * C5_AR + wm * 64 + l31 + tap) * C5_LD + kh * 8;
+        const __bf16* Bb = Bs + ((s & 1) * BN + wn * RN * 32 + l31) * C5_LD + kh * 8;
+#pragma unroll
+        for (int ks = 0; ks < C5_BK / 16; ++ks) {
+            bf16x8 av[RM], bv[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * C5_LD + ks * 16);
+#pragma unroll
+            for (int j = 0; j < RN; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * C5_LD + ks * 16);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        store_b((s + 1) & 1);           // (after the last step: written, never read)
+        if (tap == 1 || tap == 3) store_a((sl + 1) & 1, tap >> 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+        const int n = n0 + (wn * RN + j) * 32 + l31;
+        if (n >= A.N) continue;
+        const float sc = A.scale ? A.scale[n] : 1.f;
+        const float sh = A.shift ? A.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int t = t0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (t >= A.T) continue;
+                const int64_t m = (int64_t)b * A.T + t;
+                float v = acc[i][j][e] * sc + sh;
+                if (A.rowbias) v += A.rowbias[(int64_t)b * A.N + n];
+                if (A.act == ACT_RELU) v = fmaxf(v, 0.f);
+                else if (A.act == ACT_TANH) v = gt_tanh(v);
+                if (A.res) v += A.res[m * A.ldo + n];
+                A.out[m * A.ldo + n] = v;
+            }
+        }
+    }
+}
+
+static bool gt_conv5_bf16_applies(const ConvGemmArgs& a) {
+    return a.wt_bf16 && a.taps == 5 && a.Cin % C5_BK == 0 && !a.tokens && !a.pool2 && !a.conv2d && a.N >= 64 && a.T >= 64;
+}
+
+hipError_t gt_conv5_bf16_init() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv5_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, c5_lds_bytes<4>());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv5_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, c5_lds_bytes<2>());
+}
 
 // ---------------------------------------------------------------------------------------------------- Winograd F(2, 5)
 // Conv1D(k = 5, stride 1, SAME) as the minimal-filtering algorithm F(2, 5): two outputs from six inputs with 6
@@ -582,6 +733,12 @@ bool gt_conv_wino5_applies(const ConvGemmArgs& a) {
 
 hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const int M = a.B * a.T;
+    if (gt_conv5_bf16_applies(a)) {         // five taps sharing one staged input tile (256 frames of one utterance per workgroup)
+        const int tiles_t = (a.T + C5_BM - 1) / C5_BM;
+        if (a.N > 128) hipLaunchKernelGGL((gt_conv5_bf16_kernel<4>), dim3(a.B * tiles_t, (a.N + 255) / 256), dim3(512), c5_lds_bytes<4>(), stream, a);
+        else hipLaunchKernelGGL((gt_conv5_bf16_kernel<2>), dim3(a.B * tiles_t, 1), dim3(512), c5_lds_bytes<2>(), stream, a);
+        return hipGetLastError();
+    }
     if (a.wt_bf16) {
         const int nb = (a.N + 127) / 128;
         if (((M + 127) / 128) * nb >= 256) {

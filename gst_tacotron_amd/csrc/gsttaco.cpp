@@ -373,11 +373,11 @@ inline uint16_t bf16_bits(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-// Mixed precision: registers the bf16 TRANSPOSED copy [ceil(N/128)*128][ldk] (k contiguous, zero padded, ldk =
+// Mixed precision: registers the bf16 TRANSPOSED copy [ceil(N/256)*256][ldk] (k contiguous, zero padded, ldk =
 // ceil(K/64)*64) of a conv-GEMM weight [K, N] (row stride ldw) under its fp32 device pointer.
 int add_bf16(gsttaco_ctx* c, const float* dev_w, const float* host_w, int K, int N, int ldw) {
     if (!c->cfg.mixed_precision) return 0;
-    const int ldk = (K + 63) / 64 * 64, npad = (N + 127) / 128 * 128;
+    const int ldk = (K + 63) / 64 * 64, npad = (N + 255) / 256 * 256;     // (column blocks of up to 256: gt_conv5_bf16_kernel)
     std::vector<uint16_t> t((size_t)npad * ldk, 0);
     for (int k = 0; k < K; ++k)
         for (int n = 0; n < N; ++n) t[(size_t)n * ldk + k] = bf16_bits(host_w[(size_t)k * ldw + n]);
@@ -1811,6 +1811,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     HIPCHECK(c, gt_dec_front_init());
     HIPCHECK(c, gt_gst_init());
     HIPCHECK(c, gt_bilstm_persist_init());
+    HIPCHECK(c, gt_conv5_bf16_init());
     // the persistent BiLSTM's groups need their 32 members each on a CU of their own: exactly one workgroup per CU must fit
     if (c->bilstm_persist && gt_bilstm_persist_blocks_per_cu() != 1) {
         c->bilstm_persist = false;

@@ -159,7 +159,7 @@ struct ConvGemmArgs {
     const int32_t* row_len; // masked-mode extension (A12): input rows t >= row_len[b] read as zero, or NULL
     int ldw;                // row stride of w in floats (0 = N); lets N be odd (513) over a zero-padded multiple of 4
     int pool2;              // 1: the input row is max(x[t], x[t+1]) -- MaxPool1D(2, stride 1, 'same') fused into the gather
-    // mixed precision (Use_Mixed_Precision): the weights TRANSPOSED in bf16, [ceil(N/128)*128][ldk] with k contiguous and
+    // mixed precision (Use_Mixed_Precision): the weights TRANSPOSED in bf16, [ceil(N/256)*256][ldk] with k contiguous and
     // zero padding (ldk = ceil(taps*Cin/64)*64), or NULL = fp32 path.  Activations are rounded to bf16 on their way into
     // LDS, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16), the epilogue and the output stay fp32.
     const void* wt_bf16;
@@ -178,6 +178,7 @@ struct ConvGemmArgs {
 };
 
 hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
+hipError_t gt_conv5_bf16_init();           // opt in to >64 KiB dynamic LDS; call once outside stream capture
 // Highwaynet combine (reference Taco2.py:409-424): z [M, 2S] = [relu-branch | sigmoid-branch] pre-activations,
 // out = relu(z_h) * sigmoid(z_t) + x * (1 - sigmoid(z_t));  S % 4 == 0
 hipError_t gt_launch_highway(const float* z, const float* x, float* out, int64_t M, int S, hipStream_t stream);
