@@ -57,6 +57,7 @@ struct ConvLayer {
 struct GraphKey {
     int kind, B, Tv, Tref1, steps, has_mask, has_noise, prof, masked;
     int persist = 0;    // captured with the persistent BiLSTM launches enabled (filled in by run_cached)
+    int fuse12 = 0;     // captured with both decode LSTM cells in one launch (only while this is the process's one live context)
     bool operator<(const GraphKey& o) const {
         return memcmp(this, &o, sizeof(GraphKey)) < 0;
     }
@@ -128,6 +129,9 @@ struct gsttaco_ctx {
                                  // otherwise, 2 = F(2,5) only, 0 = implicit GEMM only (GSTTACO_WINO)
     bool bilstm_persist = true;  // one persistent launch per BiLSTM instead of one per time step (GSTTACO_BILSTM_PERSIST=0: per step)
     bool keep_hash = true;       // throughput mode: hashed keep decisions, dropped weight rows not requested (GSTTACO_DEBUG: KEEP_HASH=0)
+    bool fuse12 = true;          // both decode LSTM cells in one launch with an in-kernel hand-off (GSTTACO_FUSED_LSTM=0: two launches)
+    bool fuse12_now = false;     // ... for the call being enqueued: fuse12 and this is the process's only live context
+    uint32_t* w_arrive = nullptr;    // [steps_max][8 x 32] arrival counters of the fused launch, zeroed at the start of every decode
     int debug_drop_member = -1;  // fault injection (gsttaco_debug_raise_handoff_error): a member of the next persistent launches never shows up
     mutable std::string warn;    // last warning (a recovered condition): readable through gsttaco_last_error until the next error
     bool lean = true;            // lean_body.h kernels for the decode shapes they cover (GSTTACO_LEAN=0: general kernels only)
@@ -824,6 +828,11 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     HIPCHECK(c, gt_launch_zero(c->w_c1, (size_t)B * H1, s));
     HIPCHECK(c, gt_launch_zero(c->w_c2, (size_t)B * H2, s));
     if (g.att_type == GSTTACO_ATT_LSA) HIPCHECK(c, gt_launch_zero(c->w_lsa_state, (size_t)B * Tv, s));   // Layers.py:356
+    // both LSTM cells in one launch (skinny_gemm.hip gt_lstm12_kernel): fp32 lean shapes, batch <= 32, one live context
+    const bool fuse12 = c->fuse12_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && !c->lstm_x[0].bf16 && !c->lstm_x[1].bf16 &&
+                        g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv) &&
+                        gt_lstm12_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->n_cu);
+    if (fuse12) HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_arrive), (size_t)steps * 256, s));
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
     // throughput mode: the whole decode's dropout masks and sigmoid noise are generated up front (same Philox streams the
@@ -968,6 +977,22 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         HIPCHECK(c, gt_launch_attn_step(a, s));
         }
         // 5/6. the two LSTM cells (StackedRNNCells, Taco2.py:111)
+        if (fuse12) {
+            Lstm12Args fa{};
+            for (int layer = 0; layer < 2; ++layer) {
+                const PackedLinear& L = c->lstm_x[layer];
+                float** hb = layer == 0 ? c->w_h1 : c->w_h2;
+                unsigned long long* dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
+                (layer == 0 ? fa.l1 : fa.l2) = LstmXArgs{L.wp, layer == 0 ? xa_t : c->w_h1[p], c->w_part[layer], layer == 0 ? c->w_c1 : c->w_c2, hb[p],
+                                                         nullptr, dbg, B, MT, layer == 0 ? H1 : H2, 0, L.nkb};
+            }
+            fa.arrive = c->w_arrive + (size_t)t * 256;
+            fa.err = c->w_err;
+            fa.expect = (uint32_t)((H1 + 3) / 4) + (c->debug_drop_member >= 0 ? 1u : 0u);
+            if (prof) { int rce = prof_begin(0); if (rce) return rce; }
+            HIPCHECK(c, gt_launch_lstm12(fa, s));
+            if (prof) { int rce = prof_end(0); if (rce) return rce; }
+        } else
         for (int layer = 0; layer < 2; ++layer) {
             memset(&k, 0, sizeof(k));
             const int H = layer == 0 ? H1 : H2;
@@ -1286,6 +1311,13 @@ int run_cached_inner(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in,
 // call itself.  Here, at the next call: clear the word, stop using the persistent launch on this context (one launch per time
 // step from now on: no co-residency needed) and say so through gsttaco_last_error as a warning.  Nothing stays poisoned.
 void recover_from_give_up(gsttaco_ctx* c) {
+    if (c->h_err && c->h_err[0]) {      // the fused LSTM launch's hand-off (gt_lstm12_kernel): back to one launch per cell
+        c->h_err[0] = 0;
+        c->fuse12 = false;
+        c->warn = c->err = "warning: the in-kernel hand-off of the fused decode-LSTM launch gave up in an earlier call (its workgroups were not "
+                           "co-resident: is another process or a CU mask sharing this GPU?); that call's outputs were invalid.  This context now "
+                           "runs the two LSTM cells as two launches (same results, ~4 % slower)";
+    }
     if (!c->h_err || !c->h_err[1]) return;
     c->h_err[1] = 0;
     c->bilstm_persist = false;
@@ -1313,6 +1345,9 @@ template <typename F>
 int run_cached_inner(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F body) {
     GraphKey key = key_in;
     key.persist = c->bilstm_persist ? 1 : 0;
+    // several decode loops in flight could each hold part of the chip and wait for the rest of their fused launch: one live context only
+    c->fuse12_now = c->fuse12 && g_live_contexts.load() <= 1;
+    key.fuse12 = c->fuse12_now ? 1 : 0;
     if (!c->use_graph || c->graph_cache_max < 1) return body(stream);
     const uint64_t now = ++c->graph_clock;
     auto it = c->graphs.find(key);
@@ -1449,6 +1484,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->fused_front = c->front_mode != 0;
     c->lean = env_int("GSTTACO_LEAN", 1) != 0;
     c->bilstm_persist = env_int("GSTTACO_BILSTM_PERSIST", 1) != 0;
+    c->fuse12 = env_int("GSTTACO_FUSED_LSTM", 1) != 0;
     c->wino = env_int("GSTTACO_WINO", 4);
     c->stamps = env_int("GSTTACO_STAMPS", 0) == 1;
 #ifdef GSTTACO_DEBUG
@@ -1779,6 +1815,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     }
     if ((rc = fa(&c->w_part[0], Bp * 4 * c->H1))) return rc;
     if ((rc = fa(&c->w_part[1], Bp * 4 * c->H2))) return rc;
+    if ((rc = dev_alloc(c, (void**)&c->w_arrive, (size_t)S * 256 * sizeof(uint32_t)))) return rc;
     // the give-up words of the in-kernel hand-offs live in host-mapped memory: the device raises them with a system-scope
     // atomic (failure path only), the host reads them without a synchronisation at the start of the next call
     HIPCHECK(c, hipHostMalloc((void**)&c->h_err, 16, hipHostMallocMapped));
@@ -2047,8 +2084,8 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
 int gsttaco_synchronize(gsttaco_ctx* c, void* stream) {
     if (!c) return GSTTACO_E_INVALID;
     HIPCHECK(c, hipStreamSynchronize((hipStream_t)stream));
-    if (c->h_err && c->h_err[1])
-        return fail(c, GSTTACO_E_HIP, "a hand-off wait of the persistent BiLSTM launch gave up (its members were not co-resident: is another process or "
+    if (c->h_err && (c->h_err[1] | c->h_err[0]))
+        return fail(c, GSTTACO_E_HIP, "a hand-off wait of the persistent BiLSTM launch / the fused decode-LSTM launch gave up (its members were not co-resident: is another process or "
                                       "a CU mask sharing this GPU?): the outputs of the calls since the last gsttaco_synchronize are invalid.  Repeat "
                                       "them: the context now uses one launch per time step");
     return 0;

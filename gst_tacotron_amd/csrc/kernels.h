@@ -87,6 +87,15 @@ struct LstmXArgs {
     int nkb;                    // K / 16 (the bf16 variant's 32-k blocks need not fill NW x KPW)
 };
 bool gt_lstm_x_supported(int nkb);
+// Both cells in one launch with an in-kernel hand-off of h1 (skinny_gemm.hip gt_lstm12_kernel): fp32, batch <= 32.
+struct Lstm12Args {
+    LstmXArgs l1, l2;           // exactly the two launches' arguments (l2.x == l1.h)
+    uint32_t* arrive;           // 8 x 32 words, zero before the launch: per-shard arrival counters of THIS decode step
+    uint32_t* err;              // host-mapped give-up word
+    uint32_t expect;            // arrivals to wait for = the grid size (fault injection: one more, so the wait runs into its bound)
+};
+bool gt_lstm12_supported(int nkb1, int nkb2, int H1, int H2, int M, int n_cu);
+hipError_t gt_launch_lstm12(const Lstm12Args& a, hipStream_t stream);
 hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, bool bf16, hipStream_t stream);
 
 // One time step of a Bidirectional LSTM (reference Taco2.py:39-43, 394-398) whose input halves x_t . W_x + b were hoisted

@@ -151,6 +151,155 @@ __global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
     GT_STAMP(A.dbg, 3);
 }
 
+__device__ __forceinline__ uint32_t gt_ldu_sc1(const uint32_t* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// ======================================================================================================================
+// Both decode LSTM cells in ONE launch (fp32, batch <= 32): workgroup = tile `blockIdx.x` of layer 1, then of layer 2.
+//
+// What it buys (tools/persist_phase.hip, measured on MI355X): an LSTM-2-shaped phase costs 6.3-6.9 us as a launch of its own
+// -- kernel boundary, then 64 KB of weights per CU from the Infinity Cache, then the 128 KB state -- and 5.0 us when the
+// weights are already in registers and the boundary is an in-kernel hand-off.  Here the layer-2 tile's weights, bias-side
+// partial sums and cell state are REQUESTED BEFORE the workgroup starts waiting for layer 1 (they depend on nothing this
+// launch computes), so the wait for the other 255 tiles' h1 hides their latency; h1 itself is stored write-through and read
+// with sc1 loads (gt_xload), the arrival counter is sharded over 8 cache lines and polled with sc1 loads.
+// Arithmetic = gt_lstm_x_kernel<8,3> followed by gt_lstm_x_kernel<8,8>, same orders: bitwise equal states.
+//
+// The hand-off needs all of the launch's workgroups resident together: 256 x 512 threads always are on an otherwise idle
+// MI355X (two fit a CU), and the host only takes this path while the process has ONE live context (several decode loops in
+// flight could each hold part of the chip and wait for the rest).  The wait is bounded all the same: a give-up raises the
+// host-mapped error word (gsttaco_synchronize reports it, the next call falls back to two launches).
+// ======================================================================================================================
+__device__ __forceinline__ void gt_st1_sc1(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+__global__ __launch_bounds__(512) void gt_lstm12_kernel(Lstm12Args P) {
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 1>::kFloats];
+    __shared__ int s_abort;
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
+    GT_STAMP(P.l1.dbg, 4);
+    if (threadIdx.x == 0) s_abort = 0;
+    // ---------------------------------------------------------------- layer 1 (gt_lstm_x_kernel<8, 3>)
+    {
+        const LstmXArgs& A = P.l1;
+        const int MT = A.MT, unit = tile * 4 + col;
+        const float pin = (row < MT * 16) ? A.partial_in[((size_t)tile * MT * 16 + row) * 16 + col] : 0.f;
+        const float c_prev = (col < 4 && row < A.M && unit < A.H) ? A.c[(size_t)row * A.H + unit] : 0.f;
+        GT_STAMP(A.dbg, 0);
+        f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+        gt_lean_core<NW, 3, 1, false>(A.wp, tile, 1, LeanX{A.x, A.x, NW * 3}, MT, 0, acc0, acc1);
+        GT_STAMP(A.dbg, 1);
+        gt_lean_spill<NW, 1>(lds, acc0, acc1);
+        __syncthreads();
+        GT_STAMP(A.dbg, 2);
+        float z = pin;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) z += part[w][row][col];
+        const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+        if (col < 4 && row < A.M && unit < A.H) {
+            const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
+            const float c2 = __builtin_fmaf(gf, c_prev, gi * gg);
+            A.c[(size_t)row * A.H + unit] = c2;
+            gt_st1_sc1(A.h + gt_blk_off(row, unit, MT), go * gt_tanh(c2));     // write-through: read by every other workgroup below
+        }
+        GT_STAMP(A.dbg, 3);
+    }
+    // ---------------------------------------------------------------- layer 2 (gt_lstm_x_kernel<8, 8>)
+    const LstmXArgs& A = P.l2;
+    const int MT = A.MT, unit = tile * 4 + col;
+    // arrive first: this workgroup's part of h1 is out once its stores are acknowledged (nothing else is in flight yet)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&P.arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ... then everything of layer 2 that does not depend on layer 1 is requested and arrives during the wait
+    const float pin = (row < MT * 16) ? A.partial_in[((size_t)tile * MT * 16 + row) * 16 + col] : 0.f;
+    const float c_prev = (col < 4 && row < A.M && unit < A.H) ? A.c[(size_t)row * A.H + unit] : 0.f;
+    constexpr int KPW = 8, NKB = NW * KPW;
+    float4 b[KPW];
+    {
+        const float4* wl = reinterpret_cast<const float4*>(A.wp) + ((size_t)tile * NKB + wave) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) b[i] = wl[(size_t)i * NW * 64];
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x < 64) {
+        uint32_t spins = 0;
+        for (;;) {
+            uint32_t v = lane < 8 ? gt_ldu_sc1(P.arrive + lane * 32) : 0u;
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) v += __shfl_xor(v, d, 64);
+            if (__builtin_amdgcn_readfirstlane(v) >= P.expect) break;
+            ++spins;
+            if (spins > (1u << 18)) { if (lane == 0) { atomicOr(P.err, 1u); s_abort = 1; } break; }
+            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(gt_ldu_sc1(P.err)) != 0u) { if (lane == 0) s_abort = 1; break; }
+        }
+    }
+    __syncthreads();
+    if (s_abort) return;
+    GT_STAMP(A.dbg, 4);
+    const LeanX X{A.x, A.x, NKB};
+    const LeanXR XR = gt_x_rsrc(X);
+    float4 x0[KPW], x1[KPW];
+    const int mt1 = min(1, MT - 1);
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        x0[i] = gt_xload(XR, X, wave + i * NW, MT, 0);
+        x1[i] = gt_xload(XR, X, wave + i * NW, MT, mt1);
+    }
+    GT_STAMP(A.dbg, 0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, b[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, b[i].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, b[i].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, b[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, b[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, b[i].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, b[i].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, b[i].w, acc1, 0, 0, 0);
+    }
+    GT_STAMP(A.dbg, 1);
+    {
+        f32x4 a0[1] = {acc0}, a1[1] = {acc1};
+        gt_lean_spill<NW, 1>(lds, a0, a1);          // (layer 1's partial sums were read before the arrival barrier)
+    }
+    __syncthreads();
+    GT_STAMP(A.dbg, 2);
+    float z = pin;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) z += part[w][row][col];
+    const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+    if (col < 4 && row < A.M && unit < A.H) {
+        const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
+        const float c2 = __builtin_fmaf(gf, c_prev, gi * gg);
+        A.c[(size_t)row * A.H + unit] = c2;
+        A.h[gt_blk_off(row, unit, MT)] = go * gt_tanh(c2);
+    }
+    GT_STAMP(A.dbg, 3);
+}
+
+bool gt_lstm12_supported(int nkb1, int nkb2, int H1, int H2, int M, int n_cu) {
+    return nkb1 == 24 && nkb2 == 64 && H1 == H2 && H1 % 4 == 0 && M <= 32 && H1 / 4 <= 2 * n_cu;
+}
+
+hipError_t gt_launch_lstm12(const Lstm12Args& a, hipStream_t stream) {
+    hipLaunchKernelGGL(gt_lstm12_kernel, dim3((a.l1.H + 3) / 4), dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+
 // Batches above 32 rows (lean_body.h, "Batches above 32 rows"): a workgroup owns a PAIR of tiles (8 hidden units) and half of
 // the batch's 32-row chunks, keeps the pair's weights in registers over its chunks and multiplies every activation fragment
 // with both tiles.  The two workgroups of a pair sit 8 block indices apart = on one XCD under the round-robin block -> XCD
@@ -444,11 +593,6 @@ __global__ __launch_bounds__(NW * 64) void gt_bilstm_lean_kernel(BiLstmArgs A) {
 //
 // Arithmetic = gt_bilstm_lean_kernel<8, 2>'s exactly (k-block kb on wave kb % 8, ascending; partial sums added over waves in
 // ascending order after the hoisted input half): bitwise equal outputs, which is what the GPU test checks.
-__device__ __forceinline__ uint32_t gt_ldu_sc1(const uint32_t* p) {
-    uint32_t v;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
 __device__ __forceinline__ void gt_ld2x4_sc1(const float* p0, const float* p1, float4& a, float4& b) {
     f32x4 ra, rb;
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
