@@ -160,11 +160,12 @@ def cpu_baseline(hp, w, inputs, budget_s=15.0, runs=5):
                                    "(fastest of 1/4/8/16)".format(steps0, runs, best0[0])}}
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary (FETCH_SIZE x2 +
-    WRITE_SIZE, separate passes: tools/profile.sh); None when no summary is present."""
+def pmc_traffic(kernel_substr, cfg_tag):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of THIS configuration
+    (profiles/<round>_<cfg_tag>_hbm_pmc.json: FETCH_SIZE x2 + WRITE_SIZE, separate passes, tools/profile.sh); None when
+    no summary of this configuration is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_hbm_pmc.json" % cfg_tag))) if cfg_tag else []
     if not files:
         return None, None
     try:
@@ -177,12 +178,13 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
-def rocprof_avg_us(kernel_substr):
-    """Average duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary (tools/profile.sh), for
-    cross-reference with the live HIP-event figure (which includes ~2.5 us of event-node overhead); None if absent."""
+def rocprof_avg_us(kernel_substr, cfg_tag):
+    """Average duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary of THIS configuration
+    (tools/profile.sh), for cross-reference with the live HIP-event figure (which includes ~2.5 us of event-node
+    overhead); None if absent."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_kernel_stats.csv" % cfg_tag))) if cfg_tag else []
     if not files:
         return None, None
     try:
@@ -375,8 +377,10 @@ def main():
         dom = max(prof, key=lambda k: prof[k][0])          # dominant = largest share of the decode step
         ms1, cnt1, bytes1 = prof[dom]
         achieved = (bytes1 / (ms1 * 1e-3)) / 1e9 if ms1 > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(KPMC[dom])
-        rp_us, rp_src = rocprof_avg_us(KPMC[dom])
+        # which committed profile belongs to this run: BASELINE configs[1] (the headline), the configs[2]-sized batch, the configs[4] shard
+        cfg_tag = {(32, False): "cfg2", (128, False): "cfg3", (64, True): "cfg5"}.get((args.batch_per_gpu, bool(args.mixed)))
+        traffic, traffic_src = pmc_traffic(KPMC[dom], cfg_tag)
+        rp_us, rp_src = rocprof_avg_us(KPMC[dom], cfg_tag)
         step_us = sum(v[0] for v in prof.values()) * 1e3
         step_bytes = sum(v[2] for v in prof.values())
         # the decode step's GEMM work (prenet-1, query, both LSTM cells, projection + fused prenet-0): what bounds it at batches
