@@ -478,7 +478,8 @@ hipError_t gt_conv5_bf16_init() {
 // One workgroup owns 64 tiles (128 output rows) x 128 columns; each of the six GEMMs has its own 32 x 32 accumulator tile per wave,
 // advanced one 32-channel slice at a time in turn (the slice's input rows are fetched once for all six), and the output
 // transform is the epilogue's (V never touches memory, no cross-workgroup reduction).
-// Measured error on the postnet's shapes: 2-3.6e-6 max-abs at |y| ~ 3 (the direct fp32 sum: 1.1e-6) -- tools/wino_error.py.
+// Measured error on the postnet's shapes: 2-3.6e-6 max-abs at |y| ~ 3 (the direct fp32 sum: 1.1e-6) --
+// tests/test_gpu_configs.py::test_winograd_postnet_matches_the_oracle_and_the_implicit_gemm prints all three variants' errors.
 // Applies to: taps == 5, pad_before == 2, Cin % 32 == 0, no pooling, no 2-D mode.
 // Transform rows at compile time.  MO = outputs per tile: 2 -> F(2,5), points 0, +-1, +-1/2, inf (6 GEMMs per 2 outputs, 0.6x
 // the multiplications of the direct sum); 4 -> F(4,5), points 0, +-1, +-1/2, +-2, inf (8 GEMMs per 4 outputs, 0.4x).
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5_kernel(ConvGemmArgs A, co
     // follow each other, each on its own accumulator, so that the slice's raw input rows are fetched ONCE (into dE / dO, even /
     // odd slices, seven steps ahead) instead of once per GEMM -- the pass-major order moved 61 KB per step and CU through the
     // L1 (1 630 cycles per step with the MFMAs taken out, against 2 050 of MFMA), this one 24 KB.  Per step: request the B
-    // slice of step g + 2 (two register sets by step parity), at XI = 0 the next slice's taps; the MFMAs on the current LDS
+    // slice of the next step (one register set, bP0 / bP1), at XI = 0 the next slice's taps; the MFMAs on the current LDS
     // stage; transform + store the operands of step g + 1 into the other stage; barrier.  Nothing pins the order inside a
     // step: left to the scheduler, the transform's VALU work and the LDS writes land between the dependent MFMAs.  Slices are
     // unrolled by two so that the tap sets are named statically; every load is unconditional, so every wait is a counted one.
@@ -641,8 +642,6 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5_kernel(ConvGemmArgs A, co
     const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, (int)((size_t)AL * A.wino_cin * A.N * 4), 0x00020000);
     const uint32_t vb0 = (uint32_t)(((tid >> 5) * A.N + min(n0 + (tid & 31) * 4, A.N - 4)) * 4);   // (columns past N are never stored)
     const uint32_t vb1 = vb0 + (uint32_t)(16 * A.N * 4);
-#define WINO_BSET0 bP0, bP1
-#define WINO_BSET1 bQ0, bQ1
     // (ablation switches of tools/wino_bench.hip; the product compiles the plain forms)
 #ifdef GT_WINO_NO_MFMA
 #define WINO_ABL_MMA(ACC) do { ACC[0] += As[cur][tid & 31] + Bs[cur][tid & 31]; } while (0)
