@@ -335,8 +335,8 @@ def main():
         # both decode LSTM cells ran as ONE launch (gt_lstm12_kernel, in-kernel hand-off of h1): one bracket, both cells' bytes
         prof[0] = (prof[0][0], prof[0][1], prof[0][2] + prof[1][2])
         del prof[1]
-        KNAMES[0] = "gt_lstm12_kernel (both LSTM cells: input halves + gates, h1 handed over in-kernel)"
-        KPMC[0] = "gt_lstm12_kernel"
+        KNAMES[0] = ("gt_lstm12_mc_kernel" if big else "gt_lstm12_kernel") + " (both LSTM cells: input halves + gates, h1 handed over in-kernel)"
+        KPMC[0] = "gt_lstm12_mc_kernel" if big else "gt_lstm12_kernel"
     # An event-record node is a graph node of its own, so a bracketed kernel reads ~2-3 us longer than rocprofv3
     # --kernel-trace reports for it (profiles/*_kernel_stats.csv); the figures are NOT corrected (conservative: the
     # roofline fraction is understated).  The empty bracket (two event nodes back to back) is reported for reference.

@@ -829,9 +829,12 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     HIPCHECK(c, gt_launch_zero(c->w_c2, (size_t)B * H2, s));
     if (g.att_type == GSTTACO_ATT_LSA) HIPCHECK(c, gt_launch_zero(c->w_lsa_state, (size_t)B * Tv, s));   // Layers.py:356
     // both LSTM cells in one launch (skinny_gemm.hip gt_lstm12_kernel): fp32 lean shapes, batch <= 32, one live context
-    const bool fuse12 = c->fuse12_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && !c->lstm_x[0].bf16 && !c->lstm_x[1].bf16 &&
-                        g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv) &&
-                        gt_lstm12_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->n_cu);
+    // (batch <= 32: fp32; above: the multi-chunk form, fp32 or bf16)
+    const bool fuse_base = c->fuse12_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->lstm_x[0].bf16 == c->lstm_x[1].bf16 &&
+                           g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv);
+    const bool fuse12_small = fuse_base && !c->lstm_x[0].bf16 && gt_lstm12_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->n_cu);
+    const bool fuse12_mc = fuse_base && gt_lstm12_mc_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->n_cu);
+    const bool fuse12 = fuse12_small || fuse12_mc;
     if (fuse12) HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_arrive), (size_t)steps * 256, s));
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
@@ -988,8 +991,10 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             }
             fa.arrive = c->w_arrive + (size_t)t * 256;
             fa.err = c->w_err;
-            fa.expect = (uint32_t)((H1 + 3) / 4) + (c->debug_drop_member >= 0 ? 1u : 0u);
+            fa.expect = (uint32_t)(fuse12_mc ? gt_lstm12_mc_grid(H1) : (H1 + 3) / 4) + (c->debug_drop_member >= 0 ? 1u : 0u);
             if (prof) { int rce = prof_begin(0); if (rce) return rce; }
+            if (fuse12_mc) HIPCHECK(c, gt_launch_lstm12_mc(fa, c->lstm_x[0].bf16 != 0, s));
+            else
             HIPCHECK(c, gt_launch_lstm12(fa, s));
             if (prof) { int rce = prof_end(0); if (rce) return rce; }
         } else

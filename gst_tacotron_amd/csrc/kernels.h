@@ -96,6 +96,9 @@ struct Lstm12Args {
 };
 bool gt_lstm12_supported(int nkb1, int nkb2, int H1, int H2, int M, int n_cu);
 hipError_t gt_launch_lstm12(const Lstm12Args& a, hipStream_t stream);
+bool gt_lstm12_mc_supported(int nkb1, int nkb2, int H1, int H2, int M, int n_cu);      // the same at batches above 32 rows (fp32 / bf16)
+int gt_lstm12_mc_grid(int H);
+hipError_t gt_launch_lstm12_mc(const Lstm12Args& a, bool bf16, hipStream_t stream);
 hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, bool bf16, hipStream_t stream);
 
 // One time step of a Bidirectional LSTM (reference Taco2.py:39-43, 394-398) whose input halves x_t . W_x + b were hoisted

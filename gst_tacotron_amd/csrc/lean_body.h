@@ -266,18 +266,52 @@ __device__ __forceinline__ void gt_lean_partial(const LeanPartialArgs& A, const 
 // two M-tiles' activations of k-block i -- so all waves' k-block 0 is served first and the MFMAs of k-block i run while k-block
 // i + 1 .. are still arriving; and inside the loop the NEXT chunk's activations of k-block i are requested right behind the
 // MFMAs that consumed k-block i, one request per 8 NT MFMAs instead of a burst that would stall every wave's MFMA issue at once.
-template <int NW, int KPW, int NT, bool BF16, bool NTW, class Pre, class Epi>
-__device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const int tile0, const int ntile, const LeanX X, const int nkb32,
-                                           const int MT, const int c0, const int c1, float* lds, Pre pre, Epi epi,
-                                           unsigned long long* dbg = nullptr) {
+// Weight fragments of a workgroup's NT tiles for its wave's k-blocks: float4 (fp32) or uint4 (bf16 pack) per (k-block, tile).
+template <int KPW, int NT, bool BF16>
+struct LeanW {
+    float4 f[BF16 ? 1 : KPW][BF16 ? 1 : NT];
+    u32x4 h[BF16 ? KPW : 1][BF16 ? NT : 1];
+};
+template <int NW, int KPW, int NT, bool BF16, bool NTW>
+__device__ __forceinline__ void gt_lean_mc_load_w(const float* __restrict__ wp, const int tile0, const int ntile, const int nkb32,
+                                                  LeanW<KPW, NT, BF16>& W) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (BF16) {
+        const u32x4* wl = reinterpret_cast<const u32x4*>(wp) + ((size_t)tile0 * nkb32 + wave) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int ic = (wave + i * NW < nkb32) ? i : 0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const u32x4* src = wl + ((size_t)(j < ntile ? j : 0) * nkb32 + ic * NW) * 64;
+                W.h[i][j] = NTW ? __builtin_nontemporal_load(src) : *src;
+            }
+        }
+    } else {
+        constexpr int NKB = NW * KPW;
+        const float4* wl = reinterpret_cast<const float4*>(wp) + ((size_t)tile0 * NKB + wave) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) W.f[i][j] = wl[((size_t)(j < ntile ? j : 0) * NKB + i * NW) * 64];
+    }
+}
+
+// PRE: the weight fragments were requested by the caller (gt_lean_mc_load_w) -- the fused LSTM launch does that before it waits
+// for the other workgroups' layer-1 state -- and only the activations are requested here.
+template <int NW, int KPW, int NT, bool BF16, bool NTW, bool PRE, class Pre, class Epi>
+__device__ __forceinline__ void gt_lean_mc_impl(const float* __restrict__ wp, const int tile0, const int ntile, const LeanX X, const int nkb32,
+                                                const int MT, const int c0, const int c1, float* lds, Pre pre, Epi epi,
+                                                unsigned long long* dbg, LeanW<KPW, NT, BF16>& WPRE) {
     // diagnostic stamps of block 0 (tools/stamps_batch.py): 0 = first chunk's loads requested, 2 = its MFMAs issued (+ the next
     // chunk's loads requested), 3 = its partial sums in LDS (barrier passed), 5 = its epilogue done; 6 = end
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if constexpr (BF16) {
-        uint4 b[KPW][NT];
+        u32x4 (&b)[KPW][NT] = WPRE.h;
         float4 xa[KPW][2], xb[KPW][2];
-        const uint4* wl = reinterpret_cast<const uint4*>(wp) + ((size_t)tile0 * nkb32 + wave) * 64 + lane;
+        const u32x4* wl = reinterpret_cast<const u32x4*>(wp) + ((size_t)tile0 * nkb32 + wave) * 64 + lane;
         const LeanXR XR = gt_x_rsrc(X);
         auto xld = [&](const int i, const int hf, const int mt) {
             const int kb32 = (wave + i * NW < nkb32) ? wave + i * NW : wave;    // wave-uniform; past the end: re-read, never multiplied
@@ -288,14 +322,11 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
 #pragma unroll
             for (int i = 0; i < KPW; ++i) {
                 const int ic = (wave + i * NW < nkb32) ? i : 0;
+                if constexpr (!PRE) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const uint4* src = wl + ((size_t)(j < ntile ? j : 0) * nkb32 + ic * NW) * 64;
-                    if (NTW) {
-                        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
-                        b[i][j] = make_uint4(t[0], t[1], t[2], t[3]);
-                    } else {
-                        b[i][j] = *src;
+                    for (int j = 0; j < NT; ++j) {
+                        const u32x4* src = wl + ((size_t)(j < ntile ? j : 0) * nkb32 + ic * NW) * 64;
+                        b[i][j] = NTW ? __builtin_nontemporal_load(src) : *src;
                     }
                 }
 #pragma unroll
@@ -344,7 +375,8 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
         GT_STAMP(dbg, 6);
     } else {
         constexpr int NKB = NW * KPW;
-        float4 b[KPW][NT], xa[KPW], xb[KPW];
+        float4 (&b)[KPW][NT] = WPRE.f;
+        float4 xa[KPW], xb[KPW];
         const float4* wl = reinterpret_cast<const float4*>(wp) + ((size_t)tile0 * NKB + wave) * 64 + lane;
         const LeanXR XR = gt_x_rsrc(X);
         auto xld = [&](const int i, const int mt) { return gt_xload(XR, X, wave + i * NW, MT, mt); };
@@ -352,15 +384,17 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
             const int ma = 2 * c0, mb = min(2 * c0 + 1, MT - 1);
 #pragma unroll
             for (int i = 0; i < KPW; ++i) {
+                if constexpr (!PRE) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    // (a pair's second tile beyond the matrix re-reads the first: loaded, multiplied, never stored)
-                    const float4* src = wl + ((size_t)(j < ntile ? j : 0) * NKB + i * NW) * 64;
-                    if (NTW) {
-                        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-                        b[i][j] = make_float4(t[0], t[1], t[2], t[3]);
-                    } else {
-                        b[i][j] = *src;
+                    for (int j = 0; j < NT; ++j) {
+                        // (a pair's second tile beyond the matrix re-reads the first: loaded, multiplied, never stored)
+                        const float4* src = wl + ((size_t)(j < ntile ? j : 0) * NKB + i * NW) * 64;
+                        if (NTW) {
+                            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+                            b[i][j] = make_float4(t[0], t[1], t[2], t[3]);
+                        } else {
+                            b[i][j] = *src;
+                        }
                     }
                 }
                 xa[i] = xld(i, ma);
@@ -414,6 +448,14 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
         }
         GT_STAMP(dbg, 6);
     }
+}
+
+template <int NW, int KPW, int NT, bool BF16, bool NTW, class Pre, class Epi>
+__device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const int tile0, const int ntile, const LeanX X, const int nkb32,
+                                           const int MT, const int c0, const int c1, float* lds, Pre pre, Epi epi,
+                                           unsigned long long* dbg = nullptr) {
+    LeanW<KPW, NT, BF16> W;
+    gt_lean_mc_impl<NW, KPW, NT, BF16, NTW, false>(wp, tile0, ntile, X, nkb32, MT, c0, c1, lds, pre, epi, dbg, W);
 }
 
 // Recurrent-half worker job over chunks [c0, c1): gt_lean_partial's result for each, the job's weights read once.

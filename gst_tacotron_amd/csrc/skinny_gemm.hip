@@ -300,23 +300,12 @@ hipError_t gt_launch_lstm12(const Lstm12Args& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Batches above 32 rows (lean_body.h, "Batches above 32 rows"): a workgroup owns a PAIR of tiles (8 hidden units) and half of
-// the batch's 32-row chunks, keeps the pair's weights in registers over its chunks and multiplies every activation fragment
-// with both tiles.  The two workgroups of a pair sit 8 block indices apart = on one XCD under the round-robin block -> XCD
-// deal (speed only), so the pair's weights leave the Infinity Cache once.  Per chunk the arithmetic is gt_lstm_x_kernel's:
-// the states are bitwise the same.
-template <int NW, int KPW, int TAG, bool BF16>
-__global__ __launch_bounds__(NW * 64) void gt_lstm_x_mc_kernel(LstmXArgs A) {
-    static_assert(NW * 64 == 512, "one (row, col) element of each of the two tiles per thread");
-    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 2>::kFloats];
-    const int ntiles = (A.H + 3) / 4, npairs = (ntiles + 1) / 2;
-    const int pair = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), rpart = ((int)blockIdx.x >> 3) & 1;
-    if (pair >= npairs) return;
-    const int tile0 = pair * 2, ntile = min(2, ntiles - tile0), MT = A.MT;
-    const int mchunks = (A.M + 31) / 32, csplit = (mchunks + 1) / 2;
-    const int c0 = rpart == 0 ? 0 : csplit, c1 = rpart == 0 ? csplit : mchunks;
-    if (c0 >= c1) return;
-    GT_STAMP(A.dbg, 4);
+// (pair of tiles, chunks [c0, c1)) of one decode LSTM cell.  WT: h is stored write-through (read by other workgroups of the same
+// launch); PRE: the pair's weights were requested by the caller (LeanW W).
+template <int NW, int KPW, bool BF16, bool WT, bool PRE>
+__device__ __forceinline__ void gt_lstm_x_mc_body(const LstmXArgs& A, const int tile0, const int ntile, const int c0, const int c1, float* lds,
+                                                  LeanW<KPW, 2, BF16>& W) {
+    const int MT = A.MT;
     const float (*part)[NW][32][17] = reinterpret_cast<const float (*)[NW][32][17]>(lds);
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
     float pin[2], c_prev[2];
@@ -340,21 +329,104 @@ __global__ __launch_bounds__(NW * 64) void gt_lstm_x_mc_kernel(LstmXArgs A) {
             const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
             const int unit = (tile0 + j) * 4 + col;
             if (j < ntile && col < 4 && grow < A.M && unit < A.H) {
-                if (A.row_len && A.t_index >= A.row_len[grow]) {
-                    A.h[gt_blk_off(grow, unit, MT)] = 0.f;          // masked mode: this step does not exist for this utterance
-                } else {
+                float hv = 0.f;                                     // masked mode: a step that does not exist for this utterance writes 0
+                if (!(A.row_len && A.t_index >= A.row_len[grow])) {
                     const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
                     const float c2 = __builtin_fmaf(gf, c_prev[j], gi * gg);
                     A.c[(size_t)grow * A.H + unit] = c2;
-                    A.h[gt_blk_off(grow, unit, MT)] = go * gt_tanh(c2);
+                    hv = go * gt_tanh(c2);
                 }
+                if (WT) gt_st1_sc1(A.h + gt_blk_off(grow, unit, MT), hv);
+                else A.h[gt_blk_off(grow, unit, MT)] = hv;
             }
         }
     };
-    gt_lean_mc<NW, KPW, 2, BF16, false>(A.wp, tile0, ntile, LeanX{A.x, A.x, BF16 ? A.nkb : NW * KPW}, (A.nkb + 1) >> 1, MT, c0, c1, lds, pre, epi,
-                                        A.dbg);
+    gt_lean_mc_impl<NW, KPW, 2, BF16, false, PRE>(A.wp, tile0, ntile, LeanX{A.x, A.x, BF16 ? A.nkb : NW * KPW}, (A.nkb + 1) >> 1, MT, c0, c1, lds,
+                                                  pre, epi, A.dbg, W);
 }
 
+// which (pair, chunk range) a workgroup of the 1-D grid owns: the two workgroups of a pair sit 8 block indices apart
+__device__ __forceinline__ bool gt_lstm_mc_job(const LstmXArgs& A, int& tile0, int& ntile, int& c0, int& c1) {
+    const int ntiles = (A.H + 3) / 4, npairs = (ntiles + 1) / 2;
+    const int pair = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), rpart = ((int)blockIdx.x >> 3) & 1;
+    tile0 = pair * 2; ntile = min(2, ntiles - tile0);
+    const int mchunks = (A.M + 31) / 32, csplit = (mchunks + 1) / 2;
+    c0 = rpart == 0 ? 0 : csplit; c1 = rpart == 0 ? csplit : mchunks;
+    return pair < npairs && c0 < c1;
+}
+
+template <int NW, int KPW, int TAG, bool BF16>
+__global__ __launch_bounds__(NW * 64) void gt_lstm_x_mc_kernel(LstmXArgs A) {
+    static_assert(NW * 64 == 512, "one (row, col) element of each of the two tiles per thread");
+    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 2>::kFloats];
+    int tile0, ntile, c0, c1;
+    if (!gt_lstm_mc_job(A, tile0, ntile, c0, c1)) return;
+    GT_STAMP(A.dbg, 4);
+    LeanW<KPW, 2, BF16> W;
+    gt_lstm_x_mc_body<NW, KPW, BF16, false, false>(A, tile0, ntile, c0, c1, lds, W);
+}
+
+// Both cells in one launch at batches above 32 rows: gt_lstm12_kernel's protocol on the multi-chunk bodies.  Every workgroup
+// runs its (pair, chunk half) of layer 1, arrives, requests its pair's layer-2 weights, waits for all arrivals and runs the
+// same (pair, chunk half) of layer 2.  (Workgroups without a job -- a padded pair index -- arrive at once and leave.)
+template <int KPW1, int KPW2, bool BF16>
+__global__ __launch_bounds__(512) void gt_lstm12_mc_kernel(Lstm12Args P) {
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) float lds[LeanLds<NW, 2>::kFloats];
+    __shared__ int s_abort;
+    const int lane = threadIdx.x & 63;
+    int tile0, ntile, c0, c1;
+    const bool job = gt_lstm_mc_job(P.l1, tile0, ntile, c0, c1);
+    if (threadIdx.x == 0) s_abort = 0;
+    GT_STAMP(P.l1.dbg, 4);
+    if (job) {
+        LeanW<KPW1, 2, BF16> W1;
+        gt_lstm_x_mc_body<NW, KPW1, BF16, true, false>(P.l1, tile0, ntile, c0, c1, lds, W1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&P.arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!job) return;
+    LeanW<KPW2, 2, BF16> W2;
+    gt_lean_mc_load_w<NW, KPW2, 2, BF16, false>(P.l2.wp, tile0, ntile, (P.l2.nkb + 1) >> 1, W2);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x < 64) {
+        uint32_t spins = 0;
+        for (;;) {
+            uint32_t v = lane < 8 ? gt_ldu_sc1(P.arrive + lane * 32) : 0u;
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) v += __shfl_xor(v, d, 64);
+            if (__builtin_amdgcn_readfirstlane(v) >= P.expect) break;
+            ++spins;
+            if (spins > (1u << 18)) { if (lane == 0) { atomicOr(P.err, 1u); s_abort = 1; } break; }
+            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(gt_ldu_sc1(P.err)) != 0u) { if (lane == 0) s_abort = 1; break; }
+        }
+    }
+    __syncthreads();
+    if (s_abort) return;
+    GT_STAMP(P.l2.dbg, 4);
+    gt_lstm_x_mc_body<NW, KPW2, BF16, false, true>(P.l2, tile0, ntile, c0, c1, lds, W2);
+}
+
+// batches above 32 rows (fp32 and bf16): grid = pairs of tiles (rounded up to 8) x 2 chunk halves, as gt_lstm_x_mc_kernel's
+bool gt_lstm12_mc_supported(int nkb1, int nkb2, int H1, int H2, int M, int n_cu) {
+    return nkb1 == 24 && nkb2 == 64 && H1 == H2 && H1 % 4 == 0 && M > 32 && (((H1 + 3) / 4 + 1) / 2 + 7) / 8 * 16 <= 2 * n_cu;
+}
+int gt_lstm12_mc_grid(int H) { return (((H + 3) / 4 + 1) / 2 + 7) / 8 * 16; }
+
+hipError_t gt_launch_lstm12_mc(const Lstm12Args& a, bool bf16, hipStream_t stream) {
+    const dim3 g(gt_lstm12_mc_grid(a.l1.H));
+    if (bf16) hipLaunchKernelGGL((gt_lstm12_mc_kernel<2, 4, true>), g, dim3(512), 0, stream, a);
+    else hipLaunchKernelGGL((gt_lstm12_mc_kernel<3, 8, false>), g, dim3(512), 0, stream, a);
+    return hipGetLastError();
+}
+
+// Batches above 32 rows (lean_body.h, "Batches above 32 rows"): a workgroup owns a PAIR of tiles (8 hidden units) and half of
+// the batch's 32-row chunks, keeps the pair's weights in registers over its chunks and multiplies every activation fragment
+// with both tiles.  The two workgroups of a pair sit 8 block indices apart = on one XCD under the round-robin block -> XCD
+// deal (speed only), so the pair's weights leave the Infinity Cache once.  Per chunk the arithmetic is gt_lstm_x_kernel's:
+// the states are bitwise the same.
 bool gt_lstm_x_supported(int nkb) { return nkb == 24 || nkb == 64; }
 
 template <int TAG>
