@@ -1,0 +1,29 @@
+"""Stress check of the in-kernel hand-offs: whole Inference_Steps (all 500 decode steps, throughput-mode randomness) with the fused
+LSTM launch, repeated, against the two-launch form -- bitwise.  A stale read in the hand-off would show up as a difference.
+    python tools/fused_stress.py [batch] [reps] [--mixed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gst_tacotron_amd import synthetic, weights
+from gst_tacotron_amd.model import GST_Tacotron
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 32
+reps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 10
+hp, inputs = synthetic.config_inputs("cfg2", batch=B)
+hp["Use_Mixed_Precision"] = "--mixed" in sys.argv
+w = weights.synthetic_weights(hp, seed=0)
+outs = {}
+for flag in ("0", "1"):
+    os.environ["GSTTACO_FUSED_LSTM"] = flag
+    m = GST_Tacotron(hyper_parameters=hp, max_batch=B, max_tokens=128, max_ref_frames=257)
+    m.Restore(weights=w)
+    res = []
+    for i in range(reps):
+        mel, stop, _, align = m.Inference_Step(inputs["tokens"], None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"], seed=100 + i)
+        res.append((mel.cpu().numpy(), align.cpu().numpy()))
+    m.synchronize()
+    assert m.handoff_error() == 0
+    outs[flag] = res
+    del m
+bad = sum(int(not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))) for a, b in zip(outs["0"], outs["1"]))
+print("batch", B, "mixed" if hp["Use_Mixed_Precision"] else "fp32", ":", reps, "Inference_Steps x 500 decode steps, fused vs two launches:", bad, "differ")
+sys.exit(1 if bad else 0)
