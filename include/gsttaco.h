@@ -249,25 +249,28 @@ int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
 /* Diagnostic (GSTTACO_STAMPS=1): 3 x 16 phase stamps (100 MHz ticks) of workgroup 0 of the fused front kernel
  * and the two decode LSTM kernels at the middle decode step of the last replay.  Synchronises the device. */
 int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
-/* The persistent BiLSTM launch (one launch for all time steps of the encoder's / vocoder's Bidirectional LSTM, reference
- * Taco2.py:39-43, 394-398) hands its state around inside the kernel and needs the 32 workgroups of each of its groups resident
- * together.  The library arranges that for everything it controls: exactly one workgroup per compute unit is checked at
- * finalize, and the launches of ALL contexts of the process are chained on the GPU, so two of them never split an XCD.  What
- * it cannot see -- another process on the GPU, a CU mask -- is caught by BOUNDED waits: a wait that gives up raises a word in
- * host-mapped memory, the whole launch drains at once, and
+/* Two launches hand data between their workgroups INSIDE the kernel and therefore need those workgroups resident together: the
+ * persistent BiLSTM launch (one launch for all time steps of the encoder's / vocoder's Bidirectional LSTM, reference
+ * Taco2.py:39-43, 394-398; the 32 workgroups of each of its groups) and the fused decode-LSTM launch (both LSTMCells of a decoder
+ * step, Taco2.py:77-85,111, in one launch; all of its workgroups).  The library arranges that for everything it controls:
+ * exactly one persistent workgroup per compute unit is checked at finalize; the persistent launches of ALL contexts of the
+ * process are chained on the GPU, so two of them never split an XCD; the fused decode launch is taken only while the process
+ * has ONE live context.  What it cannot see -- another process on the GPU, a CU mask -- is caught by BOUNDED waits: a wait that
+ * gives up raises a word in host-mapped memory, the whole launch drains at once, and
  *   - gsttaco_synchronize(ctx, stream) synchronises the stream and returns GSTTACO_E_HIP if that happened since the last check:
  *     the outputs of those calls are invalid, repeat them;
- *   - the NEXT compute call on the context clears the word, switches the context to one BiLSTM launch per time step (same
+ *   - the NEXT compute call on the context clears the word, switches the context to the launch-per-step / two-launch form (same
  *     results, no co-residency needed), succeeds, and leaves a "warning: ..." text in gsttaco_last_error.
- * Nothing stays poisoned and nothing hangs.  gsttaco_debug_handoff_error synchronises the device and returns the word now
- * (bit 8: persistent BiLSTM; 0 = clear). */
+ * Nothing stays poisoned and nothing hangs.  gsttaco_debug_handoff_error synchronises the device and returns the words now
+ * (bit 0: fused decode-LSTM launch, bit 8: persistent BiLSTM; 0 = clear). */
 int gsttaco_synchronize(gsttaco_ctx* ctx, void* stream);
 int gsttaco_debug_handoff_error(gsttaco_ctx* ctx, uint32_t* host_out);
 /* Test support: out[0] = persistent BiLSTM launches this context has enqueued (eagerly or into a captured graph), out[1] = 1
  * while the context uses the persistent launch, 0 once it has fallen back to one launch per time step. */
 int gsttaco_debug_counters(const gsttaco_ctx* ctx, uint64_t out[2]);
-/* Test support (fault injection).  bits 8..15: raise the give-up word as a kernel would.  bits 16..: n > 0 makes member n - 1
- * of every group of the NEXT persistent launches exit at once, so that their waits really run into the bound. */
+/* Test support (fault injection).  bits 0..7 / 8..15: raise the fused launch's / the persistent BiLSTM's give-up word as a kernel
+ * would.  bits 16..: n > 0 makes member n - 1 of every group of the NEXT persistent launches exit at once and the next fused
+ * launches expect one arrival too many, so that their waits really run into the bound. */
 int gsttaco_debug_raise_handoff_error(gsttaco_ctx* ctx, uint32_t bits);
 /* Test support: the prenet keep-masks [steps][mask0 B*P0 | mask1 B*P1] (0/1) and SMA noise [steps][B][Tv] the LAST
  * gsttaco_inference_step / gsttaco_decode of that shape used -- generated from the seed in throughput mode, or the
