@@ -311,6 +311,9 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # an in-kernel hand-off that gave up (persistent BiLSTM / fused LSTM launch without co-residency) would have produced garbage at full
+    # speed: fail here rather than report a number for it (gsttaco_synchronize; the clock has stopped)
+    model.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
