@@ -2198,6 +2198,7 @@ int gsttaco_debug_raise_handoff_error(gsttaco_ctx* c, uint32_t bits) {
     c->h_err[1] |= (bits >> 8) & 0xFFu;
     if (bits >> 16) {               // fault injection for real: member (bits >> 16) - 1 of every group of the NEXT persistent launches exits
         c->debug_drop_member = (int)(bits >> 16) - 1;                // at once, so the launch's waits run into their bound
+        HIPCHECK(c, hipDeviceSynchronize());                           // (an executable may still be running)
         for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // (captured launches carry the old argument)
         c->graphs.clear();
     }
