@@ -145,8 +145,11 @@ def test_config5_two_utterances_against_the_bf16_emulating_oracle():
     print("bf16 path vs emulating oracle over 500 steps: pre-net mel max %.3g mean %.3g | mel max %.3g mean %.3g | alignment %.3g"
           " | emulated-mixed vs fp32 oracle %.3g" % (e_pre.max(), e_pre.mean(), e_mel.max(), e_mel.mean(), e_al, drift))
     assert mel.shape == (2, 1000, 80)
-    assert e_pre.max() <= MIXED_TOL and e_pre.mean() <= MIXED_MEAN
-    assert e_mel.max() <= MIXED_TOL and e_mel.mean() <= MIXED_MEAN and e_al <= MIXED_TOL
+    # the decode loop's own outputs (500 recurrent steps on bf16 operands) are held to 5e-3 max / 5e-4 mean (measured 1.6e-3 /
+    # 1.2e-4, alignments 3e-4); only behind the 5-layer postnet, which re-rounds them to bf16 and amplifies a flipped rounding
+    # ~10x per layer, does the wider mixed tolerance apply (measured 8.9e-3 / 1.1e-3)
+    assert e_pre.max() <= 5e-3 and e_pre.mean() <= 5e-4 and e_al <= 2e-3
+    assert e_mel.max() <= MIXED_TOL and e_mel.mean() <= MIXED_MEAN
     assert 0.0 < drift <= 0.25
 
 
