@@ -76,6 +76,13 @@ std::string g_create_error;
 std::atomic<int> g_live_contexts{0};
 std::mutex g_persist_mu;
 std::map<int, hipEvent_t> g_persist_event;      // device -> completion of the last persistent segment enqueued by this process
+// The fused decode-LSTM launches need ALL their workgroups co-resident, which one decode loop alone on the GPU has.  The host takes
+// them only while the process has one live context -- but a graph full of them may still be RUNNING when a second context is
+// created and starts enqueueing.  So the completion of the last segment that contained fused launches is recorded per device, and
+// the first thing any OTHER context's segment does is wait for it on the GPU: work in flight is what is guarded, not contexts
+// constructed (guarded by g_persist_mu).
+struct FusedInFlight { hipEvent_t ev = nullptr; const gsttaco_ctx* owner = nullptr; };
+std::map<int, FusedInFlight> g_fused_event;
 
 }  // namespace
 
@@ -116,8 +123,11 @@ struct gsttaco_ctx {
     PackedLinear prenet0, prenet1, query, val_gst, lstm0, lstm1, proj;
     PackedLinear lstm_x[2], lstm_h[2];   // split packs: input half (critical path) / recurrent half + bias (front-kernel workers)
     float* w_part[2] = {nullptr, nullptr};
-    uint32_t* w_err = nullptr;   // device alias of h_err: [1] persistent BiLSTM give-up word ([0] unused)
+    uint32_t* w_err = nullptr;   // device alias of h_err: [0] fused decode-LSTM launch, [1] persistent BiLSTM give-up word
     uint32_t* h_err = nullptr;
+    uint32_t gave_up = 0;        // sticky: give-ups seen by a later enqueue and not yet reported by gsttaco_synchronize (bit 0 / 1 as h_err)
+    bool announce_warn = false;  // the next compute call leaves `warn` in gsttaco_last_error
+    int fuse12_slots[3] = {0, 0, 0};    // workgroups of gt_lstm12_kernel / gt_lstm12_mc_kernel fp32 / bf16 the device holds at once (occupancy x CUs)
     bool counted = false;        // this context is included in g_live_contexts
     uint64_t n_persist_enqueued = 0;     // persistent BiLSTM launches enqueued (eagerly or into a captured graph)
     bool split_rec = true;       // recurrent halves of the decode LSTMs computed beside the front end / projection (GSTTACO_DEBUG: SPLIT_REC=0)
@@ -832,8 +842,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     // (batch <= 32: fp32; above: the multi-chunk form, fp32 or bf16)
     const bool fuse_base = c->fuse12_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->lstm_x[0].bf16 == c->lstm_x[1].bf16 &&
                            g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv);
-    const bool fuse12_small = fuse_base && !c->lstm_x[0].bf16 && gt_lstm12_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->n_cu);
-    const bool fuse12_mc = fuse_base && gt_lstm12_mc_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->n_cu);
+    const bool fuse12_small = fuse_base && !c->lstm_x[0].bf16 && gt_lstm12_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->fuse12_slots[0]);
+    const bool fuse12_mc = fuse_base && gt_lstm12_mc_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->fuse12_slots[c->lstm_x[0].bf16 ? 2 : 1]);
     const bool fuse12 = fuse12_small || fuse12_mc;
     if (fuse12) HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_arrive), (size_t)steps * 256, s));
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
@@ -1311,38 +1321,71 @@ int check_shape(gsttaco_ctx* c, int B, int Tv, int Tref1, int steps) {
 template <typename F>
 int run_cached_inner(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F body);
 
-// A wait of a persistent BiLSTM launch of an EARLIER call gave up (its members never became co-resident: another process
-// on the GPU, a CU mask, a profiler's kernel): that call's encodings were garbage -- gsttaco_synchronize reports it for the
-// call itself.  Here, at the next call: clear the word, stop using the persistent launch on this context (one launch per time
-// step from now on: no co-residency needed) and say so through gsttaco_last_error as a warning.  Nothing stays poisoned.
-void recover_from_give_up(gsttaco_ctx* c) {
-    if (c->h_err && c->h_err[0]) {      // the fused LSTM launch's hand-off (gt_lstm12_kernel): back to one launch per cell
-        c->h_err[0] = 0;
-        c->fuse12 = false;
-        c->warn = c->err = "warning: the in-kernel hand-off of the fused decode-LSTM launch gave up in an earlier call (its workgroups were not "
-                           "co-resident: is another process or a CU mask sharing this GPU?); that call's outputs were invalid.  This context now "
-                           "runs the two LSTM cells as two launches (same results, ~4 % slower)";
+// A bounded in-kernel wait of an EARLIER enqueue gave up (its workgroups never became co-resident: another process on the GPU,
+// a CU mask, a profiler's kernel): the outputs of the call it belongs to are garbage.  Seen here, at a later enqueue:
+//   * the give-up is remembered in a STICKY per-context word that only gsttaco_synchronize reports and clears ("since the last
+//     check"): a later call -- or a later graph segment of the same call -- must not erase it;
+//   * the context stops using that launch form (two launches per decode step / one launch per BiLSTM time step: no co-residency
+//     needed) and says so through gsttaco_last_error as a warning;
+//   * the device-visible word is NOT cleared here: launches of this context may still be in flight, they poll the word and
+//     leave at once while it is set; cleared, each of up to ~500 remaining fused launches would spin to its full bound.
+//     gsttaco_synchronize clears it behind the stream synchronisation.
+void note_give_up(gsttaco_ctx* c) {
+    if (!c->h_err) return;
+    if (c->h_err[0]) {          // the fused decode-LSTM launch's hand-off (gt_lstm12_kernel): back to one launch per cell
+        c->gave_up |= 1u;
+        if (c->fuse12) {
+            c->fuse12 = false;
+            c->debug_drop_member = -1;
+            c->warn = "warning: the in-kernel hand-off of the fused decode-LSTM launch gave up in an earlier call (its workgroups were not "
+                      "co-resident: is another process or a CU mask sharing this GPU?); that call's outputs were invalid.  This context now "
+                      "runs the two LSTM cells as two launches (same results, ~4 % slower)";
+            c->announce_warn = true;
+        }
     }
-    if (!c->h_err || !c->h_err[1]) return;
-    c->h_err[1] = 0;
-    c->bilstm_persist = false;
-    c->debug_drop_member = -1;
-    c->warn = "warning: a hand-off wait of the persistent BiLSTM launch gave up in an earlier call (its members were not co-resident: is another "
-              "process or a CU mask sharing this GPU?); that call's outputs were invalid.  This context now runs its BiLSTMs with one launch "
-              "per time step (same results, ~0.5 ms slower per call)";
-    c->err = c->warn;
+    if (c->h_err[1]) {
+        c->gave_up |= 2u;
+        if (c->bilstm_persist) {
+            c->bilstm_persist = false;
+            c->debug_drop_member = -1;
+            c->warn = "warning: a hand-off wait of the persistent BiLSTM launch gave up in an earlier call (its members were not co-resident: is "
+                      "another process or a CU mask sharing this GPU?); that call's outputs were invalid.  This context now runs its BiLSTMs with "
+                      "one launch per time step (bitwise the same results in fp32, within the mixed-precision tolerance under "
+                      "Use_Mixed_Precision -- the per-step bf16 kernel sums in a different order; ~0.5 ms slower per call)";
+            c->announce_warn = true;
+        }
+    }
+}
+
+void recover_from_give_up(gsttaco_ctx* c) {
+    note_give_up(c);
+    if (c->announce_warn) { c->err = c->warn; c->announce_warn = false; }
 }
 
 template <typename F>
 int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F body, bool persist_segment = false) {
     recover_from_give_up(c);
-    if (!(persist_segment && c->bilstm_persist)) return run_cached_inner(c, stream, key_in, body);
     std::lock_guard<std::mutex> lock(g_persist_mu);
-    hipEvent_t& ev = g_persist_event[c->cfg.device];
-    if (!ev) HIPCHECK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    else HIPCHECK(c, hipStreamWaitEvent(stream, ev, 0));
-    const int rc = run_cached_inner(c, stream, key_in, body);
-    HIPCHECK(c, hipEventRecord(ev, stream));
+    {   // another context's fused launches may still be in flight: this segment starts behind them (see g_fused_event)
+        auto it = g_fused_event.find(c->cfg.device);
+        if (it != g_fused_event.end() && it->second.ev && it->second.owner != c) HIPCHECK(c, hipStreamWaitEvent(stream, it->second.ev, 0));
+    }
+    int rc = 0;
+    if (!(persist_segment && c->bilstm_persist)) {
+        rc = run_cached_inner(c, stream, key_in, body);
+    } else {
+        hipEvent_t& ev = g_persist_event[c->cfg.device];
+        if (!ev) HIPCHECK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else HIPCHECK(c, hipStreamWaitEvent(stream, ev, 0));
+        rc = run_cached_inner(c, stream, key_in, body);
+        HIPCHECK(c, hipEventRecord(ev, stream));
+    }
+    if (!rc && c->fuse12_now && (key_in.kind == 0 || key_in.kind == 3)) {      // the segment held fused decode launches
+        FusedInFlight& f = g_fused_event[c->cfg.device];
+        if (!f.ev) HIPCHECK(c, hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
+        HIPCHECK(c, hipEventRecord(f.ev, stream));
+        f.owner = c;
+    }
     return rc;
 }
 
@@ -1491,6 +1534,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->bilstm_persist = env_int("GSTTACO_BILSTM_PERSIST", 1) != 0;
     c->fuse12 = env_int("GSTTACO_FUSED_LSTM", 1) != 0;
     c->wino = env_int("GSTTACO_WINO", 4);
+    if (c->wino != 0 && c->wino != 2) c->wino = 4;      // {0, 2, 4}; any other non-zero value (the old boolean's 1 included) means the default
     c->stamps = env_int("GSTTACO_STAMPS", 0) == 1;
 #ifdef GSTTACO_DEBUG
     // experiment knobs, compiled only into -DGSTTACO_DEBUG builds (python -m gst_tacotron_amd.build --debug)
@@ -1524,6 +1568,11 @@ void gsttaco_destroy(gsttaco_ctx* c) {
     for (void* p : c->allocs) (void)hipFree(p);
     if (c->h_err) (void)hipHostFree(c->h_err);
     if (c->counted) g_live_contexts.fetch_sub(1);
+    {
+        std::lock_guard<std::mutex> lock(g_persist_mu);
+        for (auto& kv : g_fused_event)
+            if (kv.second.owner == c) kv.second.owner = nullptr;    // (its work has finished: the caller synchronises before destroying)
+    }
     delete c;
 }
 
@@ -1568,7 +1617,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     if (!strstr(prop.gcnArchName, "gfx950"))
         return fail(c, GSTTACO_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     HIPCHECK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
-
+    if (prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
 
     int rc = 0;
     // ---- encoder
@@ -1859,6 +1908,12 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         c->bilstm_persist = false;
         c->warn = c->err = "warning: the persistent BiLSTM kernel does not get one workgroup per compute unit on this device; using one launch per time step";
     }
+    // the fused decode-LSTM launches hand h1 over in-kernel: their whole grid must be resident (occupancy x CUs of THIS device;
+    // a partition with fewer CUs than the grid simply keeps the two-launch form)
+    for (int i = 0; i < 3; ++i) c->fuse12_slots[i] = gt_lstm12_blocks_per_cu(i) * c->n_cu;
+    if (c->fuse12 && c->H1 == c->H2 && (c->H1 + 3) / 4 > c->fuse12_slots[0])
+        c->warn = c->err = "warning: this device cannot hold the fused decode-LSTM launch's whole grid at once (" + std::to_string((c->H1 + 3) / 4) +
+                           " workgroups, " + std::to_string(c->fuse12_slots[0]) + " resident): the two LSTM cells run as two launches";
     HIPCHECK(c, hipDeviceSynchronize());
     // host copies are no longer needed
     for (auto& t : c->tensors) std::vector<float>().swap(t.data);
@@ -2089,10 +2144,15 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
 int gsttaco_synchronize(gsttaco_ctx* c, void* stream) {
     if (!c) return GSTTACO_E_INVALID;
     HIPCHECK(c, hipStreamSynchronize((hipStream_t)stream));
-    if (c->h_err && (c->h_err[1] | c->h_err[0]))
+    note_give_up(c);
+    if (c->gave_up) {
+        // the ONLY place the give-up words are cleared: behind the synchronisation, nothing of this context polls them any more
+        c->gave_up = 0;
+        c->h_err[0] = 0; c->h_err[1] = 0;
         return fail(c, GSTTACO_E_HIP, "a hand-off wait of the persistent BiLSTM launch / the fused decode-LSTM launch gave up (its members were not co-resident: is another process or "
                                       "a CU mask sharing this GPU?): the outputs of the calls since the last gsttaco_synchronize are invalid.  Repeat "
-                                      "them: the context now uses one launch per time step");
+                                      "them: the context now uses one launch per time step / two launches per decode step");
+    }
     return 0;
 }
 
@@ -2181,7 +2241,8 @@ int gsttaco_debug_randomness(gsttaco_ctx* c, float* host_masks, float* host_nois
 int gsttaco_debug_handoff_error(gsttaco_ctx* c, uint32_t* host_out) {
     if (!c || !host_out || !c->w_err) return GSTTACO_E_INVALID;
     HIPCHECK(c, hipDeviceSynchronize());
-    *host_out = c->h_err[0] | (c->h_err[1] << 8);   // [1] persistent BiLSTM: set until the next compute call recovers from it
+    // pending = raised by a kernel or noted by a later enqueue, and not yet reported by gsttaco_synchronize
+    *host_out = (c->h_err[0] | (c->gave_up & 1u)) | ((c->h_err[1] | ((c->gave_up >> 1) & 1u)) << 8);
     return 0;
 }
 
@@ -2222,23 +2283,27 @@ int64_t gsttaco_lstm_launch_bytes(const gsttaco_ctx* c, int which, int B) {
     // in and once out (the re-reads of the shared activations by every workgroup are NOT algorithmic).
     const int64_t P0 = c->P0, P1 = c->P1, A = c->att, H1 = c->H1, H2 = c->H2, mel = c->cfg.mel_dim, Tv = c->cfg.max_tokens;
     const bool fused = c->fused_front && c->split_rec;
-    auto gemm = [&](int64_t K, int64_t N, int64_t extra_row_floats) { return 4 * (K * N + N) + 4 * (int64_t)B * (K + extra_row_floats); };
+    // weight bytes by the dtype the packs hold: bf16 under Use_Mixed_Precision for the LSTM / projection GEMMs (biases, activations,
+    // partial sums and the prenet / query weights stay fp32)
+    const int64_t wb = c->lstm_x[0].bf16 ? 2 : 4;
+    auto gemm = [&](int64_t K, int64_t N, int64_t extra_row_floats) { return wb * K * N + 4 * N + 4 * (int64_t)B * (K + extra_row_floats); };
     const int64_t ntile2 = (H2 + 3) / 4;
     int64_t co_tiles = std::max<int64_t>(0, std::min<int64_t>(ntile2, c->co_tiles >= 0 ? c->co_tiles : (B > 32 ? 128 : 64)));   // same rule as enqueue_decode
     if (c->proj.nkb < 32) co_tiles = 0;
+    const int64_t rec_tile = wb * H2 * 16 + 4 * 16 + 4 * (int64_t)B * 16;      // one layer-2 recurrent tile: weights + bias + its partial sums
     switch (which) {
         case 0:     // LSTM layer 1: x-half only when the recurrent half runs in the front launch
             return fused ? gemm(P1 + A, 4 * H1, 4 * H1 + 3 * H1) : gemm(P1 + A + H1, 4 * H1, 3 * H1);
         case 1:
             return fused ? gemm(H1, 4 * H2, 4 * H2 + 3 * H2) : gemm(H1 + H2, 4 * H2, 3 * H2);
-        case 2: {   // front: prenet x2 + query weights, processed memory, alignments; + workers' recurrent halves
+        case 2: {   // front: prenet x2 + query weights (fp32 in every mode), processed memory, alignments; + workers' recurrent halves
             int64_t b = 4 * (mel * P0 + P0 + P0 * P1 + P1 + P1 * A + A) + 4 * (int64_t)B * (Tv * A + mel + 2 * Tv + P1 + A);
-            if (fused) b += gemm(H1, 4 * H1, 4 * H1) + (ntile2 - co_tiles) * (4 * (H2 * 16 + 16) + 4 * (int64_t)B * 16) + 4 * (int64_t)B * H2;
+            if (fused) b += gemm(H1, 4 * H1, 4 * H1) + (ntile2 - co_tiles) * rec_tile + 4 * (int64_t)B * H2;
             return b;
         }
         default: {  // projection (+ co-scheduled layer-2 recurrent tiles)
             int64_t b = gemm(H2 + A, c->proj_out, c->proj_out);
-            if (fused) b += co_tiles * (4 * (H2 * 16 + 16) + 4 * (int64_t)B * 16);
+            if (fused) b += co_tiles * rec_tile;
             return b;
         }
     }

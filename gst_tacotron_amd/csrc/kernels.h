@@ -94,9 +94,10 @@ struct Lstm12Args {
     uint32_t* err;              // host-mapped give-up word
     uint32_t expect;            // arrivals to wait for = the grid size (fault injection: one more, so the wait runs into its bound)
 };
-bool gt_lstm12_supported(int nkb1, int nkb2, int H1, int H2, int M, int n_cu);
+bool gt_lstm12_supported(int nkb1, int nkb2, int H1, int H2, int M, int slots);      // slots: resident workgroups = occupancy x CUs
+int gt_lstm12_blocks_per_cu(int which);     // occupancy of the fused kernels: 0 = gt_lstm12_kernel, 1 / 2 = gt_lstm12_mc_kernel fp32 / bf16
 hipError_t gt_launch_lstm12(const Lstm12Args& a, hipStream_t stream);
-bool gt_lstm12_mc_supported(int nkb1, int nkb2, int H1, int H2, int M, int n_cu);      // the same at batches above 32 rows (fp32 / bf16)
+bool gt_lstm12_mc_supported(int nkb1, int nkb2, int H1, int H2, int M, int slots);     // the same at batches above 32 rows (fp32 / bf16)
 int gt_lstm12_mc_grid(int H);
 hipError_t gt_launch_lstm12_mc(const Lstm12Args& a, bool bf16, hipStream_t stream);
 hipError_t gt_launch_lstm_x(const LstmXArgs& a, int nkb, int tag, bool bf16, hipStream_t stream);

@@ -168,9 +168,9 @@ __device__ __forceinline__ uint32_t gt_ldu_sc1(const uint32_t* p) {
 // with sc1 loads (gt_xload), the arrival counter is sharded over 8 cache lines and polled with sc1 loads.
 // Arithmetic = gt_lstm_x_kernel<8,3> followed by gt_lstm_x_kernel<8,8>, same orders: bitwise equal states.
 //
-// The hand-off needs all of the launch's workgroups resident together: 256 x 512 threads always are on an otherwise idle
-// MI355X (two fit a CU), and the host only takes this path while the process has ONE live context (several decode loops in
-// flight could each hold part of the chip and wait for the rest).  The wait is bounded all the same: a give-up raises the
+// The hand-off needs all of the launch's workgroups resident together: the host checks the grid against occupancy x CUs at
+// finalize (gt_lstm12_blocks_per_cu) and only takes this path while the process has ONE live context and no other context's
+// fused launches are in flight (several decode loops could each hold part of the chip and wait for the rest).  The wait is bounded all the same: a give-up raises the
 // host-mapped error word (gsttaco_synchronize reports it, the next call falls back to two launches).
 // ======================================================================================================================
 __device__ __forceinline__ void gt_st1_sc1(float* p, float v) {
@@ -291,8 +291,10 @@ __global__ __launch_bounds__(512) void gt_lstm12_kernel(Lstm12Args P) {
     GT_STAMP(A.dbg, 3);
 }
 
-bool gt_lstm12_supported(int nkb1, int nkb2, int H1, int H2, int M, int n_cu) {
-    return nkb1 == 24 && nkb2 == 64 && H1 == H2 && H1 % 4 == 0 && M <= 32 && H1 / 4 <= 2 * n_cu;
+// `slots`: workgroups of the kernel the device holds at once = occupancy (gt_lstm12_blocks_per_cu) x compute units.  The in-kernel
+// hand-off needs the whole grid resident.
+bool gt_lstm12_supported(int nkb1, int nkb2, int H1, int H2, int M, int slots) {
+    return nkb1 == 24 && nkb2 == 64 && H1 == H2 && H1 % 4 == 0 && M <= 32 && H1 / 4 <= slots;
 }
 
 hipError_t gt_launch_lstm12(const Lstm12Args& a, hipStream_t stream) {
@@ -410,10 +412,22 @@ __global__ __launch_bounds__(512) void gt_lstm12_mc_kernel(Lstm12Args P) {
 }
 
 // batches above 32 rows (fp32 and bf16): grid = pairs of tiles (rounded up to 8) x 2 chunk halves, as gt_lstm_x_mc_kernel's
-bool gt_lstm12_mc_supported(int nkb1, int nkb2, int H1, int H2, int M, int n_cu) {
-    return nkb1 == 24 && nkb2 == 64 && H1 == H2 && H1 % 4 == 0 && M > 32 && (((H1 + 3) / 4 + 1) / 2 + 7) / 8 * 16 <= 2 * n_cu;
+bool gt_lstm12_mc_supported(int nkb1, int nkb2, int H1, int H2, int M, int slots) {
+    return nkb1 == 24 && nkb2 == 64 && H1 == H2 && H1 % 4 == 0 && M > 32 && (((H1 + 3) / 4 + 1) / 2 + 7) / 8 * 16 <= slots;
 }
 int gt_lstm12_mc_grid(int H) { return (((H + 3) / 4 + 1) / 2 + 7) / 8 * 16; }
+
+// Workgroups of a fused launch one compute unit holds at once, from the occupancy API (0: gt_lstm12_kernel, 1 / 2: the multi-chunk
+// kernel in fp32 / bf16 -- 179 / 158 registers: ONE 512-thread workgroup per CU, so its 256-workgroup grid needs every CU of a
+// 256-CU device and does not fit a partition with fewer).
+int gt_lstm12_blocks_per_cu(int which) {
+    int n = 0;
+    const void* f = which == 0 ? reinterpret_cast<const void*>(gt_lstm12_kernel)
+                  : which == 1 ? reinterpret_cast<const void*>(gt_lstm12_mc_kernel<3, 8, false>)
+                               : reinterpret_cast<const void*>(gt_lstm12_mc_kernel<2, 4, true>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 512, 0) != hipSuccess) return 0;
+    return n;
+}
 
 hipError_t gt_launch_lstm12_mc(const Lstm12Args& a, bool bf16, hipStream_t stream) {
     const dim3 g(gt_lstm12_mc_grid(a.l1.H));

@@ -314,9 +314,10 @@ class GST_Tacotron:
         self.ctx.check(self.ctx.lib.gsttaco_set_graph_policy(self.ctx.handle, int(max_cached), int(capture_after)))
 
     def synchronize(self):
-        """Synchronises the current stream and raises GstTacoError if a hand-off wait of a persistent BiLSTM launch gave up since
-        the last check (``gsttaco_synchronize``): the outputs of those calls are invalid and should be repeated -- the context
-        then runs its BiLSTMs with one launch per time step.  ``Inference`` calls this before it returns."""
+        """Synchronises the current stream and raises GstTacoError if a hand-off wait of a persistent BiLSTM launch or of a fused
+        decode-LSTM launch gave up since the last check (``gsttaco_synchronize``, the one place that clears the condition): the
+        outputs of the calls since then are invalid and should be repeated -- the context runs the launch-per-step forms from
+        then on.  ``Inference`` calls this before it returns."""
         with torch.cuda.device(self.device):
             self.ctx.check(self.ctx.lib.gsttaco_synchronize(self.ctx.handle, self._stream()))
 
@@ -325,8 +326,8 @@ class GST_Tacotron:
         return self.ctx.lib.gsttaco_last_error(self.ctx.handle).decode()
 
     def handoff_error(self):
-        """Non-zero while a give-up of a persistent BiLSTM launch is pending on this context (bit 8;
-        ``gsttaco_debug_handoff_error``); the next compute call recovers from it."""
+        """Non-zero while a give-up is pending on this context, i.e. raised and not yet reported by ``synchronize`` (bit 0: fused
+        decode-LSTM launch, bit 8: persistent BiLSTM; ``gsttaco_debug_handoff_error``)."""
         out = ctypes.c_uint32(0)
         self.ctx.check(self.ctx.lib.gsttaco_debug_handoff_error(self.ctx.handle, ctypes.byref(out)))
         return int(out.value)

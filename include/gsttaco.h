@@ -253,16 +253,21 @@ int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
  * persistent BiLSTM launch (one launch for all time steps of the encoder's / vocoder's Bidirectional LSTM, reference
  * Taco2.py:39-43, 394-398; the 32 workgroups of each of its groups) and the fused decode-LSTM launch (both LSTMCells of a decoder
  * step, Taco2.py:77-85,111, in one launch; all of its workgroups).  The library arranges that for everything it controls:
- * exactly one persistent workgroup per compute unit is checked at finalize; the persistent launches of ALL contexts of the
- * process are chained on the GPU, so two of them never split an XCD; the fused decode launch is taken only while the process
- * has ONE live context.  What it cannot see -- another process on the GPU, a CU mask -- is caught by BOUNDED waits: a wait that
- * gives up raises a word in host-mapped memory, the whole launch drains at once, and
+ * exactly one persistent workgroup per compute unit, and the fused launches' whole grid against occupancy x compute units, are
+ * checked at finalize; the persistent launches of ALL contexts of the process are chained on the GPU, so two of them never split
+ * an XCD; the fused decode launch is taken only while the process has ONE live context, and another context's segments start
+ * behind the fused launches still in flight (one recorded event per device).  What the library cannot see -- another process on
+ * the GPU, a CU mask -- is caught by BOUNDED waits: a wait that gives up raises a word in host-mapped memory, the whole launch
+ * drains at once, and
  *   - gsttaco_synchronize(ctx, stream) synchronises the stream and returns GSTTACO_E_HIP if that happened since the last check:
- *     the outputs of those calls are invalid, repeat them;
- *   - the NEXT compute call on the context clears the word, switches the context to the launch-per-step / two-launch form (same
- *     results, no co-residency needed), succeeds, and leaves a "warning: ..." text in gsttaco_last_error.
- * Nothing stays poisoned and nothing hangs.  gsttaco_debug_handoff_error synchronises the device and returns the words now
- * (bit 0: fused decode-LSTM launch, bit 8: persistent BiLSTM; 0 = clear). */
+ *     the outputs of the calls since then are invalid, repeat them.  It is the ONLY place that clears the condition: calls
+ *     enqueued behind the one that gave up do not erase it (they notice the word when they are enqueued, keep it in a sticky
+ *     per-context flag, and already run the launch-per-step / two-launch form);
+ *   - the next compute call that notices the word switches the context to the launch-per-step / two-launch form (bitwise the
+ *     same results in fp32; under Use_Mixed_Precision the per-step BiLSTM kernel sums in a different order: within the mixed
+ *     tolerance), succeeds, and leaves a "warning: ..." text in gsttaco_last_error.
+ * Nothing stays poisoned and nothing hangs.  gsttaco_debug_handoff_error synchronises the device and returns what is pending,
+ * i.e. raised and not yet reported by gsttaco_synchronize (bit 0: fused decode-LSTM launch, bit 8: persistent BiLSTM; 0 = clear). */
 int gsttaco_synchronize(gsttaco_ctx* ctx, void* stream);
 int gsttaco_debug_handoff_error(gsttaco_ctx* ctx, uint32_t* host_out);
 /* Test support: out[0] = persistent BiLSTM launches this context has enqueued (eagerly or into a captured graph), out[1] = 1

@@ -296,8 +296,8 @@ def test_rccl_communicator_gather_and_barrier_on_this_gpu(monkeypatch):
 def test_a_given_up_handoff_is_reported_and_the_next_call_recovers():
     """The persistent BiLSTM's waits are bounded.  Fault injection for real: one member of every group exits at once, so the
     launch's waits run into their bound -- the whole launch must drain quickly (not one bound per time step), the call's
-    encodings are invalid and ``synchronize`` says so, and the NEXT call clears the word, falls back to one launch per time
-    step, succeeds with the correct encodings and leaves a warning.  Nothing stays poisoned."""
+    encodings are invalid and ``synchronize`` says so (and is the one place that clears the give-up), and the NEXT call falls
+    back to one launch per time step, succeeds with the correct encodings and leaves a warning.  Nothing stays poisoned."""
     import time
     import torch
     from gst_tacotron_amd import synthetic, weights
@@ -316,7 +316,7 @@ def test_a_given_up_handoff_is_reported_and_the_next_call_recovers():
         m.synchronize()
     dt = time.perf_counter() - t0
     assert dt < 5.0, dt                          # 47 time steps x 2^18 polls each would be minutes
-    assert m.handoff_error() == 1 << 8
+    assert m.handoff_error() == 0 and m.debug_counters()[1] == 0     # reported once, cleared by that report; already fallen back
     enc = m.encode(tokens).cpu().numpy()         # recovers: per-step launches, no co-residency needed
     m.synchronize()
     assert np.array_equal(enc, ref)              # (the persistent kernel is bitwise the per-step kernel)
@@ -328,6 +328,85 @@ def test_a_given_up_handoff_is_reported_and_the_next_call_recovers():
     m2 = _model(hp, w, 20, 48, 4)
     m2.ctx.check(m2.ctx.lib.gsttaco_debug_raise_handoff_error(m2.ctx.handle, 1 << 8))
     assert np.array_equal(m2.encode(tokens).cpu().numpy(), ref) and m2.debug_counters()[1] == 0
+    with pytest.raises(GstTacoError, match="gave up"):      # ... and it is still reported, once, by the next synchronize
+        m2.synchronize()
+    m2.synchronize()
+
+
+def test_a_give_up_is_not_erased_by_the_calls_enqueued_behind_it():
+    """``gsttaco_synchronize`` reports give-ups "since the last check": a give-up in call N must survive the enqueue of call
+    N + 1 (and the later graph segments of call N itself -- an Inference_Step with the vocoder enqueues three), which used to
+    clear the word.  Call A gives up for real (a member dropped), the device is drained WITHOUT the library's check, calls B
+    (encode) and C (Inference_Step with the CBHG vocoder: encoder, main and vocoder segments) are enqueued -- they already run
+    the per-step fallback and are correct -- and the one ``synchronize`` at the end still reports A."""
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    from gst_tacotron_amd.capi import GstTacoError
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, seed=3)
+    rng = np.random.default_rng(1)
+    B, Tv, Tref, steps = 6, 20, 30, 3
+    tokens, tl = synthetic.make_tokens(rng, B, Tv)
+    mels, ml = synthetic.make_ref_mels(rng, B, Tref)
+    masks, noise = synthetic.make_randomness(rng, steps, B, Tv, [256, 256])
+    m = _model(hp, w, B, Tv, Tref + 1)
+    ref_enc = m.encode(tokens).cpu().numpy()
+    ref = [t.cpu().numpy() for t in m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps,
+                                                     with_vocoder=True)]
+    m.synchronize()
+    m.ctx.check(m.ctx.lib.gsttaco_debug_raise_handoff_error(m.ctx.handle, 4 << 16))
+    m.encode(tokens)                              # call A: its persistent launch gives up
+    torch.cuda.synchronize()                      # drained, but NOT checked
+    enc_b = m.encode(tokens)                      # call B: sees the word at enqueue time, falls back
+    out_c = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps, with_vocoder=True)
+    with pytest.raises(GstTacoError, match="gave up"):
+        m.synchronize()
+    m.synchronize()                               # reported once
+    assert m.handoff_error() == 0 and m.debug_counters()[1] == 0
+    assert np.array_equal(enc_b.cpu().numpy(), ref_enc)
+    for a, b in zip(out_c, ref):
+        assert np.array_equal(a.cpu().numpy(), b)
+
+
+def test_a_second_context_starts_behind_the_fused_launches_in_flight():
+    """The fused decode-LSTM launches need their whole grid co-resident, so the library takes them only while the process has ONE
+    live context -- but a graph full of them may still be running when a second context is created.  The guard is about work in
+    flight: the completion of the last segment with fused launches is recorded per device and every other context's segments
+    start behind it.  Context 1 (alone: fused) queues ~0.5 s of decode loops on its own stream, context 2 is created meanwhile
+    and runs a whole Inference_Step (persistent BiLSTM launches included) on a second stream: no give-up on either context, context 1's results bitwise what it gave
+    alone, context 2's bitwise context 1's."""
+    import gc
+    import torch
+    from test_gpu_parity import _full_case
+    gc.collect()
+    B, Tv, Tref, steps = 8, 32, 40, 250
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=21)
+    m1 = _model(hp, w, B, Tv, Tref + 1)
+    ref = [t.cpu().numpy() for t in m1.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps)
+           if t is not None]
+    m1.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    dev = dict(tokens=torch.as_tensor(tokens, device="cuda"), mels=torch.as_tensor(mels, device="cuda"), ml=torch.as_tensor(ml, device="cuda"),
+               masks=torch.as_tensor(masks, device="cuda"), noise=torch.as_tensor(noise, device="cuda"))
+    torch.cuda.synchronize()
+    done = torch.cuda.Event()
+    with torch.cuda.stream(s1):
+        outs1 = [m1.Inference_Step(dev["tokens"], None, None, dev["mels"], dev["ml"], prenet_masks=dev["masks"], attn_noise=dev["noise"],
+                                   steps=steps) for _ in range(70)]
+        done.record(s1)
+    m2 = _model(hp, w, B, Tv, Tref + 1)            # created while context 1's fused graphs are (most likely) still running
+    overlapped = not done.query()
+    with torch.cuda.stream(s2):
+        out2 = m2.Inference_Step(dev["tokens"], None, None, dev["mels"], dev["ml"], prenet_masks=dev["masks"], attn_noise=dev["noise"], steps=steps)
+    with torch.cuda.stream(s1):
+        m1.synchronize()
+    with torch.cuda.stream(s2):
+        m2.synchronize()
+    print("context 2 enqueued while context 1's queue was still running:", overlapped)
+    assert m1.handoff_error() == 0 and m2.handoff_error() == 0
+    for o in (outs1[0], outs1[-1], out2):
+        for a, b in zip([t for t in o if t is not None], ref):
+            assert np.array_equal(a.cpu().numpy(), b)
 
 
 def test_several_contexts_on_several_streams_all_keep_the_persistent_bilstm():

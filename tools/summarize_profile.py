@@ -54,7 +54,30 @@ for name in ("bench_trace.log",):
     for line in open(os.path.join(out, name)):
         if line.startswith("{"):
             open(os.path.join(summ, f"{tag}_bench_under_rocprof.json"), "w").write(line)
+# Consistency check (round 4): the ALGORITHMIC bytes the bench line prices a decode launch at can never exceed what the counters
+# saw it move (round 3's bf16 line did: 4-byte weights were assumed for 2-byte packs).  Written to <tag>_bytes_check.txt;
+# a violation makes this script exit non-zero.
+violations = []
+bl = os.path.join(summ, f"{tag}_bench_under_rocprof.json")
+if os.path.exists(bl) and res:
+    line = json.loads(open(bl).read())
+    rows_chk = []
+    for k, v in ((line.get("roofline") or {}).get("decode_step") or {}).get("kernels", {}).items():
+        sym = v["name"].split(" ")[0].split("<")[0]
+        hits = [(n, r) for n, r in res.items() if sym in n and r["dispatches"] >= 20]       # (the step kernels: hundreds of dispatches)
+        if not hits:
+            continue
+        n, r = max(hits, key=lambda x: x[1]["dispatches"])
+        traffic = r["hbm_read_bytes_corrected"] + r["hbm_write_bytes"]
+        ok = v["bytes"] <= 1.02 * traffic
+        rows_chk.append(f"{'ok ' if ok else 'BAD'} {sym}: algorithmic {v['bytes'] / 1e6:.2f} MB, PMC traffic {traffic / 1e6:.2f} MB per launch (x{traffic / max(v['bytes'], 1):.2f})")
+        if not ok:
+            violations.append(sym)
+    open(os.path.join(summ, f"{tag}_bytes_check.txt"), "w").write("\n".join(rows_chk) + "\n")
+    print("\n".join(rows_chk))
 if stats:
     print(open(os.path.join(summ, f"{tag}_kernel_stats.csv")).read()[:3000])
 print(json.dumps({k: v for k, v in res.items() if "skinny" in k or "front" in k or "lstm" in k or "proj" in k}, indent=1)[:3000])
 print(json.dumps({k[:50]: v for k, v in util.items() if v["mfma_util"]}, indent=1)[:3000])
+if violations:
+    sys.exit("algorithmic bytes exceed the measured traffic for: " + ", ".join(violations))
