@@ -190,7 +190,7 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
     if (P.type == GSTTACO_ATT_SMA) {
         for (int t = tid; t < Tv; t += ATT_THREADS) {
             float v = pv[t] * sc[t];
-            if (t > 0) v += pv[t - 1] * (1.f - sc[t - 1]);
+            if (t > 0) v = __builtin_fmaf(pv[t - 1], 1.f - sc[t - 1], v);       // (explicit: a*b + c*d can contract either way)
             al[t] = v;
         }
     } else {

@@ -24,6 +24,7 @@
 // column-wise for the context.
 #include "skinny_body.h"
 #include "lean_body.h"
+#include "chain_common.h"
 #include "../../include/gsttaco.h"
 #include <stdlib.h>
 
@@ -79,7 +80,7 @@ __device__ __forceinline__ void gemv_acc(const float* xs, int K, const GemvPlan&
         const int k = p.kp * p.rows + i0 + i;
         if (EXACT || (i0 + i < p.rows && p.kp < p.kparts && k < K)) {
             const float x = xs[k];
-            acc.x += x * r[i].x; acc.y += x * r[i].y; acc.z += x * r[i].z; acc.w += x * r[i].w;
+            gt_fma4(acc, x, r[i]);
         }
     }
 }
@@ -87,30 +88,6 @@ __device__ __forceinline__ void gemv_acc(const float* xs, int K, const GemvPlan&
 // partial[kp][N] <- this lane's partial sums; caller syncs and reduces
 __device__ __forceinline__ void gemv_store(const GemvPlan& p, int N, const float4& acc, float* partial) {
     if (p.kp < p.kparts) *reinterpret_cast<float4*>(partial + (size_t)p.kp * N + p.cg * 4) = acc;
-}
-
-// sum of the k-part partials of one column; 8 independent LDS reads in flight per round (a plain
-// `z += partial[...]` loop serialises ~100-cycle LDS round trips: 32 of them cost >1 us per phase)
-__device__ __forceinline__ float reduce_partial(const float* partial, int kparts, int N, int col) {
-    float z = 0.f;
-    int p = 0;
-    for (; p + 8 <= kparts; p += 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(p + j) * N + col];
-        z += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    }
-    for (; p < kparts; ++p) z += partial[(size_t)p * N + col];
-    return z;
-}
-
-__device__ __forceinline__ float front_wave_incl_scan(float x, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    return x;
 }
 
 // ---- worker workgroup (blockIdx.x >= B): recurrent half of an LSTM gate GEMM (see DecFrontArgs::rec).
@@ -429,8 +406,8 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
             const float4 m4 = *reinterpret_cast<const float4*>(tile + row * LD + a0);
             const float4 q4 = *reinterpret_cast<const float4*>(qs + a0);
             const float4 w4 = *reinterpret_cast<const float4*>(vs + a0);
-            s2 += f32x2{w4.x, w4.y} * gt_tanh2(f32x2{q4.x, q4.y} + f32x2{m4.x, m4.y});
-            s2 += f32x2{w4.z, w4.w} * gt_tanh2(f32x2{q4.z, q4.w} + f32x2{m4.z, m4.w});
+            s2 = __builtin_elementwise_fma(f32x2{w4.x, w4.y}, gt_tanh2(f32x2{q4.x, q4.y} + f32x2{m4.x, m4.y}), s2);
+            s2 = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, gt_tanh2(f32x2{q4.z, q4.w} + f32x2{m4.z, m4.w}), s2);
         }
         float s = s2.x + s2.y;
 #pragma unroll
@@ -446,7 +423,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         for (int t = tid; t < Tv; t += FT) {
             const bool nz = P.sigmoid_noise > 0.f;
             float v = pv[t] * gt_sigmoid(sc[t] + (nz ? snz[t] : 0.f));
-            if (t > 0) v += pv[t - 1] * (1.f - gt_sigmoid(sc[t - 1] + (nz ? snz[t - 1] : 0.f)));
+            if (t > 0) v = __builtin_fmaf(pv[t - 1], 1.f - gt_sigmoid(sc[t - 1] + (nz ? snz[t - 1] : 0.f)), v);
             al[t] = v;
         }
     } else {
@@ -497,10 +474,10 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         float p0 = 0.f, p1 = 0.f;
         int t = cp;
         for (; t + CPARTS < nr; t += 2 * CPARTS) {
-            p0 += alc[t] * tile[t * LD + ca];
-            p1 += alc[t + CPARTS] * tile[(t + CPARTS) * LD + ca];
+            p0 = __builtin_fmaf(alc[t], tile[t * LD + ca], p0);
+            p1 = __builtin_fmaf(alc[t + CPARTS], tile[(t + CPARTS) * LD + ca], p1);
         }
-        if (t < nr) p0 += alc[t] * tile[t * LD + ca];
+        if (t < nr) p0 = __builtin_fmaf(alc[t], tile[t * LD + ca], p0);
         cacc += p0 + p1;
     }
     red[cp * A + ca] = cacc;

@@ -15,7 +15,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // gives rcp -> 0 -> +1, exp(2x) -> 0 gives -1, never NaN.  abs error <= ~2e-7 (covered by the parity tests).
 __device__ __forceinline__ float gt_tanh(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);      // exp(2x) = 2^(2x*log2(e))
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    // (an explicit fma: whether `1 - 2 r` contracts is otherwise the optimiser's choice per call site, and kernels whose results
+    // are compared bitwise -- the decode launch forms -- must round alike)
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 // two at a time on the packed fp32 VALU ops (v_pk_mul / v_pk_add / v_pk_fma): the attention score pass is 16 K tanh per
@@ -30,7 +32,7 @@ __device__ __forceinline__ f32x2 gt_tanh2(f32x2 x) {
     f32x2 r;
     r.x = __builtin_amdgcn_rcpf(e.x);
     r.y = __builtin_amdgcn_rcpf(e.y);
-    return 1.0f - 2.0f * r;
+    return __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r, f32x2{1.0f, 1.0f});
 }
 
 __device__ __forceinline__ float gt_sigmoid(float x) {

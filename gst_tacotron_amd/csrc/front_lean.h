@@ -139,7 +139,7 @@ __device__ __forceinline__ void gt_front_lean(const DecFrontArgs& P, float* smem
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            acc.x += x[i] * r1[i].x; acc.y += x[i] * r1[i].y; acc.z += x[i] * r1[i].z; acc.w += x[i] * r1[i].w;
+            gt_fma4(acc, x[i], r1[i]);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -152,7 +152,7 @@ __device__ __forceinline__ void gt_front_lean(const DecFrontArgs& P, float* smem
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 8; i < 16; ++i) {
-            acc.x += x[i] * r1[i].x; acc.y += x[i] * r1[i].y; acc.z += x[i] * r1[i].z; acc.w += x[i] * r1[i].w;
+            gt_fma4(acc, x[i], r1[i]);
         }
         gemv_store(g1, P1, acc, partial);
     }
@@ -181,7 +181,7 @@ __device__ __forceinline__ void gt_front_lean(const DecFrontArgs& P, float* smem
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            acc.x += x[i] * rq[i].x; acc.y += x[i] * rq[i].y; acc.z += x[i] * rq[i].z; acc.w += x[i] * rq[i].w;
+            gt_fma4(acc, x[i], rq[i]);
         }
         gemv_store(g2, A, acc, partial);
     }
@@ -219,8 +219,8 @@ __device__ __forceinline__ void gt_front_lean(const DecFrontArgs& P, float* smem
             const float4 m4 = *reinterpret_cast<const float4*>(tile + row * LD + a0);
             const float4 q4 = *reinterpret_cast<const float4*>(qs + a0);
             const float4 w4 = *reinterpret_cast<const float4*>(vs + a0);
-            s2 += f32x2{w4.x, w4.y} * gt_tanh2(f32x2{q4.x, q4.y} + f32x2{m4.x, m4.y});
-            s2 += f32x2{w4.z, w4.w} * gt_tanh2(f32x2{q4.z, q4.w} + f32x2{m4.z, m4.w});
+            s2 = __builtin_elementwise_fma(f32x2{w4.x, w4.y}, gt_tanh2(f32x2{q4.x, q4.y} + f32x2{m4.x, m4.y}), s2);
+            s2 = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, gt_tanh2(f32x2{q4.z, q4.w} + f32x2{m4.z, m4.w}), s2);
         }
         float s = s2.x + s2.y;
 #pragma unroll
@@ -234,7 +234,9 @@ __device__ __forceinline__ void gt_front_lean(const DecFrontArgs& P, float* smem
         if (tid < Tv) {
             const int t = tid;
             float v = pv[t] * gt_sigmoid(sc[t] + (noisy ? snz[t] : 0.f));
-            if (t > 0) v += pv[t - 1] * (1.f - gt_sigmoid(sc[t - 1] + (noisy ? snz[t - 1] : 0.f)));
+            // (explicit fma: `a*b + c*d` may contract around either product, and this kernel, the general one and the persistent decode
+            // kernel must round alike -- their outputs are compared bitwise)
+            if (t > 0) v = __builtin_fmaf(pv[t - 1], 1.f - gt_sigmoid(sc[t - 1] + (noisy ? snz[t - 1] : 0.f)), v);
             al[t] = v;
         }
     } else {
@@ -285,10 +287,10 @@ __device__ __forceinline__ void gt_front_lean(const DecFrontArgs& P, float* smem
         float p0 = 0.f, p1 = 0.f;
         int t = cp;
         for (; t + CPARTS < nr; t += 2 * CPARTS) {
-            p0 += alc[t] * tile[t * LD + ca];
-            p1 += alc[t + CPARTS] * tile[(t + CPARTS) * LD + ca];
+            p0 = __builtin_fmaf(alc[t], tile[t * LD + ca], p0);
+            p1 = __builtin_fmaf(alc[t + CPARTS], tile[(t + CPARTS) * LD + ca], p1);
         }
-        if (t < nr) p0 += alc[t] * tile[t * LD + ca];
+        if (t < nr) p0 = __builtin_fmaf(alc[t], tile[t * LD + ca], p0);
         cacc += p0 + p1;
     }
     red[cp * A + ca] = cacc;

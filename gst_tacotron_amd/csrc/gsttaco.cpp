@@ -58,6 +58,7 @@ struct GraphKey {
     int kind, B, Tv, Tref1, steps, has_mask, has_noise, prof, masked;
     int persist = 0;    // captured with the persistent BiLSTM launches enabled (filled in by run_cached)
     int fuse12 = 0;     // captured with both decode LSTM cells in one launch (only while this is the process's one live context)
+    int persist_dec = 0;    // captured with the whole decode loop as one persistent launch (same condition)
     bool operator<(const GraphKey& o) const {
         return memcmp(this, &o, sizeof(GraphKey)) < 0;
     }
@@ -127,6 +128,11 @@ struct gsttaco_ctx {
     uint32_t* h_err = nullptr;
     uint32_t gave_up = 0;        // sticky: give-ups seen by a later enqueue and not yet reported by gsttaco_synchronize (bit 0 / 1 as h_err)
     bool announce_warn = false;  // the next compute call leaves `warn` in gsttaco_last_error
+    bool persist_decode = true;  // the whole decode loop as ONE persistent launch where it applies (GSTTACO_PERSIST_DECODE=0: launches)
+    bool persist_now = false;    // ... for the call being enqueued (one live context, as fuse12_now)
+    int persist_slots = 0;       // workgroups of gt_persist_decode_kernel the device holds at once
+    uint64_t n_persist_decodes = 0;      // persistent decode launches enqueued (eagerly or into a captured graph)
+    float* w_xa2 = nullptr; uint2* w_z0g = nullptr; float* w_hpart = nullptr; uint32_t* w_pctl = nullptr;    // its workspace
     int fuse12_slots[3] = {0, 0, 0};    // workgroups of gt_lstm12_kernel / gt_lstm12_mc_kernel fp32 / bf16 the device holds at once (occupancy x CUs)
     bool counted = false;        // this context is included in g_live_contexts
     uint64_t n_persist_enqueued = 0;     // persistent BiLSTM launches enqueued (eagerly or into a captured graph)
@@ -877,6 +883,46 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     // (batches above 32 rows: every launch is throughput-bound, the front launch most of all, and the projection launch has
     // ~150 CUs to spare: it takes half of layer 2's recurrent tiles instead of a quarter)
     const int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, c->co_tiles >= 0 ? c->co_tiles : (B > 32 ? 128 : 64)));
+    // ---- the whole loop as ONE persistent launch (persist_decode.hip): the headline shape class -- fp32, batch <= 32, T_v <= 128, the
+    // reference's decoder sizes, SMA / BMA -- while this is the process's only live context (its hand-offs need every workgroup resident).
+    // Bitwise the launches below (GPU test), which stay the path for every other shape, for several contexts, and after a give-up.
+    {
+        const bool base = c->persist_now && !c->stamps && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->front_mode >= 2 &&
+                          !c->lstm_x[0].bf16 && !c->lstm_x[1].bf16 && !c->proj_z.bf16 && c->proj_z.wp != nullptr && c->proj.nkb >= 32 &&
+                          c->worker_tiles == 2 && c->co_worker_tiles == 1 && g.att_type != GSTTACO_ATT_LSA &&
+                          gt_dec_front_supported(mel, P0, P1, att, Tv) && c->lstm_x[0].nkb == 24 && c->lstm_x[1].nkb == 64 && c->lstm_h[0].nkb == 64 &&
+                          c->lstm_h[1].nkb == 64 &&
+                          gt_persist_decode_supported(mel, r, P0, P1, att, H1, H2, B, Tv, c->proj_z.ntiles, c->proj_z.nkb, c->persist_slots);
+        const bool hashed = !injected_mask && g.prenet_rate == 0.5f && c->keep_hash;
+        if (base && (g.prenet_rate == 0.f || hashed || has_mask) && (g.sigmoid_noise == 0.f || has_noise)) {
+            PersistDecodeArgs a{};
+            a.w1x = c->lstm_x[0].wp; a.w1h = c->lstm_h[0].wp; a.b1h = c->lstm_h[0].bias;
+            a.w2x = c->lstm_x[1].wp; a.w2h = c->lstm_h[1].wp; a.b2h = c->lstm_h[1].bias;
+            a.wp = c->proj_z.wp; a.bp = c->proj_z.bias; a.pj_tiles = c->proj_z.ntiles;
+            a.n_out = c->proj_out; a.n_split = mel * r; a.z_col0 = c->z_col0;
+            a.W1 = c->pw1; a.b1 = c->pb1; a.Wq = c->pwq; a.bq = c->pbq; a.av = c->att_v; a.score_bias = c->att_sb;
+            a.pm = c->w_pm;
+            a.noise = (g.sigmoid_noise > 0.f) ? c->w_noise : nullptr;
+            a.masks = (g.prenet_rate > 0.f && !hashed) ? c->w_masks : nullptr;
+            a.seed_ptr = c->w_seed; a.tok_len = tlen;
+            a.drop_rate = g.prenet_rate; a.drop_scale = drop_scale; a.sigmoid_noise = g.sigmoid_noise;
+            a.keep_hash = hashed ? 1 : 0; a.att_type = g.att_type;
+            a.xa[0] = c->w_xa; a.xa[1] = c->w_xa2;
+            a.h1[0] = c->w_h1[0]; a.h1[1] = c->w_h1[1]; a.h2[0] = c->w_h2[0]; a.h2[1] = c->w_h2[1];
+            a.z0g = c->w_z0g; a.hpart = c->w_hpart; a.ctl = c->w_pctl; a.err = c->w_err;
+            a.pre = c->w_pre; a.ld_pre = ld_pre; a.stop = c->w_stop; a.align = c->w_align; a.ld_align = (int64_t)steps * Tv;
+            a.B = B; a.MT = MT; a.Tv = Tv; a.steps = steps; a.co_tiles = co_tiles;
+            a.expect_extra = c->debug_drop_member >= 0 ? 1 : 0;
+            const bool prof = c->prof_every > 0;
+            if (prof) { int rce = prof_begin(2); if (rce) return rce; }
+            HIPCHECK(c, gt_launch_persist_decode(a, c->pb0, s));
+            if (prof) { int rce = prof_end(2); if (rce) return rce; }
+            ++c->n_persist_decodes;
+            if (c->prof_every > 0)
+                for (int i = 0; i < 5; ++i) c->prof_count[i] = nprof[i];
+            return 0;
+        }
+    }
     for (int t = 0; t < steps; ++t) {
         const int p = t & 1;
         SkinnyArgs k;
@@ -1332,9 +1378,17 @@ int run_cached_inner(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in,
 //     gsttaco_synchronize clears it behind the stream synchronisation.
 void note_give_up(gsttaco_ctx* c) {
     if (!c->h_err) return;
-    if (c->h_err[0]) {          // the fused decode-LSTM launch's hand-off (gt_lstm12_kernel): back to one launch per cell
+    if (c->h_err[0]) {          // word 0: bit 0 the fused decode-LSTM launch's hand-off, bit 1 the persistent decode launch's
         c->gave_up |= 1u;
-        if (c->fuse12) {
+        if ((c->h_err[0] & 2u) && c->persist_decode) {
+            c->persist_decode = false;
+            c->debug_drop_member = -1;
+            c->warn = "warning: a hand-off wait of the persistent decode launch gave up in an earlier call (its workgroups were not co-resident: "
+                      "is another process or a CU mask sharing this GPU?); that call's outputs were invalid.  This context now runs the decode "
+                      "loop as launches per step (bitwise the same results, ~25 % slower)";
+            c->announce_warn = true;
+        }
+        if ((c->h_err[0] & 1u) && c->fuse12) {
             c->fuse12 = false;
             c->debug_drop_member = -1;
             c->warn = "warning: the in-kernel hand-off of the fused decode-LSTM launch gave up in an earlier call (its workgroups were not "
@@ -1380,7 +1434,7 @@ int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F bod
         rc = run_cached_inner(c, stream, key_in, body);
         HIPCHECK(c, hipEventRecord(ev, stream));
     }
-    if (!rc && c->fuse12_now && (key_in.kind == 0 || key_in.kind == 3)) {      // the segment held fused decode launches
+    if (!rc && (c->fuse12_now || c->persist_now) && (key_in.kind == 0 || key_in.kind == 3)) {      // the segment held fused / persistent decode launches
         FusedInFlight& f = g_fused_event[c->cfg.device];
         if (!f.ev) HIPCHECK(c, hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
         HIPCHECK(c, hipEventRecord(f.ev, stream));
@@ -1396,6 +1450,8 @@ int run_cached_inner(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in,
     // several decode loops in flight could each hold part of the chip and wait for the rest of their fused launch: one live context only
     c->fuse12_now = c->fuse12 && g_live_contexts.load() <= 1;
     key.fuse12 = c->fuse12_now ? 1 : 0;
+    c->persist_now = c->persist_decode && g_live_contexts.load() <= 1;
+    key.persist_dec = c->persist_now ? 1 : 0;
     if (!c->use_graph || c->graph_cache_max < 1) return body(stream);
     const uint64_t now = ++c->graph_clock;
     auto it = c->graphs.find(key);
@@ -1533,6 +1589,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->lean = env_int("GSTTACO_LEAN", 1) != 0;
     c->bilstm_persist = env_int("GSTTACO_BILSTM_PERSIST", 1) != 0;
     c->fuse12 = env_int("GSTTACO_FUSED_LSTM", 1) != 0;
+    c->persist_decode = env_int("GSTTACO_PERSIST_DECODE", 1) != 0;
     c->wino = env_int("GSTTACO_WINO", 4);
     if (c->wino != 0 && c->wino != 2) c->wino = 4;      // {0, 2, 4}; any other non-zero value (the old boolean's 1 included) means the default
     c->stamps = env_int("GSTTACO_STAMPS", 0) == 1;
@@ -1870,6 +1927,13 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     if ((rc = fa(&c->w_part[0], Bp * 4 * c->H1))) return rc;
     if ((rc = fa(&c->w_part[1], Bp * 4 * c->H2))) return rc;
     if ((rc = dev_alloc(c, (void**)&c->w_arrive, (size_t)S * 256 * sizeof(uint32_t)))) return rc;
+    // persistent decode launch (persist_decode.hip): second prenet | context buffer (ping-pong by step parity), prenet-0 granules,
+    // the chain workgroups' recurrent halves, control words
+    if ((rc = fa(&c->w_xa2, Bp * (c->P1 + c->att)))) return rc;
+    HIPCHECK(c, hipMemset(c->w_xa2, 0, Bp * (c->P1 + c->att) * sizeof(float)));
+    if ((rc = dev_alloc(c, (void**)&c->w_z0g, (size_t)32 * 256 * sizeof(uint2)))) return rc;
+    if ((rc = fa(&c->w_hpart, (size_t)2 * 32 * 512))) return rc;
+    if ((rc = dev_alloc(c, (void**)&c->w_pctl, gt_persist_decode_ctl_words() * sizeof(uint32_t)))) return rc;
     // the give-up words of the in-kernel hand-offs live in host-mapped memory: the device raises them with a system-scope
     // atomic (failure path only), the host reads them without a synchronisation at the start of the next call
     HIPCHECK(c, hipHostMalloc((void**)&c->h_err, 16, hipHostMallocMapped));
@@ -1903,6 +1967,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     HIPCHECK(c, gt_gst_init());
     HIPCHECK(c, gt_bilstm_persist_init());
     HIPCHECK(c, gt_conv5_bf16_init());
+    HIPCHECK(c, gt_persist_decode_init());
     // the persistent BiLSTM's groups need their 32 members each on a CU of their own: exactly one workgroup per CU must fit
     if (c->bilstm_persist && gt_bilstm_persist_blocks_per_cu() != 1) {
         c->bilstm_persist = false;
@@ -1911,6 +1976,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     // the fused decode-LSTM launches hand h1 over in-kernel: their whole grid must be resident (occupancy x CUs of THIS device;
     // a partition with fewer CUs than the grid simply keeps the two-launch form)
     for (int i = 0; i < 3; ++i) c->fuse12_slots[i] = gt_lstm12_blocks_per_cu(i) * c->n_cu;
+    c->persist_slots = gt_persist_decode_blocks_per_cu() * c->n_cu;
     if (c->fuse12 && c->H1 == c->H2 && (c->H1 + 3) / 4 > c->fuse12_slots[0])
         c->warn = c->err = "warning: this device cannot hold the fused decode-LSTM launch's whole grid at once (" + std::to_string((c->H1 + 3) / 4) +
                            " workgroups, " + std::to_string(c->fuse12_slots[0]) + " resident): the two LSTM cells run as two launches";
@@ -2246,10 +2312,12 @@ int gsttaco_debug_handoff_error(gsttaco_ctx* c, uint32_t* host_out) {
     return 0;
 }
 
-int gsttaco_debug_counters(const gsttaco_ctx* c, uint64_t out[2]) {
+int gsttaco_debug_counters(const gsttaco_ctx* c, uint64_t out[4]) {
     if (!c || !out) return GSTTACO_E_INVALID;
     out[0] = c->n_persist_enqueued;
     out[1] = c->bilstm_persist ? 1u : 0u;
+    out[2] = c->n_persist_decodes;
+    out[3] = c->persist_decode ? 1u : 0u;
     return 0;
 }
 

@@ -272,6 +272,41 @@ bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv);
 hipError_t gt_dec_front_init();
 hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t stream);
 
+// ---------------------------------------------------------------- persist_decode.hip
+// The whole decoder loop as ONE persistent launch (batch <= 32, T_v <= 128, fp32, the reference's decoder sizes): see the file.
+struct PersistDecodeArgs {
+    // weights: the launch path's packs (MFMA-fragment order [tile][k-block][lane][4])
+    const float *w1x, *w1h, *b1h, *w2x, *w2h, *b2h;   // lstm_x[l].wp / lstm_h[l].wp / lstm_h[l].bias
+    const float *wp, *bp;                              // proj_z: projection columns | padding | fused prenet-0 columns
+    int pj_tiles, n_out, n_split, z_col0;              // tiles of proj_z; mel*r + 1; mel*r; first prenet-0 column
+    const float *W1, *b1, *Wq, *bq, *av, *score_bias;  // prenet-1 [P0][P1] + bias, query [P1][A] + bias (plain layouts), attention v, score bias
+    const float* pm;                                   // processed memory [B][Tv][A]
+    const float* noise;                                // N(0,1) [steps][B][Tv] (injected or pre-generated), or NULL when sigmoid_noise == 0
+    const float* masks;                                // keep masks [steps][mask0 B*P0 | mask1 B*P1], or NULL (hashed / no dropout)
+    const uint64_t* seed_ptr;
+    const int32_t* tok_len;                            // masked-mode extension (A12) or NULL
+    float drop_rate, drop_scale, sigmoid_noise;
+    int keep_hash, att_type;
+    // state / workspace
+    float* xa[2];                                      // blocked [24][MT][256], ping-pong by step parity
+    float* h1[2]; float* h2[2];                        // blocked [64][MT][256]
+    uint2* z0g;                                        // [32][256] {value bits, step tag}
+    float* hpart;                                      // [2][32][512] recurrent halves of the chain workgroups' tiles
+    uint32_t* ctl;                                     // gt_persist_decode_ctl_words() words, zeroed by the launcher
+    uint32_t* err;                                     // host-mapped give-up word (shared with the fused LSTM launch)
+    // outputs
+    float* pre; int64_t ld_pre;                        // [B][steps*r*mel]
+    float* stop;                                       // [B][steps]
+    float* align; int64_t ld_align;                    // [B][steps][Tv]
+    int B, MT, Tv, steps, co_tiles;                    // co_tiles: layer-2 tiles whose recurrent half the launch path sums in 8-wave order
+    int expect_extra;                                  // fault injection (tests): the all-to-all waits expect this many arrivals too many
+};
+size_t gt_persist_decode_ctl_words();
+bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots);
+hipError_t gt_persist_decode_init();                   // opt in to > 64 KiB dynamic LDS; once, outside stream capture
+int gt_persist_decode_blocks_per_cu();
+hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a, const float* b0, hipStream_t stream);
+
 // ---------------------------------------------------------------- gst.hip
 struct Conv2dArgs {
     const float* x;         // [B, H, W, Cin] (batch stride xb floats; lets frame 0 be skipped)

@@ -1,0 +1,762 @@
+// The whole decoder loop (reference Taco2.py:153-228: Max_Step // r iterations of Decoder_Step, Taco2.py:96-120, with the
+// monotonic attention of Steps.py:107-229) as ONE PERSISTENT LAUNCH -- batches of up to 32 utterances of up to 128 tokens in
+// fp32 at the reference's decoder sizes (prenet 256/256, attention 128, LSTM 1024/1024), i.e. the headline shape.
+//
+// Why (tools/persist_step.hip, profiles/r04_persist_step.txt, EXPERIMENTS round 4): the three-launch step costs 26.0 us, of
+// which 6.6 us are kernel boundaries, ~4 us the weights' trip from the Infinity Cache behind each boundary and 9 us a
+// per-utterance chain that starts from nothing every step.  Here 256 workgroups (one per CU, 512 threads) stay resident for
+// all steps:
+//   * EVERY workgroup owns gate tile `blockIdx.x` (4 hidden units x 4 gates) of BOTH LSTM cells, weights in registers;
+//   * workgroups 0..31 also run utterance b's chain -- prenet-1 + dropout, query, scores, SMA / BMA alignment, context -- with
+//     the utterance's processed memory in LDS for the whole loop and ALL of prenet-1's weights requested while the previous
+//     step's projection is still running (rows the hashed dropout zeroes are never requested);
+//   * the next workgroups also own a (projection tile, 16-row M-tile) with its 72 KB in registers;
+//   * the chain workgroups' LSTM tiles still need their recurrent halves h . W_h + b (3.4 us of MFMA per step that would sit
+//     between the chain and the cells): 64 HELPER workgroups compute them from the state fragments they hold anyway and hand
+//     them back through memory.
+// Hand-offs (all bounded; a give-up raises the host-mapped word the fused LSTM launch uses, gsttaco_synchronize reports it, the
+// context falls back to launches):
+//   S1  projection -> chains   prenet-0 pre-activations as 8-byte {value, step tag} granules, one row per utterance (1-to-1)
+//   S2  chains -> everybody    prenet output (early: the LSTM-1 workgroups multiply it under the attention) and context,
+//                              16-byte write-through stores, one flag per utterance
+//   S3 / S4  h1 / h2 all-to-all  write-through stores, drained, 8-way sharded arrival counter, one sc1 poll in flight per
+//                              workgroup (pipelined polls made it slower: the arrivals queue behind them), sc1 loads
+//
+// ARITHMETIC: bitwise the launch path's (gt_dec_front[_lean]_kernel, gt_lstm12_kernel, gt_proj_lean_kernel and their workers):
+// the same k-block -> wave assignment and summation orders everywhere; where the launch path runs 1024 threads (the chain,
+// the recurrent-half workers) every thread here plays two of them with separate accumulators.  tests/test_gpu_parity.py
+// compares the two paths bitwise over hundreds of steps -- which is also the test that no hand-off ever delivers a stale word.
+#include "chain_common.h"
+#include "device_utils.h"
+#include "kernels.h"
+#include "../../include/gsttaco.h"
+
+namespace {
+
+constexpr int PD_NT = 512, PD_NW = 8, PD_NWG = 256, PD_UTT = 32, PD_HELP = 64;
+constexpr int PD_P = 256, PD_A = 128, PD_H = 1024, PD_TV = 128, PD_LDV = PD_A + 4;
+constexpr int PD_KBP = PD_P / 16, PD_KBC = PD_A / 16, PD_KBH = PD_H / 16, PD_KBPJ = PD_KBH + PD_KBC;
+constexpr uint32_t PD_SPIN_MAX = 1u << 20;
+
+// control words (zeroed before every launch): a 128-byte line per flag / counter shard
+constexpr int PD_F_P = 0, PD_F_C = 32 * 32, PD_CNT3 = 2 * 32 * 32, PD_CNT4 = PD_CNT3 + 256, PD_F_H = PD_CNT4 + 256, PD_CTL_WORDS = PD_F_H + 64 * 32;
+
+__device__ __forceinline__ uint32_t pd_ld_sc1(const uint32_t* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint2 pd_ld2_sc1(const uint2* p) {
+    uint2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void pd_st4_sc1(float* p, float4 v) {
+    f32x4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void pd_st2_sc1(uint2* p, uint2 v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void pd_st1_sc1(uint32_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void pd_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#define PD_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// the accumulator is "used" here: the FMAs that feed it cannot sink below what follows (a sched_barrier orders the machine
+// scheduler, not the IR passes before it)
+#define PD_PIN4(a) do { asm volatile("" : "+v"((a).x), "+v"((a).y), "+v"((a).z), "+v"((a).w) : : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+struct PdShared { int abort; };
+
+// ---- bounded waits: one wave polls (ONE read in flight), the workgroup joins behind a barrier
+__device__ __forceinline__ void pd_give_up(const PersistDecodeArgs& A, PdShared* sh, bool raise) {
+    if (raise) atomicOr(A.err, 2u);         // (word 0 of the context's give-up words: bit 0 the fused LSTM launch, bit 1 this kernel)
+    sh->abort = 1;
+}
+// flags [n] (a line each) all >= want
+__device__ __forceinline__ void pd_wait_flags(const PersistDecodeArgs& A, const uint32_t* f, int n, uint32_t want, PdShared* sh) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t spins = 0;
+        for (;;) {
+            const uint32_t v = lane < n ? pd_ld_sc1(f + lane * 32) : want;
+            if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(v >= want))) == 64) break;
+            if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
+            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+// sum of the 8 counter shards >= want
+__device__ __forceinline__ void pd_wait_count(const PersistDecodeArgs& A, const uint32_t* c, uint32_t want, PdShared* sh) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t spins = 0;
+        for (;;) {
+            uint32_t v = lane < 8 ? pd_ld_sc1(c + lane * 32) : 0u;
+#pragma unroll
+            for (int d = 1; d < 8; d <<= 1) v += __shfl_xor(v, d, 64);
+            if (__builtin_amdgcn_readfirstlane(v) >= want) break;
+            if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
+            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+// every storing wave has drained; then one lane signals for the workgroup
+__device__ __forceinline__ void pd_arrive(uint32_t* c) {
+    pd_drain();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(c + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- GEMM pieces (lean_body.h's arithmetic): wave w owns k-blocks w, w + 8, ... of a blocked A operand [kb][MT][64][4]
+// fragments i0 <= i < i1 of the wave's k-blocks kb = wave + 8 i, both M-tiles (MT == 1: the second is the first again, never stored)
+template <int I0, int I1, int NB>
+__device__ __forceinline__ void pd_xload(const float* base, int MT, float4 (&x0)[NB], float4 (&x1)[NB]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto rs = gt_rsrc(base, 0x7FFFF000u);
+    const uint32_t m1 = (uint32_t)min(1, MT - 1) * 1024u;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        const uint32_t so = (uint32_t)((wave + i * PD_NW) * MT) * 1024u;
+        x0[i] = gt_bload4_sc1(rs, (uint32_t)lane * 16u, so);
+        x1[i] = gt_bload4_sc1(rs, (uint32_t)lane * 16u, so + m1);
+    }
+}
+// b[OFF + i * STRIDE], i < KPW (compile-time indices only: the weight fragments must stay registers)
+template <int KPW, int OFF, int STRIDE, int NB>
+__device__ __forceinline__ void pd_mma(const float4 (&x0)[NB], const float4 (&x1)[NB], const float4 (&b)[NB], f32x4& a0, f32x4& a1) {
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int k = OFF + i * STRIDE;
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].x, b[k].x, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[k].x, b[k].x, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].y, b[k].y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[k].y, b[k].y, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].z, b[k].z, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[k].z, b[k].z, a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].w, b[k].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[k].w, b[k].w, a1, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void pd_spill(float* lds, int slab, const f32x4& a0, const f32x4& a1) {
+    float (*part)[32][17] = reinterpret_cast<float (*)[32][17]>(lds);
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { part[slab][q * 4 + v][r] = a0[v]; part[slab][16 + q * 4 + v][r] = a1[v]; }
+}
+// element (row = tid >> 4, col = tid & 15) = base + sum over the first `nslab` slabs (ascending)
+template <int NSLAB>
+__device__ __forceinline__ float pd_reduce(float* lds, float base) {
+    __syncthreads();
+    const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    float z = base;
+#pragma unroll
+    for (int w = 0; w < NSLAB; ++w) z += part[w][row][col];
+    __syncthreads();            // the slabs are re-used by the next reduction
+    return z;
+}
+// h . W_h (+ bias) of one tile from the fragments x0 / x1 of the whole state (8 k-blocks per wave).  ORDER16: the summation order
+// of the launch path's 16-wave workers (gt_lean_partial<16, 4, 2>: virtual wave v owns k-blocks v, v + 16, v + 32, v + 48; this
+// wave plays v = wave and v = wave + 8), else the 8-wave order of the projection launch's co-workers (gt_lean_partial<8, 8, 1>).
+template <bool ORDER16>
+__device__ __forceinline__ float pd_rec_tile(const float4 (&x0)[8], const float4 (&x1)[8], const float4 (&wh)[8], float bias, float* lds) {
+    const int wave = threadIdx.x >> 6;
+    if (ORDER16) {
+        f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+        pd_mma<4, 0, 2, 8>(x0, x1, wh, a0, a1);         // k-blocks wave + 16 j
+        pd_mma<4, 1, 2, 8>(x0, x1, wh, b0, b1);         // k-blocks wave + 8 + 16 j
+        pd_spill(lds, wave, a0, a1);
+        pd_spill(lds, wave + 8, b0, b1);
+        return pd_reduce<16>(lds, bias);
+    } else {
+        f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+        pd_mma<8, 0, 1, 8>(x0, x1, wh, a0, a1);
+        pd_spill(lds, wave, a0, a1);
+        return pd_reduce<8>(lds, bias);
+    }
+}
+// gates of tile-local column g*4+u (i, f, c~, o of unit tile*4+u; Appendix A.6, reference Taco2.py:79-85): lanes col < 4 own a unit;
+// h of the tile's 4 units leaves as ONE 16-byte write-through store per row (rows >= M are never stored)
+__device__ __forceinline__ void pd_gates_store(float z, float& c, float* hdst, int tile, int M, int MT) {
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+    float hv = 0.f;
+    if (col < 4 && row < M) {
+        const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
+        c = __builtin_fmaf(gf, c, gi * gg);
+        hv = go * gt_tanh(c);
+    }
+    const float h1v = __shfl_down(hv, 1, 16), h2v = __shfl_down(hv, 2, 16), h3v = __shfl_down(hv, 3, 16);
+    if (col == 0 && row < M) pd_st4_sc1(hdst + gt_blk_off(row, tile * 4, MT), make_float4(hv, h1v, h2v, h3v));
+}
+template <int KPW>
+__device__ __forceinline__ void pd_load_tile(const float* wp, int tile, float4 (&dst)[KPW]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float4* wl = reinterpret_cast<const float4*>(wp) + ((size_t)tile * (KPW * PD_NW) + wave) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) dst[i] = wl[(size_t)i * PD_NW * 64];
+}
+// a [32][16] tile of recurrent-half sums (thread = element) for another workgroup: 16-byte write-through stores, drained, one flag
+__device__ __forceinline__ void pd_publish_part(float v, float* dst, uint32_t* flag, uint32_t tag) {
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const float v1 = __shfl_down(v, 1, 16), v2 = __shfl_down(v, 2, 16), v3 = __shfl_down(v, 3, 16);
+    if ((col & 3) == 0) pd_st4_sc1(dst + row * 16 + col, make_float4(v, v1, v2, v3));
+    pd_drain();
+    __syncthreads();
+    if (threadIdx.x == 0) pd_st1_sc1(flag, tag);
+}
+
+struct PdW { float4 x1[3], h1[8], x2[8], h2[8]; };
+
+// ====================================================================================================================== phases
+// LSTM cell 1: z = [p | ctx] . W1x + part1 (= h1_{t-1} . W1h + b1).  split: the prenet part is multiplied as soon as the chains
+// have published it, the context part when it arrives (same accumulator, same k-block order as gt_lstm_x_kernel<8, 3>).
+__device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int t, int tile, float* lds, float& c1v, float p1v, PdShared* sh, bool split,
+                                        bool stream_x1 = false) {
+    const int par = t & 1, MT = A.MT;
+    if (stream_x1) pd_load_tile<3>(A.w1x, tile, W.x1);          // (the chain role: arrives while the other chains finish)
+    const float* xa = A.xa[par];
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    float4 x0[3], x1[3];
+    if (split) {
+        pd_wait_flags(A, A.ctl + PD_F_P, A.B, (uint32_t)t + 1u, sh);
+        if (sh->abort) return;
+        pd_xload<0, 2, 3>(xa, MT, x0, x1);
+        PD_PIN();
+        pd_mma<2, 0, 1, 3>(x0, x1, W.x1, a0, a1);
+        pd_wait_flags(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);
+        if (sh->abort) return;
+        pd_xload<2, 3, 3>(xa, MT, x0, x1);
+        PD_PIN();
+        pd_mma<1, 2, 1, 3>(x0, x1, W.x1, a0, a1);
+    } else {
+        pd_wait_flags(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);      // (a chain's context flag is set after its prenet flag)
+        if (sh->abort) return;
+        pd_xload<0, 3, 3>(xa, MT, x0, x1);
+        PD_PIN();
+        pd_mma<3, 0, 1, 3>(x0, x1, W.x1, a0, a1);
+    }
+    pd_spill(lds, threadIdx.x >> 6, a0, a1);
+    const float z = pd_reduce<8>(lds, p1v);
+    pd_gates_store(z, c1v, A.h1[par], tile, A.B, MT);
+    pd_arrive(A.ctl + PD_CNT3);
+}
+
+// LSTM cell 2: z = h1_t . W2x + part2; then, from the same fragments, recurrent halves of cell 1 for the NEXT step: a chain
+// workgroup's (help_tile >= 0, published for it) and this workgroup's own (with_rec1)
+__device__ __forceinline__ void pd_cell2(const PersistDecodeArgs& A, PdW& W, int t, int tile, float* lds, float& c2v, float p2v, float& p1_next, bool with_rec1,
+                                        PdShared* sh, int help_tile, bool stream_h1, bool stream_x2) {
+    const int par = t & 1, MT = A.MT;
+    if (stream_x2) pd_load_tile<8>(A.w2x, tile, W.x2);          // (the chain role: these registers belong to the chain's operands until here)
+    float4 wu[8];
+    if (help_tile >= 0) pd_load_tile<8>(A.w1h, help_tile, wu);  // (a chain workgroup's W1h tile, streamed: arrives during the wait)
+    if (stream_h1) pd_load_tile<8>(A.w1h, tile, W.h1);          // (layer-2 helpers keep W2h resident and stream their own W1h)
+    pd_wait_count(A, A.ctl + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+    if (sh->abort) return;
+    float4 x0[8], x1[8];
+    pd_xload<0, 8, 8>(A.h1[par], MT, x0, x1);
+    PD_PIN();
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    pd_mma<8, 0, 1, 8>(x0, x1, W.x2, a0, a1);
+    pd_spill(lds, threadIdx.x >> 6, a0, a1);
+    const float z = pd_reduce<8>(lds, p2v);
+    pd_gates_store(z, c2v, A.h2[par], tile, A.B, MT);
+    pd_arrive(A.ctl + PD_CNT4);
+    const int col = threadIdx.x & 15;
+    if (help_tile >= 0) {       // (the chain workgroup's half first: it is waited for sooner than this workgroup's own)
+        const float v = pd_rec_tile<true>(x0, x1, wu, A.b1h[help_tile * 16 + col], lds);
+        pd_publish_part(v, A.hpart + (size_t)help_tile * 512, A.ctl + PD_F_H + help_tile * 32, (uint32_t)t + 1u);
+    }
+    if (with_rec1) p1_next = pd_rec_tile<true>(x0, x1, W.h1, A.b1h[tile * 16 + col], lds);
+}
+
+// layer-2 recurrent half of this workgroup's tile from h2 in memory (+ a chain workgroup's, for helpers); tiles below co_tiles sum
+// in the projection launch's co-workers' order (8 waves), the others in the front launch's workers' (16 waves)
+__device__ __forceinline__ float pd_rec2(const PersistDecodeArgs& A, int t, const float* hbuf, const float4 (&wh)[8], int tile, int help_tile, float* lds) {
+    float4 wu[8];
+    if (help_tile >= 0) pd_load_tile<8>(A.w2h, help_tile, wu);
+    float4 x0[8], x1[8];
+    pd_xload<0, 8, 8>(hbuf, A.MT, x0, x1);
+    PD_PIN();
+    const int col = threadIdx.x & 15;
+    if (help_tile >= 0) {
+        const float v = help_tile < A.co_tiles ? pd_rec_tile<false>(x0, x1, wu, A.b2h[help_tile * 16 + col], lds)
+                                               : pd_rec_tile<true>(x0, x1, wu, A.b2h[help_tile * 16 + col], lds);
+        pd_publish_part(v, A.hpart + (size_t)(32 + help_tile) * 512, A.ctl + PD_F_H + (32 + help_tile) * 32, (uint32_t)t + 1u);
+    }
+    return tile < A.co_tiles ? pd_rec_tile<false>(x0, x1, wh, A.b2h[tile * 16 + col], lds) : pd_rec_tile<true>(x0, x1, wh, A.b2h[tile * 16 + col], lds);
+}
+__device__ __forceinline__ float pd_rec1_mem(const PersistDecodeArgs& A, const float* hbuf, const float4 (&wh)[8], int tile, float* lds) {
+    float4 x0[8], x1[8];
+    pd_xload<0, 8, 8>(hbuf, A.MT, x0, x1);
+    PD_PIN();
+    return pd_rec_tile<true>(x0, x1, wh, A.b1h[tile * 16 + (threadIdx.x & 15)], lds);
+}
+
+// Projection tile `ptile`, M-tile `pmt` (Taco2.py:112-118: r mel frames | stop logit) + the next step's prenet-0 pre-activations
+// (both layers are linear: gsttaco.cpp proj_z), gt_proj_lean_kernel's arithmetic
+__device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4 (&wp)[9], int t, int ptile, int pmt, float* lds, PdShared* sh) {
+    const int par = t & 1, MT = A.MT;
+    pd_wait_count(A, A.ctl + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+    if (sh->abort) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto rh = gt_rsrc(A.h2[par], 0x7FFFF000u);
+    const auto rx = gt_rsrc(A.xa[par], 0x7FFFF000u);
+    float4 x[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int kb = wave + i * PD_NW;                                // wave-uniform; k-blocks [0, 64) = h2, [64, 72) = context
+        x[i] = kb < PD_KBH ? gt_bload4_sc1(rh, (uint32_t)lane * 16u, (uint32_t)((kb * MT + pmt) * 1024))
+                           : gt_bload4_sc1(rx, (uint32_t)lane * 16u, (uint32_t)(((kb - PD_KBH + PD_KBP) * MT + pmt) * 1024));
+    }
+    PD_PIN();
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].x, wp[i].x, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].y, wp[i].y, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].z, wp[i].z, a0, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].w, wp[i].w, a0, 0, 0, 0);
+    }
+    pd_spill(lds, threadIdx.x >> 6, a0, a1);
+    const float v = pd_reduce<8>(lds, A.bp[ptile * 16 + (threadIdx.x & 15)]);
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const int grow = pmt * 16 + row, gcol = ptile * 16 + col;
+    if (row < 16 && grow < A.B) {
+        if (gcol >= A.z_col0) {
+            if (gcol < A.z_col0 + PD_P) {
+                uint2 g;
+                g.x = __builtin_bit_cast(uint32_t, v); g.y = (uint32_t)t + 1u;
+                pd_st2_sc1(A.z0g + (size_t)grow * PD_P + (gcol - A.z_col0), g);
+            }
+        } else if (gcol < A.n_split) {
+            A.pre[(size_t)grow * A.ld_pre + (size_t)t * A.n_split + gcol] = v;
+        } else if (gcol < A.n_out) {
+            A.stop[(size_t)grow * A.steps + t] = v;
+        }
+    }
+}
+
+// ---- the per-utterance chain (front_lean.h's arithmetic; every thread plays launch-path threads tid and tid + 512)
+struct PdChainLds {
+    float *y0, *y1, *qs, *vs, *sc, *nz, *pv, *al, *ks1, *partial, *red, *tile;
+};
+constexpr int PD_CHAIN_FLOATS = 2 * PD_P + 2 * PD_A + 4 * PD_TV + PD_P + 4096 + 8 * PD_A + PD_TV * PD_LDV;
+constexpr int PD_LDS_FLOATS = 16 * 32 * 17 + PD_CHAIN_FLOATS;
+__device__ __forceinline__ PdChainLds pd_carve(float* base) {
+    PdChainLds L;
+    L.y0 = base; L.y1 = L.y0 + PD_P; L.qs = L.y1 + PD_P; L.vs = L.qs + PD_A; L.sc = L.vs + PD_A; L.nz = L.sc + PD_TV; L.pv = L.nz + PD_TV;
+    L.al = L.pv + PD_TV; L.ks1 = L.al + PD_TV; L.partial = L.ks1 + PD_P; L.red = L.partial + 4096; L.tile = L.red + 8 * PD_A;
+    return L;
+}
+
+struct PdChainRegs { float bias1, biasq, sbias; int Tv; uint64_t seed; bool hashed, drop, noisy; };
+
+__device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int par = t & 1, Tv = R.Tv, TvFull = A.Tv, MT = A.MT;
+    // ---- ALL of prenet-1's weights for this step, requested before the projection's hand-off is even looked at.  Launch-path wave
+    // kp (of 16) owns rows 16 kp .. 16 kp + 15, lane = 4 output columns; this wave plays kp = wave and kp = wave + 8.  Hashed
+    // dropout (throughput mode): rows whose input the keep decisions zero are not requested (they would multiply an exact zero).
+    const auto rsW1 = gt_rsrc(A.W1, (uint32_t)(PD_P * PD_P) * 4u);
+    const auto rsWq = gt_rsrc(A.Wq, (uint32_t)(PD_P * PD_A) * 4u);
+    uint32_t rba = 0xFFFFu, rbb = 0xFFFFu;
+    if (R.hashed) {
+        const uint32_t w0 = gt_keep_word(R.seed, (uint32_t)t, 0u, (uint32_t)b, (uint32_t)wave >> 1);
+        const uint32_t w1 = gt_keep_word(R.seed, (uint32_t)t, 0u, (uint32_t)b, ((uint32_t)wave >> 1) + 4u);
+        rba = (w0 >> ((wave & 1) * 16)) & 0xFFFFu;
+        rbb = (w1 >> ((wave & 1) * 16)) & 0xFFFFu;
+    }
+    float4 ra[16], rb[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ra[i] = gt_bload4(rsW1, ((rba >> i) & 1u) ? (uint32_t)lane * 16u : GT_OOB, (uint32_t)((16 * wave + i) * PD_P * 4));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rb[i] = gt_bload4(rsW1, ((rbb >> i) & 1u) ? (uint32_t)lane * 16u : GT_OOB, (uint32_t)((16 * (wave + 8) + i) * PD_P * 4));
+    // small per-step operands: noise row, injected keep masks (parity mode)
+    float nzv = 0.f, k0 = 1.f, k1 = 1.f;
+    if (R.noisy && tid < Tv) nzv = A.noise[((size_t)t * A.B + b) * TvFull + tid];
+    if (R.drop && !R.hashed && tid < PD_P) {
+        const float* m = A.masks + (size_t)t * A.B * (2 * PD_P);
+        k0 = m[(size_t)b * PD_P + tid];
+        k1 = m[(size_t)A.B * PD_P + (size_t)b * PD_P + tid];
+    }
+    PD_PIN();
+    // ---- S1: this utterance's row of prenet-0 pre-activations (granules tagged with the step they are for)
+    if (tid < PD_P) {
+        uint2 g = pd_ld2_sc1(A.z0g + (size_t)b * PD_P + tid);
+        uint32_t spins = 0;
+        while (__builtin_amdgcn_readfirstlane(__popcll(__ballot(g.y == (uint32_t)t))) != 64) {
+            if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
+            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
+            g = pd_ld2_sc1(A.z0g + (size_t)b * PD_P + tid);
+        }
+        if (R.hashed) {
+            k0 = gt_drop_keep(R.seed, (uint32_t)t, 0u, (uint32_t)b, (uint32_t)tid, (uint32_t)PD_P, A.drop_rate);
+            k1 = gt_drop_keep(R.seed, (uint32_t)t, 1u, (uint32_t)b, (uint32_t)tid, (uint32_t)PD_P, A.drop_rate);
+        }
+        if (R.drop) { k0 *= A.drop_scale; k1 *= A.drop_scale; }
+        else { k0 = 1.f; k1 = 1.f; }
+        L.y0[tid] = fmaxf(__builtin_bit_cast(float, g.x), 0.f) * k0;
+        L.ks1[tid] = k1;
+    }
+    if (tid < Tv) L.nz[tid] = A.sigmoid_noise * nzv;
+    __syncthreads();
+    if (sh->abort) return;
+    // ---- prenet layer 1 (Taco2.py:262-283): two launch-path threads' 16-row sums each.  The query weights (Steps.py:122) are
+    // requested into the first half's registers as soon as it is consumed: launch-path thread = (4 output columns cgq, k-part kp of
+    // 8 rows), this thread plays kp = tid / 32 and 16 + tid / 32; rows whose input (mask 1) is dropped are not requested.
+    const int cgq = tid & 31, kpa = tid >> 5, kpb = 16 + (tid >> 5);
+    uint32_t qba = 0xFFu, qbb = 0xFFu;
+    if (R.hashed) {
+        qba = (gt_keep_word(R.seed, (uint32_t)t, 1u, (uint32_t)b, (uint32_t)kpa >> 2) >> ((8 * kpa) & 31)) & 0xFFu;
+        qbb = (gt_keep_word(R.seed, (uint32_t)t, 1u, (uint32_t)b, (uint32_t)kpb >> 2) >> ((8 * kpb) & 31)) & 0xFFu;
+    }
+    float4 (&qa)[16] = ra;
+    {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = L.y0[16 * wave + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            gt_fma4(acc, x[i], ra[i]);
+        }
+        PD_PIN4(acc);
+        *reinterpret_cast<float4*>(L.partial + wave * PD_P + 4 * lane) = acc;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qa[i] = gt_bload4(rsWq, ((qba >> i) & 1u) ? (uint32_t)cgq * 16u : GT_OOB, (uint32_t)((8 * kpa + i) * PD_A * 4));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qa[8 + i] = gt_bload4(rsWq, ((qbb >> i) & 1u) ? (uint32_t)cgq * 16u : GT_OOB, (uint32_t)((8 * kpb + i) * PD_A * 4));
+        PD_PIN();
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = L.y0[16 * (wave + 8) + i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            gt_fma4(acc, x[i], rb[i]);
+        }
+        PD_PIN4(acc);
+        *reinterpret_cast<float4*>(L.partial + (wave + 8) * PD_P + 4 * lane) = acc;
+    }
+    __syncthreads();
+    if (tid < PD_P) {
+        const float v = fmaxf(reduce_partial(L.partial, 16, PD_P, tid) + R.bias1, 0.f) * L.ks1[tid];
+        L.y1[tid] = v;
+    }
+    __syncthreads();
+    // ---- S2p: the prenet output leaves now (the LSTM-1 workgroups multiply it while the attention below runs)
+    float* xa = A.xa[par];
+    if (tid < 64) {
+        pd_st4_sc1(xa + gt_blk_off(b, 4 * tid, MT), *reinterpret_cast<const float4*>(L.y1 + 4 * tid));
+        pd_drain();
+        if (tid == 0) pd_st1_sc1(A.ctl + PD_F_P + b * 32, (uint32_t)t + 1u);
+    }
+    if (t > 0 && tid >= PD_NT - 64) {        // the last wave, meanwhile: this tile's layer-1 recurrent half from its helper must show step t
+        const int l2 = tid & 63;
+        uint32_t spins = 0;
+        for (;;) {
+            const uint32_t v = l2 < 1 ? pd_ld_sc1(A.ctl + PD_F_H + b * 32) : (uint32_t)t;
+            if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(v >= (uint32_t)t))) == 64) break;
+            if (++spins > PD_SPIN_MAX) { if (l2 == 0) pd_give_up(A, sh, true); break; }
+            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (l2 == 0) pd_give_up(A, sh, false); break; }
+        }
+    }
+    // ---- query projection
+    {
+        float x[8];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = L.y1[8 * kpa + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            gt_fma4(acc, x[i], qa[i]);
+        }
+        *reinterpret_cast<float4*>(L.partial + kpa * PD_A + 4 * cgq) = acc;
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = L.y1[8 * kpb + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            gt_fma4(acc, x[i], qa[8 + i]);
+        }
+        *reinterpret_cast<float4*>(L.partial + kpb * PD_A + 4 * cgq) = acc;
+    }
+    __syncthreads();
+    if (sh->abort) return;
+    if (t > 0) {                                    // (behind the barrier the flag poll joined: the helper's sums, consumed by cell 1)
+        const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
+        const float4 d1 = gt_bload4_sc1(rh, (uint32_t)((b * 512 + (tid & ~3)) * 4), 0u);
+        const int e = tid & 3;
+        p1v = e == 0 ? d1.x : e == 1 ? d1.y : e == 2 ? d1.z : d1.w;
+    }
+    if (tid < PD_A) L.qs[tid] = reduce_partial(L.partial, 32, PD_A, tid) + R.biasq;
+    __syncthreads();
+    // ---- scores (Steps.py:126-152): 8 lanes per memory row, 4 x 16-byte pieces each; rows tid / 8 and 64 + tid / 8
+#pragma unroll 1
+    for (int hh = 0; hh < 2; ++hh) {
+        const int row = hh * 64 + (tid >> 3), li = tid & 7;
+        f32x2 s2 = {0.f, 0.f};
+#pragma unroll 2
+        for (int j = 0; j < 4; ++j) {
+            const int a0 = 4 * (li + 8 * j);
+            const float4 m4 = *reinterpret_cast<const float4*>(L.tile + row * PD_LDV + a0);
+            const float4 q4 = *reinterpret_cast<const float4*>(L.qs + a0);
+            const float4 w4 = *reinterpret_cast<const float4*>(L.vs + a0);
+            s2 = __builtin_elementwise_fma(f32x2{w4.x, w4.y}, gt_tanh2(f32x2{q4.x, q4.y} + f32x2{m4.x, m4.y}), s2);
+            s2 = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, gt_tanh2(f32x2{q4.z, q4.w} + f32x2{m4.z, m4.w}), s2);
+        }
+        float s = s2.x + s2.y;
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) s += __shfl_xor(s, d, 64);
+        if (li == 0 && row < Tv) L.sc[row] = s + R.sbias;
+    }
+    __syncthreads();
+    // ---- noise + sigmoid + alignment: SMA (Steps.py:215-229) or BMA (Steps.py:168-199)
+    if (A.att_type == GSTTACO_ATT_SMA) {
+        if (tid < Tv) {
+            const int tt = tid;
+            float v = L.pv[tt] * gt_sigmoid(L.sc[tt] + (R.noisy ? L.nz[tt] : 0.f));
+            if (tt > 0) v = __builtin_fmaf(L.pv[tt - 1], 1.f - gt_sigmoid(L.sc[tt - 1] + (R.noisy ? L.nz[tt - 1] : 0.f)), v);
+            L.al[tt] = v;
+        }
+    } else {
+        if (tid < Tv) {
+            float s = L.sc[tid];
+            if (R.noisy) s += L.nz[tid];
+            L.sc[tid] = gt_sigmoid(s);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int per = (Tv + 63) / 64;
+            const int t0 = lane * per, t1 = min(Tv, t0 + per);
+            float run = 0.f;
+            for (int tt = t0; tt < t1; ++tt) run += logf(fminf(fmaxf(1.f - L.sc[tt], 1.17549435e-38f), 1.f));
+            float base = front_wave_incl_scan(run, lane) - run;
+            for (int tt = t0; tt < t1; ++tt) {
+                const float lg = logf(fminf(fmaxf(1.f - L.sc[tt], 1.17549435e-38f), 1.f));
+                L.al[tt] = expf(base);
+                base += lg;
+            }
+            run = 0.f;
+            for (int tt = t0; tt < t1; ++tt) run += L.pv[tt] / fminf(fmaxf(L.al[tt], 1e-10f), 1.f);
+            base = front_wave_incl_scan(run, lane) - run;
+            for (int tt = t0; tt < t1; ++tt) {
+                base += L.pv[tt] / fminf(fmaxf(L.al[tt], 1e-10f), 1.f);
+                L.al[tt] = L.sc[tt] * L.al[tt] * base;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < TvFull) A.align[(size_t)b * A.ld_align + (size_t)t * TvFull + tid] = tid < Tv ? L.al[tid] : 0.f;
+    // ---- context (Steps.py:160-166): lane = channel, 8 row groups (this thread plays groups tid / 128 and 4 + tid / 128)
+    {
+        const int ca = tid & (PD_A - 1);
+#pragma unroll 1
+        for (int hh = 0; hh < 2; ++hh) {
+            const int cp = hh * 4 + (tid >> 7);
+            float p0 = 0.f, p1 = 0.f;
+            int tt = cp;
+            for (; tt + 8 < Tv; tt += 16) {
+                p0 = __builtin_fmaf(L.al[tt], L.tile[tt * PD_LDV + ca], p0);
+                p1 = __builtin_fmaf(L.al[tt + 8], L.tile[(tt + 8) * PD_LDV + ca], p1);
+            }
+            if (tt < Tv) p0 = __builtin_fmaf(L.al[tt], L.tile[tt * PD_LDV + ca], p0);
+            float cacc = 0.f;
+            cacc += p0 + p1;
+            L.red[cp * PD_A + ca] = cacc;
+        }
+    }
+    __syncthreads();
+    if (tid < Tv) L.pv[tid] = L.al[tid];                    // (the next step's "previous alignment"; every read of pv is behind barriers)
+    if (tid < 64) {
+        if (tid < PD_A / 4) {
+            float c[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float z = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) z += L.red[w * PD_A + 4 * tid + e];
+                c[e] = z;
+            }
+            pd_st4_sc1(xa + gt_blk_off(b, PD_P + 4 * tid, MT), make_float4(c[0], c[1], c[2], c[3]));
+        }
+        pd_drain();
+        if (tid == 0) pd_st1_sc1(A.ctl + PD_F_C + b * 32, (uint32_t)t + 1u);
+    }
+}
+
+// ====================================================================================================================== roles
+// Register discipline: the roles are separate loops, each loading what IT keeps resident, so the allocation is the maximum over
+// the roles, not their sum.
+__device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* smem, PdShared* sh) {
+    float* lds = smem;
+    const PdChainLds L = pd_carve(smem + 16 * 32 * 17);
+    const int tile = blockIdx.x, b = blockIdx.x, tid = threadIdx.x, col = tid & 15;
+    const bool live = b < A.B;                                  // (batches below 32: the spare chain workgroups only run their LSTM tile)
+    // nothing of this tile's LSTM weights stays resident here: the chain's own operands (all of prenet 1's weights, prefetched)
+    // need the registers.  W1x / W2x (24 + 64 KB) are streamed per step into registers the chain has freed -- they arrive while the
+    // workgroup waits for the other chains / for h1 anyway -- and the tile's two recurrent halves come from helper workgroups.
+    PdW W;
+    float c1v = 0.f, c2v = 0.f, p1v = A.b1h[tile * 16 + col], p2v = A.b2h[tile * 16 + col];
+    PdChainRegs R{};
+    if (live) {
+        R.Tv = A.tok_len ? max(1, min(A.Tv, (int)A.tok_len[b])) : A.Tv;         // masked mode (A12): only the first tok_len[b] positions exist
+        R.drop = A.drop_rate > 0.f;
+        R.hashed = R.drop && A.keep_hash != 0;
+        R.noisy = A.sigmoid_noise > 0.f;
+        R.seed = R.hashed ? *A.seed_ptr : 0ull;
+        R.bias1 = tid < PD_P ? A.b1[tid] : 0.f;
+        R.biasq = tid < PD_A ? A.bq[tid] : 0.f;
+        R.sbias = A.score_bias[0];
+        // processed memory of utterance b -> LDS, once (rows >= T_v: zeros, as the launch path's bounded descriptor reads them)
+        const float4* src = reinterpret_cast<const float4*>(A.pm + (size_t)b * A.Tv * PD_A);
+        for (int e = tid; e < PD_TV * PD_A / 4; e += PD_NT) {
+            const int row = e / (PD_A / 4), c4 = e % (PD_A / 4);
+            *reinterpret_cast<float4*>(L.tile + row * PD_LDV + 4 * c4) = row < R.Tv ? src[(size_t)row * (PD_A / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < PD_A) L.vs[tid] = A.av[tid];
+        if (tid < PD_TV) L.pv[tid] = tid == 0 ? 1.f : 0.f;     // one-hot(0) initial alignment (Steps.py:201-206)
+    }
+    __syncthreads();
+    for (int t = 0; t < A.steps; ++t) {
+        if (live) {
+            pd_chain(A, L, R, t, b, sh, p1v);
+            if (sh->abort) return;
+        } else if (t > 0) {                                     // no chain to hide it behind: fetch the layer-1 half directly
+            pd_wait_flags(A, A.ctl + PD_F_H + tile * 32, 1, (uint32_t)t, sh);
+            if (sh->abort) return;
+            const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
+            const float4 d1 = gt_bload4_sc1(rh, (uint32_t)((tile * 512 + (tid & ~3)) * 4), 0u);
+            const int e = tid & 3;
+            p1v = e == 0 ? d1.x : e == 1 ? d1.y : e == 2 ? d1.z : d1.w;
+        }
+        pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, false, true);
+        if (sh->abort) return;
+        if (t > 0) {        // the layer-2 half from its helper, in the shadow of the wait for h1 (one flag, then one 16-byte load per thread)
+            pd_wait_flags(A, A.ctl + PD_F_H + (32 + tile) * 32, 1, (uint32_t)t, sh);
+            if (sh->abort) return;
+            const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
+            const float4 d2 = gt_bload4_sc1(rh, (uint32_t)(((32 + tile) * 512 + (tid & ~3)) * 4), 0u);
+            const int e = tid & 3;
+            p2v = e == 0 ? d2.x : e == 1 ? d2.y : e == 2 ? d2.z : d2.w;
+        }
+        float unused = 0.f;
+        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, true);
+        if (sh->abort) return;
+    }
+}
+
+__device__ __forceinline__ void pd_run_proj(const PersistDecodeArgs& A, float* lds, PdShared* sh) {
+    const int tile = blockIdx.x, col = threadIdx.x & 15;
+    const int pi = tile - PD_UTT, ptile = pi % A.pj_tiles, pmt = pi / A.pj_tiles;
+    // resident: the input halves of both cells and the projection tile (80 registers); the recurrent-half tiles run behind the
+    // projection, off the critical path, and are streamed
+    PdW W;
+    pd_load_tile<3>(A.w1x, tile, W.x1); pd_load_tile<8>(A.w2x, tile, W.x2);
+    float4 wpj[9];
+    pd_load_tile<9>(A.wp, ptile, wpj);
+    float c1v = 0.f, c2v = 0.f, p1v = A.b1h[tile * 16 + col], p2v = A.b2h[tile * 16 + col];
+    for (int t = 0; t < A.steps; ++t) {
+        const int par = t & 1;
+        pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, true);
+        if (sh->abort) return;
+        float unused = 0.f;
+        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, false);
+        if (sh->abort) return;
+        pd_proj(A, wpj, t, ptile, pmt, lds, sh);
+        if (sh->abort) return;
+        if (t + 1 == A.steps) break;
+        pd_load_tile<8>(A.w1h, tile, W.h1);
+        PD_PIN();
+        p1v = pd_rec1_mem(A, A.h1[par], W.h1, tile, lds);       // for step t + 1 (h1_t re-read: off the critical path)
+        pd_load_tile<8>(A.w2h, tile, W.h2);
+        PD_PIN();
+        p2v = pd_rec2(A, t, A.h2[par], W.h2, tile, -1, lds);
+    }
+}
+
+// HELP: 0 = plain; 1 / 2 = also the layer-1 / layer-2 recurrent half of chain workgroup `help_tile`.  A helper keeps three of its own
+// four weight tiles resident and streams the fourth (used off the critical path), so that the extra tile's fragments fit.
+template <int HELP>
+__device__ __forceinline__ void pd_run_plain(const PersistDecodeArgs& A, float* lds, PdShared* sh, int help_tile) {
+    const int tile = blockIdx.x, col = threadIdx.x & 15;
+    PdW W;
+    pd_load_tile<3>(A.w1x, tile, W.x1); pd_load_tile<8>(A.w2x, tile, W.x2);
+    if (HELP != 2) pd_load_tile<8>(A.w1h, tile, W.h1);
+    if (HELP != 1) pd_load_tile<8>(A.w2h, tile, W.h2);
+    float c1v = 0.f, c2v = 0.f, p1v = A.b1h[tile * 16 + col], p2v = A.b2h[tile * 16 + col];
+    for (int t = 0; t < A.steps; ++t) {
+        const int par = t & 1;
+        pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, true);
+        if (sh->abort) return;
+        pd_cell2(A, W, t, tile, lds, c2v, p2v, p1v, true, sh, HELP == 1 ? help_tile : -1, HELP == 2, false);
+        if (sh->abort) return;
+        if (t + 1 == A.steps) break;
+        if (HELP == 1) pd_load_tile<8>(A.w2h, tile, W.h2);      // (streamed: arrives during the wait)
+        pd_wait_count(A, A.ctl + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        if (sh->abort) return;
+        p2v = pd_rec2(A, t, A.h2[par], W.h2, tile, HELP == 2 ? help_tile : -1, lds);        // for step t + 1
+    }
+}
+
+__global__ __launch_bounds__(PD_NT) void gt_persist_decode_kernel(PersistDecodeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ PdShared sh;
+    if (threadIdx.x == 0) sh.abort = 0;
+    __syncthreads();
+    const int tile = blockIdx.x;
+    const int n_pj = A.pj_tiles * A.MT;
+#ifndef PD_ONLY
+#define PD_ONLY -1          // (register-budget diagnosis: compile one role alone)
+#endif
+    if (tile < PD_UTT) { if (PD_ONLY < 0 || PD_ONLY == 0) pd_run_chain(A, smem, &sh); }
+    else if (tile < PD_UTT + n_pj) { if (PD_ONLY < 0 || PD_ONLY == 1) pd_run_proj(A, smem, &sh); }
+    else {
+        const int hidx = tile - (PD_UTT + n_pj);            // 64 helpers: even = layer 1, odd = layer 2 of chain tile hidx / 2
+        if (hidx >= PD_HELP) { if (PD_ONLY < 0 || PD_ONLY == 2) pd_run_plain<0>(A, smem, &sh, -1); }
+        else if ((hidx & 1) == 0) { if (PD_ONLY < 0 || PD_ONLY == 3) pd_run_plain<1>(A, smem, &sh, hidx >> 1); }
+        else if (PD_ONLY < 0 || PD_ONLY == 4) pd_run_plain<2>(A, smem, &sh, hidx >> 1);
+    }
+}
+
+// z0 granules of step 0: the first frame is zero (Taco2.py:162-165), so prenet 0's pre-activations are its bias; + the control words
+__global__ void gt_persist_decode_init_kernel(uint2* z0g, const float* b0, uint32_t* ctl, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < PD_CTL_WORDS) ctl[i] = 0u;
+    if (i < B * PD_P) {
+        uint2 g;
+        g.x = __builtin_bit_cast(uint32_t, b0[i % PD_P]); g.y = 0u;
+        z0g[i] = g;
+    }
+}
+
+}  // namespace
+
+size_t gt_persist_decode_ctl_words() { return PD_CTL_WORDS; }
+
+bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots) {
+    (void)mel; (void)r;
+    return P0 == PD_P && P1 == PD_P && A == PD_A && H1 == PD_H && H2 == PD_H && B >= 1 && B <= 32 && Tv >= 1 && Tv <= PD_TV && pj_nkb == PD_KBPJ &&
+           pj_tiles >= 1 && PD_UTT + pj_tiles * ((B + 15) / 16) + PD_HELP <= PD_NWG && slots >= PD_NWG;
+}
+
+hipError_t gt_persist_decode_init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(gt_persist_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_FLOATS * 4);
+}
+
+int gt_persist_decode_blocks_per_cu() {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(gt_persist_decode_kernel), PD_NT, (size_t)PD_LDS_FLOATS * 4) != hipSuccess) return 0;
+    return n;
+}
+
+hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a, const float* b0, hipStream_t stream) {
+    const int n = PD_CTL_WORDS > a.B * PD_P ? PD_CTL_WORDS : a.B * PD_P;
+    hipLaunchKernelGGL(gt_persist_decode_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.z0g, b0, a.ctl, a.B);
+    hipLaunchKernelGGL(gt_persist_decode_kernel, dim3(PD_NWG), dim3(PD_NT), (size_t)PD_LDS_FLOATS * 4, stream, a);
+    return hipGetLastError();
+}

@@ -335,9 +335,16 @@ class GST_Tacotron:
     def debug_counters(self):
         """(persistent BiLSTM launches this context has enqueued, 1 while the context still uses the persistent launch) --
         ``gsttaco_debug_counters``."""
-        out = (ctypes.c_uint64 * 2)()
+        out = (ctypes.c_uint64 * 4)()
         self.ctx.check(self.ctx.lib.gsttaco_debug_counters(self.ctx.handle, out))
         return int(out[0]), int(out[1])
+
+    def decode_counters(self):
+        """(persistent decode launches this context has enqueued, 1 while the context still uses the persistent decode launch) --
+        the whole decoder loop as ONE launch (``csrc/persist_decode.hip``; ``gsttaco_debug_counters`` out[2:4])."""
+        out = (ctypes.c_uint64 * 4)()
+        self.ctx.check(self.ctx.lib.gsttaco_debug_counters(self.ctx.handle, out))
+        return int(out[2]), int(out[3])
 
     def graph_cache_size(self):
         return int(self.ctx.lib.gsttaco_graph_cache_size(self.ctx.handle))

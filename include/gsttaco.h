@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 10
+#define GSTTACO_ABI_VERSION 11
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -249,14 +249,15 @@ int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
 /* Diagnostic (GSTTACO_STAMPS=1): 3 x 16 phase stamps (100 MHz ticks) of workgroup 0 of the fused front kernel
  * and the two decode LSTM kernels at the middle decode step of the last replay.  Synchronises the device. */
 int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
-/* Two launches hand data between their workgroups INSIDE the kernel and therefore need those workgroups resident together: the
+/* Three launches hand data between their workgroups INSIDE the kernel and therefore need those workgroups resident together: the
  * persistent BiLSTM launch (one launch for all time steps of the encoder's / vocoder's Bidirectional LSTM, reference
- * Taco2.py:39-43, 394-398; the 32 workgroups of each of its groups) and the fused decode-LSTM launch (both LSTMCells of a decoder
- * step, Taco2.py:77-85,111, in one launch; all of its workgroups).  The library arranges that for everything it controls:
+ * Taco2.py:39-43, 394-398; the 32 workgroups of each of its groups), the persistent decode launch (the whole decoder loop,
+ * Taco2.py:153-228, in one launch of 256 workgroups) and the fused decode-LSTM launch (both LSTMCells of a decoder step,
+ * Taco2.py:77-85,111, in one launch; all of its workgroups).  The library arranges that for everything it controls:
  * exactly one persistent workgroup per compute unit, and the fused launches' whole grid against occupancy x compute units, are
  * checked at finalize; the persistent launches of ALL contexts of the process are chained on the GPU, so two of them never split
- * an XCD; the fused decode launch is taken only while the process has ONE live context, and another context's segments start
- * behind the fused launches still in flight (one recorded event per device).  What the library cannot see -- another process on
+ * an XCD; the fused / persistent decode launches are taken only while the process has ONE live context, and another context's
+ * segments start behind those still in flight (one recorded event per device).  What the library cannot see -- another process on
  * the GPU, a CU mask -- is caught by BOUNDED waits: a wait that gives up raises a word in host-mapped memory, the whole launch
  * drains at once, and
  *   - gsttaco_synchronize(ctx, stream) synchronises the stream and returns GSTTACO_E_HIP if that happened since the last check:
@@ -267,12 +268,15 @@ int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
  *     same results in fp32; under Use_Mixed_Precision the per-step BiLSTM kernel sums in a different order: within the mixed
  *     tolerance), succeeds, and leaves a "warning: ..." text in gsttaco_last_error.
  * Nothing stays poisoned and nothing hangs.  gsttaco_debug_handoff_error synchronises the device and returns what is pending,
- * i.e. raised and not yet reported by gsttaco_synchronize (bit 0: fused decode-LSTM launch, bit 8: persistent BiLSTM; 0 = clear). */
+ * i.e. raised and not yet reported by gsttaco_synchronize (bit 0: fused decode-LSTM launch, bit 1: persistent decode launch,
+ * bit 8: persistent BiLSTM; 0 = clear). */
 int gsttaco_synchronize(gsttaco_ctx* ctx, void* stream);
 int gsttaco_debug_handoff_error(gsttaco_ctx* ctx, uint32_t* host_out);
 /* Test support: out[0] = persistent BiLSTM launches this context has enqueued (eagerly or into a captured graph), out[1] = 1
- * while the context uses the persistent launch, 0 once it has fallen back to one launch per time step. */
-int gsttaco_debug_counters(const gsttaco_ctx* ctx, uint64_t out[2]);
+ * while the context uses the persistent launch, 0 once it has fallen back to one launch per time step; out[2] / out[3] the same
+ * for the persistent DECODE launch (the whole decoder loop of Taco2.py:153-228 as one launch: batch <= 32, T_v <= 128, fp32, the
+ * reference's decoder sizes, one live context; GSTTACO_PERSIST_DECODE=0 or a give-up: launches per step, bitwise the same). */
+int gsttaco_debug_counters(const gsttaco_ctx* ctx, uint64_t out[4]);
 /* Test support (fault injection).  bits 0..7 / 8..15: raise the fused launch's / the persistent BiLSTM's give-up word as a kernel
  * would.  bits 16..: n > 0 makes member n - 1 of every group of the NEXT persistent launches exit at once and the next fused
  * launches expect one arrival too many, so that their waits really run into the bound. */

@@ -162,12 +162,13 @@ def test_eager_graph_and_unfused_paths_agree(monkeypatch):
     assert np.abs(outs[0][0] - outs[2][0]).max() <= TOL and np.abs(outs[0][1] - outs[2][1]).max() <= TOL
 
 
-@pytest.mark.parametrize("env", [{"GSTTACO_FUSED_FRONT": "1"}, {"GSTTACO_FUSED_FRONT": "2"}])
+@pytest.mark.parametrize("env", [{"GSTTACO_FUSED_FRONT": "1"}, {"GSTTACO_FUSED_FRONT": "2", "GSTTACO_PERSIST_DECODE": "0"}, {"GSTTACO_FUSED_FRONT": "2"}])
 @pytest.mark.parametrize("att", ["SMA", "BMA"])
 def test_front_end_variants_match_oracle(monkeypatch, env, att):
-    """The fused front kernel exists as the general kernel (GSTTACO_FUSED_FRONT=1) and with the lean utterance path
-    (front_lean.h, buffer loads with counted waits; 2 = the default): the same function.  Each against the float64 oracle over
-    40 steps at full dimensions, injected and hashed (throughput-mode) dropout, 5 and 32 utterances."""
+    """The decode step's front end exists as the general fused kernel (GSTTACO_FUSED_FRONT=1), as the fused kernel with the lean
+    utterance path (front_lean.h, buffer loads with counted waits; 2 with GSTTACO_PERSIST_DECODE=0: the launch path's default) and
+    inside the persistent decode launch (persist_decode.hip, the default at these shapes): the same function.  Each against the
+    float64 oracle over 40 steps at full dimensions, injected and hashed (throughput-mode) dropout, 5 and 32 utterances."""
     import torch
     from oracle import oracle_np
     for k, v in env.items():
@@ -238,6 +239,7 @@ def test_fused_lstm_launch_is_bitwise_the_two_launches(monkeypatch, B, mixed):
     hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=17 + B)
     hp = dict(hp); hp["Use_Mixed_Precision"] = bool(mixed)      # (above 32 rows the fused launch also exists on bf16 operands)
     outs = {}
+    monkeypatch.setenv("GSTTACO_PERSIST_DECODE", "0")           # (the launch path: at <= 32 rows the default is the persistent launch)
     for flag in ("1", "0"):
         monkeypatch.setenv("GSTTACO_FUSED_LSTM", flag)
         m = _model(hp, w, B, Tv, Tref + 1)
@@ -255,16 +257,23 @@ def test_fused_lstm_launch_is_bitwise_the_two_launches(monkeypatch, B, mixed):
         assert np.abs(outs["1"][0] - ref[0]).max() <= TOL and np.abs(outs["1"][2] - ref[3]).max() <= TOL
 
 
-def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers():
-    """The fused launch's wait is bounded: with one arrival too many expected (fault injection) every workgroup runs into the
-    bound, the call's outputs are invalid and ``synchronize`` says so; the next call uses two launches and is correct."""
+@pytest.mark.parametrize("persist", ["0", "1"])
+def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers(monkeypatch, persist):
+    """The fused LSTM launch's wait (persist = 0) and the persistent decode launch's waits (1) are bounded: with one arrival too
+    many expected (fault injection) every workgroup runs into the bound, the call's outputs are invalid and ``synchronize``
+    says so; the next call uses the next launch form down (persistent -> fused -> two launches) and is correct."""
+    import gc
     import time
     import torch
     from gst_tacotron_amd.capi import GstTacoError
+    gc.collect()                                    # (both launch forms are taken only while the process has ONE live context)
+    monkeypatch.setenv("GSTTACO_PERSIST_DECODE", persist)
     hp, w, tokens, tl, mels, ml, masks, noise = _full_case(4, 24, 40, 3, seed=8)
     m = _model(hp, w, 4, 24, 41)
+    assert m.decode_counters()[1] == int(persist)
     ref = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=3)[0].cpu().numpy()
     m.synchronize()
+    assert m.decode_counters()[0] == int(persist)
     m.ctx.check(m.ctx.lib.gsttaco_debug_raise_handoff_error(m.ctx.handle, 1 << 16))
     t0 = time.perf_counter()
     m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=3)
@@ -274,6 +283,56 @@ def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers():
     out = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=3)[0].cpu().numpy()
     m.synchronize()
     assert np.array_equal(out, ref) and "warning" in m.last_message() and m.handoff_error() == 0
+    assert m.decode_counters()[1] == 0
+
+
+@pytest.mark.parametrize("B,Tv,att,mode", [(32, 128, "SMA", "hashed"), (32, 128, "BMA", "hashed"), (5, 40, "SMA", "injected"),
+                                           (17, 100, "BMA", "injected"), (9, 77, "SMA", "masked"), (16, 128, "SMA", "rate25"),
+                                           (3, 20, "SMA", "nodrop")])
+def test_persistent_decode_launch_is_bitwise_the_launches(monkeypatch, B, Tv, att, mode):
+    """The whole decoder loop as ONE persistent launch (csrc/persist_decode.hip: every GEMM weight resident in registers, the
+    utterances' processed memory in LDS, in-kernel hand-offs with bounded waits) against the launch path
+    (GSTTACO_PERSIST_DECODE=0: fused front launch + fused LSTM launch + projection launch per step): the SAME arithmetic in
+    the same order -- mel, stop and alignment outputs bitwise equal over 150 steps at full dimensions, which is also the test
+    that no in-kernel hand-off ever delivers a stale word.  Hashed (throughput-mode) and injected dropout, a rate the hash
+    does not cover (masks from the buffer), no dropout, SMA and BMA, batches of one and two M-tiles, ragged batches in masked
+    mode, repeated calls; and the persistent form against the float64 oracle."""
+    import gc
+    import torch
+    from oracle import oracle_np
+    gc.collect()                                    # (the persistent launch is taken only while the process has ONE live context)
+    steps, Tref = 150, 60
+    rate = {"rate25": 0.25, "nodrop": 0.0}.get(mode, 0.5)
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=40 + B, att=att, rate=rate)
+    kw = dict(steps=steps)
+    if mode == "injected" or mode == "masked":
+        kw.update(prenet_masks=masks, attn_noise=noise)
+    else:
+        kw.update(seed=77)
+    if mode == "masked":
+        tl = np.random.default_rng(3).integers(Tv // 3, Tv + 1, B).astype(np.int32)
+        tl[0] = Tv
+        kw.update(masked=True)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GSTTACO_PERSIST_DECODE", flag)
+        m = _model(hp, w, B, Tv, Tref + 1)
+        for rep in range(2):
+            mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, **kw)
+        m.synchronize()
+        assert m.handoff_error() == 0
+        n_persist, on = m.decode_counters()            # (enqueued once: the second call replays the captured graph)
+        assert (n_persist >= 1 and on == 1) if flag == "1" else (n_persist == 0 and on == 0)
+        outs[flag] = (mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy())
+        if flag == "1" and mode == "injected":
+            ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
+            assert np.abs(outs[flag][0] - ref[0]).max() <= TOL and np.abs(outs[flag][2] - ref[3]).max() <= TOL
+        del m, mel, stop, align
+        gc.collect()
+    monkeypatch.delenv("GSTTACO_PERSIST_DECODE")
+    assert np.isfinite(outs["1"][0]).all()
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.array_equal(a, b)
 
 
 def test_on_device_randomness_is_seeded():
