@@ -354,7 +354,20 @@ def main():
         ms, cnt = ctypes.c_float(), ctypes.c_int()
         model.ctx.check(lib.gsttaco_get_profile(handle, which, ctypes.byref(ms), ctypes.byref(cnt)))
         prof[which] = (ms.value, cnt.value, int(lib.gsttaco_lstm_launch_bytes(handle, which, B)))
-    if prof[1][1] == 0 and prof[0][1] > 0:
+    n_steps_dec = model.dims.steps
+    persistent = model.decode_counters()[0] > 0
+    if persistent:
+        # the whole decode loop ran as ONE persistent launch (csrc/persist_decode.hip): one bracket around it; a decode step is
+        # 1 / steps of it.  Algorithmic bytes per step as SURVEY 8(d) defines them (every weight once PER STEP + the activations),
+        # although this kernel keeps the weights in registers: the compulsory variant (weights once per launch) is reported beside it.
+        step_bytes_all = sum(v[2] for v in prof.values())
+        act_bytes = 4 * B * (Tv * 128 + 2 * Tv + 2 * 4 * 1024 + (model.dims.mel * model.dims.r + 1 + Tv))       # SURVEY 8(d) row "activation bytes per step"
+        ms_total, cnt_total = prof[2][0], prof[2][1]
+        prof = {2: (ms_total / n_steps_dec, cnt_total * n_steps_dec, step_bytes_all)}
+        KNAMES[2] = ("gt_persist_decode_kernel, 1 / {} of it (the whole decoder loop as ONE persistent launch: weights resident in registers, "
+                     "processed memory in LDS, in-kernel hand-offs; a step = prenet + query + attention + both LSTM cells + projection)".format(n_steps_dec))
+        KPMC[2] = "gt_persist_decode_kernel"
+    elif prof[1][1] == 0 and prof[0][1] > 0:
         # both decode LSTM cells ran as ONE launch (gt_lstm12_kernel, in-kernel hand-off of h1): one bracket, both cells' bytes
         prof[0] = (prof[0][0], prof[0][1], prof[0][2] + prof[1][2])
         del prof[1]
@@ -419,6 +432,9 @@ def main():
         cfg_tag = {(32, False): "cfg2", (128, False): "cfg3", (64, True): "cfg5"}.get((args.batch_per_gpu, bool(args.mixed)))
         traffic, traffic_src = pmc_traffic(KPMC[dom], cfg_tag)
         rp_us, rp_src = rocprof_avg_us(KPMC[dom], cfg_tag)
+        if persistent:          # (the committed figures are per launch = per decode loop; everything below is per step)
+            rp_us = rp_us / n_steps_dec if rp_us else None
+            traffic = traffic / n_steps_dec if traffic else None
         step_us = sum(v[0] for v in prof.values()) * 1e3
         step_bytes = sum(v[2] for v in prof.values())
         # the decode step's GEMM work (prenet-1, query, both LSTM cells, projection + fused prenet-0): what bounds it at batches
@@ -441,6 +457,8 @@ def main():
                        1: 2 * B * H1 * 4 * H2,
                        2: 2 * B * (P0 * P1 + P1 * A_) + 2 * B * H1 * 4 * H1 + 2 * B * H2 * 4 * H2 * (1.0 - (128.0 if B > 32 else 64.0) / max(H2 // 4, 1)),
                        3: 2 * B * (H2 + A_) * (dd.mel * dd.r + 1 + P0) + 2 * B * H2 * 4 * H2 * ((128.0 if B > 32 else 64.0) / max(H2 // 4, 1))}[dom]
+        if persistent:
+            launch_flop = step_flop
         if step_bound == "mfma":
             achieved, peak, unit = launch_flop / (dur_us * 1e-6) / 1e12, mfma_peak, "TFLOP/s"
             achieved_raw = launch_flop / (ms1 * 1e-3) / 1e12 if ms1 > 0 else 0.0
@@ -472,11 +490,18 @@ def main():
                                         "resident in the 256 MiB MALL; the memory-side counters count those hits); shared "
                                         "activations: XCD L2.  `peak` is the HBM3E spec rate the guide names for the hbm bound",
                          "bytes_per_launch": bytes1,
+                         "persistent_decode": ({"launch_us": ms1 * 1e3 * n_steps_dec, "steps_per_launch": n_steps_dec,
+                                                "compulsory_bytes_per_step": (step_bytes_all - act_bytes) / n_steps_dec + act_bytes,
+                                                "frac_compulsory": ((step_bytes_all - act_bytes) / n_steps_dec + act_bytes) / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                "note": "achieved / frac price the step at SURVEY 8(d)'s algorithmic bytes (every weight once per step); "
+                                                        "this kernel reads the weights once per LAUNCH -- frac_compulsory counts them so: the step is "
+                                                        "bound by its dependent hand-offs (in-kernel all-to-alls of h1 / h2, ~3 us each), not by bytes"}
+                                               if persistent else None),
                          "avg_launch_us": ms1 * 1e3, "launches_timed": cnt1, "empty_event_bracket_us": bracket_ms * 1e3,
                          "avg_launch_us_rocprofv3": rp_us, "rocprofv3_source": rp_src,
                          "step_frac": max(step_frac_hbm, step_frac_mfma),
                          "step_bound": step_bound,
-                         "step_frac_note": "whole decode step (3-4 launches; x 500 = 88 % of the run): algorithmic bytes / sum of the bracketed "
+                         "step_frac_note": "whole decode step (one persistent launch for all steps, or 3-4 launches per step; x 500 = 86 % of the run): algorithmic bytes / sum of the bracketed "
                                            "launch times / 8 TB/s, or GEMM FLOP / the same time / the dense MFMA peak of the compute "
                                            "dtype, whichever is larger (fp32 MFMA overtakes the weight stream above 32 rows)",
                          "postnet": post,
@@ -484,7 +509,9 @@ def main():
                                          "GB/s": step_bytes / step_us / 1e3 if step_us > 0 else 0.0,
                                          "frac_hbm": step_frac_hbm, "gemm_flop": step_flop,
                                          "TFLOP/s": step_flop / (step_us * 1e-6) / 1e12 if step_us > 0 else 0.0, "frac_mfma": step_frac_mfma,
-                                         "kernels": {str(k): {"name": KNAMES[k], "avg_us": prof[k][0] * 1e3, "bytes": prof[k][2]}
+                                         "kernels": {str(k): dict({"name": KNAMES[k], "avg_us": prof[k][0] * 1e3, "bytes": prof[k][2]},
+                                                                  **({"compulsory_bytes_per_launch": (step_bytes_all - act_bytes) + act_bytes * n_steps_dec}
+                                                                     if persistent else {}))
                                                      for k in prof}}},
         }
         if world == 1 and not args.no_serving:

@@ -64,11 +64,13 @@ if os.path.exists(bl) and res:
     rows_chk = []
     for k, v in ((line.get("roofline") or {}).get("decode_step") or {}).get("kernels", {}).items():
         sym = v["name"].split(" ")[0].split("<")[0]
-        hits = [(n, r) for n, r in res.items() if sym in n and r["dispatches"] >= 20]       # (the step kernels: hundreds of dispatches)
+        hits = [(n, r) for n, r in res.items() if sym in n and r["dispatches"] >= 2]
         if not hits:
             continue
         n, r = max(hits, key=lambda x: x[1]["dispatches"])
         traffic = r["hbm_read_bytes_corrected"] + r["hbm_write_bytes"]
+        if "compulsory_bytes_per_launch" in v:      # the persistent decode launch: weights once per launch + the activations of every step
+            v = dict(v, bytes=v["compulsory_bytes_per_launch"])
         ok = v["bytes"] <= 1.02 * traffic
         rows_chk.append(f"{'ok ' if ok else 'BAD'} {sym}: algorithmic {v['bytes'] / 1e6:.2f} MB, PMC traffic {traffic / 1e6:.2f} MB per launch (x{traffic / max(v['bytes'], 1):.2f})")
         if not ok:
