@@ -183,7 +183,30 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
 #define BKH 64
 #define LDH (BKH + 8)
 
-template <int RM>
+// 4 consecutive channels of an activation row as fp32, from an fp32 or a bf16 buffer (element index `idx`, a multiple of 4)
+__device__ __forceinline__ float4 gt_act_load4(const float* x, const int64_t idx, const bool bf16) {
+    if (!bf16) return *reinterpret_cast<const float4*>(x + idx);
+    const uint2 h = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(x) + idx);
+    return make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xFFFF0000u),
+                       __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xFFFF0000u));
+}
+// Epilogue store of two vertically adjacent elements (rows m0 / m1, column n) of a 32x32 accumulator tile as bf16: adjacent lanes
+// exchange so that each owns a PAIR of adjacent columns of ONE of the two rows -- one 4-byte store instead of two 2-byte ones
+// (even lanes keep row m0, odd lanes row m1).  All 64 lanes must call.
+__device__ __forceinline__ void gt_store_pair_bf16(float* out, const int64_t ldo, const int n, const bool n_ok, const float v0, const float v1,
+                                                   const int64_t m0, const int64_t m1, const int64_t row_limit) {
+    const bool odd = threadIdx.x & 1;
+    const float recv = __shfl_xor(odd ? v0 : v1, 1, 64);
+    const float lo = odd ? recv : v0, hi = odd ? v1 : recv;       // columns (n & ~1, n | 1) of row m0 (even lanes) / m1 (odd lanes)
+    const int64_t m = odd ? m1 : m0;
+    if (m < row_limit && n_ok) {
+        bf16x2 h;
+        h[0] = (__bf16)lo; h[1] = (__bf16)hi;
+        *reinterpret_cast<bf16x2*>(reinterpret_cast<__bf16*>(out) + m * ldo + (n & ~1)) = h;
+    }
+}
+
+template <int RM, bool XB = false, bool OB = false>
 __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) {
     constexpr int BM = 2 * RM * 32, BN = 128, RN = 2;
     constexpr int A_F4 = BM * (BKH / 4) / 256;          // float4 (4 k of one row) per thread per slice
@@ -232,10 +255,10 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
                 const int ts = a_t[i] + tap - A.pad_before;
                 if (ts >= 0 && ts < a_len[i]) {
                     const int64_t rowi = (int64_t)a_b[i] * A.T + ts;
-                    const float* rp = A.tokens ? A.x + (int64_t)A.tokens[rowi] * A.Cin : A.x + rowi * A.Cin;
-                    v = *reinterpret_cast<const float4*>(rp + c);
+                    const int64_t ri = A.tokens ? (int64_t)A.tokens[rowi] * A.Cin : rowi * A.Cin;
+                    v = gt_act_load4(A.x, ri + c, XB);
                     if (A.pool2 && ts + 1 < a_len[i]) {
-                        const float4 v2 = *reinterpret_cast<const float4*>(rp + A.Cin + c);
+                        const float4 v2 = gt_act_load4(A.x, ri + A.Cin + c, XB);
                         v.x = fmaxf(v.x, v2.x); v.y = fmaxf(v.y, v2.y); v.z = fmaxf(v.z, v2.z); v.w = fmaxf(v.w, v2.w);
                     }
                 }
@@ -294,21 +317,31 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
 #pragma unroll
     for (int j = 0; j < RN; ++j) {
         const int n = n0 + (wn * RN + j) * 32 + l31;
-        if (n >= A.N) continue;
-        const float sc = A.scale ? A.scale[n] : 1.f;
-        const float sh = A.shift ? A.shift[n] : 0.f;
+        const bool n_ok = n < A.N;
+        const int nc = n_ok ? n : 0;                    // (columns beyond N: computed on column 0's parameters, never stored)
+        const float sc = A.scale ? A.scale[nc] : 1.f;
+        const float sh = A.shift ? A.shift[nc] : 0.f;
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
+            auto row_of = [&](const int e) { return (int64_t)(m0 + (wm * RM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh); };
+            auto value = [&](const int e) {
+                const int64_t m = min(row_of(e), (int64_t)Mtot - 1);
+                float x = acc[i][j][e] * sc + sh;
+                if (A.rowbias) x += A.rowbias[(m / A.T) * A.N + nc];
+                if (A.act == ACT_RELU) x = fmaxf(x, 0.f);
+                else if (A.act == ACT_TANH) x = gt_tanh(x);
+                if (A.res) x += A.res[m * A.ldo + nc];
+                return x;
+            };
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * RM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                if (m >= Mtot) continue;
-                float v = acc[i][j][e] * sc + sh;
-                if (A.rowbias) v += A.rowbias[(int64_t)(m / A.T) * A.N + n];
-                if (A.act == ACT_RELU) v = fmaxf(v, 0.f);
-                else if (A.act == ACT_TANH) v = gt_tanh(v);
-                if (A.res) v += A.res[(int64_t)m * A.ldo + n];
-                A.out[(int64_t)m * A.ldo + n] = v;
+            for (int e = 0; e < 16; e += 2) {
+                const float v0 = value(e), v1 = value(e + 1);
+                if (OB) {
+                    gt_store_pair_bf16(A.out, A.ldo, n, n_ok, v0, v1, row_of(e), row_of(e + 1), (int64_t)Mtot);
+                } else {
+                    if (n_ok && row_of(e) < Mtot) A.out[row_of(e) * A.ldo + n] = v0;
+                    if (n_ok && row_of(e + 1) < Mtot) A.out[row_of(e + 1) * A.ldo + n] = v1;
+                }
             }
         }
     }
@@ -328,7 +361,8 @@ constexpr int C5_BM = 256, C5_BK = 64, C5_LD = C5_BK + 8, C5_AR = C5_BM + 4;
 template <int RN>       // 32-column tiles per wave: the workgroup tile is 256 frames x (2 * RN * 32) channels
 constexpr int c5_lds_bytes() { return 2 * (C5_AR + 2 * RN * 32) * C5_LD * 2; }
 
-template <int RN>
+// XB / OB: the input / output activations are stored as bf16 (compile-time: as run-time flags both forms' registers were live at once)
+template <int RN, bool XB = false, bool OB = false>
 __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
     constexpr int BN = 2 * RN * 32, RM = 2;
     constexpr int A_F4 = (C5_AR * (C5_BK / 4) + 511) / 512;      // float4 pieces (4 channels of one row) per thread per slice
@@ -340,10 +374,14 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves: 64 frames x (RN * 32) channels each
     const int tiles_t = (A.T + C5_BM - 1) / C5_BM;
-    const int b = blockIdx.x / tiles_t, t0 = (blockIdx.x % tiles_t) * C5_BM;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid: the column blocks of one frame tile sit 8 block indices apart = on ONE XCD under the round-robin block -> XCD deal, at
+    // the same time (speed only, never correctness): the second read of the tile's input rows is an L2 hit
+    const int ncb = (A.N + BN - 1) / BN;
+    const int bx = ((int)blockIdx.x / (8 * ncb)) * 8 + ((int)blockIdx.x & 7), by = ((int)blockIdx.x >> 3) % ncb;
+    if (bx >= A.B * tiles_t) return;
+    const int b = bx / tiles_t, t0 = (bx % tiles_t) * C5_BM;
+    const int n0 = by * BN;
     const int len = A.row_len ? min(A.T, A.row_len[b]) : A.T;    // masked mode: input rows >= len read as zero
-    const float* xb = A.x + (int64_t)b * A.T * A.Cin;
     const __bf16* wt = reinterpret_cast<const __bf16*>(A.wt_bf16);
 
     f32x16 acc[RM][RN];
@@ -366,7 +404,7 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
             const int f = tid + (half * A_H0 + i) * 512;
             const int row = f >> 4, t = t0 - A.pad_before + row;
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < C5_AR && t >= 0 && t < len) ra[i] = *reinterpret_cast<const float4*>(xb + (int64_t)t * A.Cin + k0 + (f & 15) * 4);
+            if (row < C5_AR && t >= 0 && t < len) ra[i] = gt_act_load4(A.x, ((int64_t)b * A.T + t) * A.Cin + k0 + (f & 15) * 4, XB);
         }
     };
     auto store_a = [&](const int buf, const int half) {
@@ -432,25 +470,49 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
         __syncthreads();
     }
 
+    if constexpr (!OB) {
 #pragma unroll
-    for (int j = 0; j < RN; ++j) {
-        const int n = n0 + (wn * RN + j) * 32 + l31;
-        if (n >= A.N) continue;
-        const float sc = A.scale ? A.scale[n] : 1.f;
-        const float sh = A.shift ? A.shift[n] : 0.f;
+        for (int j = 0; j < RN; ++j) {
+            const int n = n0 + (wn * RN + j) * 32 + l31;
+            if (n >= A.N) continue;
+            const float sc = A.scale ? A.scale[n] : 1.f;
+            const float sh = A.shift ? A.shift[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < RM; ++i) {
+            for (int i = 0; i < RM; ++i) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int t = t0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                if (t >= A.T) continue;
-                const int64_t m = (int64_t)b * A.T + t;
-                float v = acc[i][j][e] * sc + sh;
-                if (A.rowbias) v += A.rowbias[(int64_t)b * A.N + n];
-                if (A.act == ACT_RELU) v = fmaxf(v, 0.f);
-                else if (A.act == ACT_TANH) v = gt_tanh(v);
-                if (A.res) v += A.res[m * A.ldo + n];
-                A.out[m * A.ldo + n] = v;
+                for (int e = 0; e < 16; ++e) {
+                    const int t = t0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    if (t >= A.T) continue;
+                    const int64_t m = (int64_t)b * A.T + t;
+                    float v = acc[i][j][e] * sc + sh;
+                    if (A.rowbias) v += A.rowbias[(int64_t)b * A.N + n];
+                    if (A.act == ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (A.act == ACT_TANH) v = gt_tanh(v);
+                    if (A.res) v += A.res[m * A.ldo + n];
+                    A.out[m * A.ldo + n] = v;
+                }
+            }
+        }
+    } else {
+        // bf16 output (an intermediate of a bf16 chain: no residual here): pairs of rows, adjacent lanes exchange (gt_store_pair_bf16)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+            const int n = n0 + (wn * RN + j) * 32 + l31;
+            const bool n_ok = n < A.N;
+            const int nc = n_ok ? n : 0;
+            const float sc = A.scale ? A.scale[nc] : 1.f;
+            const float sh = (A.shift ? A.shift[nc] : 0.f) + (A.rowbias ? A.rowbias[(int64_t)b * A.N + nc] : 0.f);
+            const int64_t m_end = (int64_t)(b + 1) * A.T;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const int64_t m0r = (int64_t)b * A.T + t0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;     // (frames past T land beyond m_end)
+                    float v0 = acc[i][j][e] * sc + sh, v1 = acc[i][j][e + 1] * sc + sh;
+                    if (A.act == ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                    else if (A.act == ACT_TANH) { v0 = gt_tanh(v0); v1 = gt_tanh(v1); }
+                    gt_store_pair_bf16(A.out, A.ldo, n, n_ok, v0, v1, m0r, m0r + 1, m_end);
+                }
             }
         }
     }
@@ -461,9 +523,14 @@ static bool gt_conv5_bf16_applies(const ConvGemmArgs& a) {
 }
 
 hipError_t gt_conv5_bf16_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv5_bf16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, c5_lds_bytes<4>());
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv5_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, c5_lds_bytes<2>());
+    hipError_t e = hipSuccess;
+#define GT_C5_ATTR(RN, XB, OB)                                                                                                                    \
+    if (e == hipSuccess)                                                                                                                          \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv5_bf16_kernel<RN, XB, OB>), hipFuncAttributeMaxDynamicSharedMemorySize, c5_lds_bytes<RN>());
+    GT_C5_ATTR(4, false, false) GT_C5_ATTR(4, true, false) GT_C5_ATTR(4, false, true) GT_C5_ATTR(4, true, true)
+    GT_C5_ATTR(2, false, false) GT_C5_ATTR(2, true, false) GT_C5_ATTR(2, false, true) GT_C5_ATTR(2, true, true)
+#undef GT_C5_ATTR
+    return e;
 }
 
 // ---------------------------------------------------------------------------------------------------- Winograd F(2, 5)
@@ -734,17 +801,34 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const int M = a.B * a.T;
     if (gt_conv5_bf16_applies(a)) {         // five taps sharing one staged input tile (256 frames of one utterance per workgroup)
         const int tiles_t = (a.T + C5_BM - 1) / C5_BM;
-        if (a.N > 128) hipLaunchKernelGGL((gt_conv5_bf16_kernel<4>), dim3(a.B * tiles_t, (a.N + 255) / 256), dim3(512), c5_lds_bytes<4>(), stream, a);
-        else hipLaunchKernelGGL((gt_conv5_bf16_kernel<2>), dim3(a.B * tiles_t, 1), dim3(512), c5_lds_bytes<2>(), stream, a);
+        const int nx8 = (a.B * tiles_t + 7) / 8 * 8;         // (1-D grids: frame tiles rounded up to 8 x column blocks, see the kernel)
+        const dim3 g4(nx8 * ((a.N + 255) / 256)), g2(nx8);
+#define GT_C5_LAUNCH(XB, OB)                                                                                                       \
+        do {                                                                                                                       \
+            if (a.N > 128) hipLaunchKernelGGL((gt_conv5_bf16_kernel<4, XB, OB>), g4, dim3(512), c5_lds_bytes<4>(), stream, a);     \
+            else hipLaunchKernelGGL((gt_conv5_bf16_kernel<2, XB, OB>), g2, dim3(512), c5_lds_bytes<2>(), stream, a);               \
+        } while (0)
+        if (a.x_bf16 && a.out_bf16) GT_C5_LAUNCH(true, true);
+        else if (a.x_bf16) GT_C5_LAUNCH(true, false);
+        else if (a.out_bf16) GT_C5_LAUNCH(false, true);
+        else GT_C5_LAUNCH(false, false);
+#undef GT_C5_LAUNCH
         return hipGetLastError();
     }
     if (a.wt_bf16) {
         const int nb = (a.N + 127) / 128;
-        if (((M + 127) / 128) * nb >= 256) {
-            hipLaunchKernelGGL((gt_conv_gemm_bf16_kernel<2>), dim3((M + 127) / 128, nb), dim3(256), 0, stream, a);
-        } else {
-            hipLaunchKernelGGL((gt_conv_gemm_bf16_kernel<1>), dim3((M + 63) / 64, nb), dim3(256), 0, stream, a);
-        }
+        const bool big = ((M + 127) / 128) * nb >= 256;
+        const dim3 gb((M + 127) / 128, nb), gs((M + 63) / 64, nb);
+#define GT_CG_LAUNCH(XB, OB)                                                                                              \
+        do {                                                                                                              \
+            if (big) hipLaunchKernelGGL((gt_conv_gemm_bf16_kernel<2, XB, OB>), gb, dim3(256), 0, stream, a);              \
+            else hipLaunchKernelGGL((gt_conv_gemm_bf16_kernel<1, XB, OB>), gs, dim3(256), 0, stream, a);                  \
+        } while (0)
+        if (a.x_bf16 && a.out_bf16) GT_CG_LAUNCH(true, true);
+        else if (a.x_bf16) GT_CG_LAUNCH(true, false);
+        else if (a.out_bf16) GT_CG_LAUNCH(false, true);
+        else GT_CG_LAUNCH(false, false);
+#undef GT_CG_LAUNCH
         return hipGetLastError();
     }
     if (gt_conv_wino5_applies(a)) {

@@ -887,7 +887,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     // reference's decoder sizes, SMA / BMA -- while this is the process's only live context (its hand-offs need every workgroup resident).
     // Bitwise the launches below (GPU test), which stay the path for every other shape, for several contexts, and after a give-up.
     {
-        const bool base = c->persist_now && !c->stamps && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->front_mode >= 2 &&
+        const bool base = c->persist_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->front_mode >= 2 &&
                           !c->lstm_x[0].bf16 && !c->lstm_x[1].bf16 && !c->proj_z.bf16 && c->proj_z.wp != nullptr && c->proj.nkb >= 32 &&
                           c->worker_tiles == 2 && c->co_worker_tiles == 1 && g.att_type != GSTTACO_ATT_LSA &&
                           gt_dec_front_supported(mel, P0, P1, att, Tv) && c->lstm_x[0].nkb == 24 && c->lstm_x[1].nkb == 64 && c->lstm_h[0].nkb == 64 &&
@@ -913,6 +913,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             a.pre = c->w_pre; a.ld_pre = ld_pre; a.stop = c->w_stop; a.align = c->w_align; a.ld_align = (int64_t)steps * Tv;
             a.B = B; a.MT = MT; a.Tv = Tv; a.steps = steps; a.co_tiles = co_tiles;
             a.expect_extra = c->debug_drop_member >= 0 ? 1 : 0;
+            a.dbg = c->stamps ? c->w_dbg : nullptr;
             const bool prof = c->prof_every > 0;
             if (prof) { int rce = prof_begin(2); if (rce) return rce; }
             HIPCHECK(c, gt_launch_persist_decode(a, c->pb0, s));
@@ -1150,6 +1151,12 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
         a.B = B; a.T = Tf; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;
         a.pad_before = same_pad_before(Tf, L.taps, 1, nullptr);
         a.act = i < g.post_tanh ? ACT_TANH : ACT_NONE;     // tanh on the first post_tanh layers only (F9)
+        // mixed precision: the activations BETWEEN the layers are stored as bf16 -- the next layer rounds them to bf16 on its way into
+        // LDS anyway, so no result changes and half the bytes move; the residual input and the last layer's output stay fp32
+        if (c->cfg.mixed_precision && c->bf16_w.count(L.w)) {
+            a.x_bf16 = i > 0 && c->bf16_w.count(c->post_conv[i - 1].w) ? 1 : 0;
+            a.out_bf16 = !last && c->bf16_w.count(c->post_conv[i + 1].w) ? 1 : 0;
+        }
         HIPCHECK(c, launch_conv(c, a, s));
         x = a.out; cur ^= 1;
     }
@@ -1882,8 +1889,8 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     if ((rc = dev_alloc(c, (void**)&c->w_mel_len, B * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&c->w_tok_len, B * 4))) return rc;
     if ((rc = dev_alloc(c, (void**)&c->w_seed, 16))) return rc;
-    if ((rc = dev_alloc(c, (void**)&c->w_dbg, 3 * 16 * 8))) return rc;
-    HIPCHECK(c, hipMemset(c->w_dbg, 0, 3 * 16 * 8));
+    if ((rc = dev_alloc(c, (void**)&c->w_dbg, 3 * 32 * 8))) return rc;       // ([3][16] for the launch path's kernels, [3][32] for the persistent decode launch)
+    HIPCHECK(c, hipMemset(c->w_dbg, 0, 3 * 32 * 8));
     if ((rc = fa(&c->w_masks, S * B * (c->P0 + c->P1)))) return rc;
     if ((rc = fa(&c->w_noise, S * B * Tv))) return rc;
     size_t actc = g.emb;
@@ -2259,9 +2266,9 @@ int gsttaco_get_profile(gsttaco_ctx* c, int layer, float* avg_ms, int* count) {
     return 0;
 }
 
-int gsttaco_debug_stamps(gsttaco_ctx* c, unsigned long long* host_out48) {
-    if (!c || !host_out48 || !c->w_dbg) return GSTTACO_E_INVALID;
-    HIPCHECK(c, hipMemcpy(host_out48, c->w_dbg, 3 * 16 * 8, hipMemcpyDeviceToHost));
+int gsttaco_debug_stamps(gsttaco_ctx* c, unsigned long long* host_out96) {
+    if (!c || !host_out96 || !c->w_dbg) return GSTTACO_E_INVALID;
+    HIPCHECK(c, hipMemcpy(host_out96, c->w_dbg, 3 * 32 * 8, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -177,6 +177,10 @@ struct ConvGemmArgs {
     // LDS, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16), the epilogue and the output stay fp32.
     const void* wt_bf16;
     int ldk;
+    // mixed precision, activations BETWEEN bf16 layers: `x` / `out` hold bf16 instead of fp32 (same [rows, channels] layout, half the
+    // bytes).  The consumer rounds its input to bf16 on the way into LDS anyway, so storing the rounded value changes no result.
+    // Only the bf16 kernels honour them (the host sets them for layers it knows run there); residual input and `res` stay fp32.
+    int x_bf16, out_bf16;
     // Winograd F(2,5) (gemm_conv.hip): the transformed weights U[6][Cin][N] = G . w (float64 at finalize), or NULL
     const float* wino_u;    // F(2,5): [6][wino_cin][N]
     const float* wino_u4;   // F(4,5): [8][wino_cin][N], or NULL
@@ -300,6 +304,7 @@ struct PersistDecodeArgs {
     float* align; int64_t ld_align;                    // [B][steps][Tv]
     int B, MT, Tv, steps, co_tiles;                    // co_tiles: layer-2 tiles whose recurrent half the launch path sums in 8-wave order
     int expect_extra;                                  // fault injection (tests): the all-to-all waits expect this many arrivals too many
+    unsigned long long* dbg;                           // diagnostic stamps [3 roles][32] or NULL (GSTTACO_STAMPS=1)
 };
 size_t gt_persist_decode_ctl_words();
 bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots);

@@ -66,6 +66,14 @@ __device__ __forceinline__ void pd_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 
 struct PdShared { int abort; };
 
+// diagnostic phase stamps (GSTTACO_STAMPS=1, tools/stamps_persist.py): thread 0 of workgroups 0 (chain), 32 (projection) and 255 (plain) at
+// the middle step, slot = role * 32 + index (100 MHz ticks)
+#define PD_STAMP(role, slot)                                                                                              \
+    do {                                                                                                                  \
+        if (A.dbg && t == (A.steps >> 1) && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == PD_UTT || blockIdx.x == PD_NWG - 1)) \
+            A.dbg[(role) * 32 + (slot)] = __builtin_amdgcn_s_memrealtime();                                                 \
+    } while (0)
+
 // ---- bounded waits: one wave polls (ONE read in flight), the workgroup joins behind a barrier
 __device__ __forceinline__ void pd_give_up(const PersistDecodeArgs& A, PdShared* sh, bool raise) {
     if (raise) atomicOr(A.err, 2u);         // (word 0 of the context's give-up words: bit 0 the fused LSTM launch, bit 1 this kernel)
@@ -214,7 +222,7 @@ struct PdW { float4 x1[3], h1[8], x2[8], h2[8]; };
 // LSTM cell 1: z = [p | ctx] . W1x + part1 (= h1_{t-1} . W1h + b1).  split: the prenet part is multiplied as soon as the chains
 // have published it, the context part when it arrives (same accumulator, same k-block order as gt_lstm_x_kernel<8, 3>).
 __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int t, int tile, float* lds, float& c1v, float p1v, PdShared* sh, bool split,
-                                        bool stream_x1 = false) {
+                                        bool stream_x1 = false, int role = 2) {
     const int par = t & 1, MT = A.MT;
     if (stream_x1) pd_load_tile<3>(A.w1x, tile, W.x1);          // (the chain role: arrives while the other chains finish)
     const float* xa = A.xa[par];
@@ -223,17 +231,21 @@ __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int
     if (split) {
         pd_wait_flags(A, A.ctl + PD_F_P, A.B, (uint32_t)t + 1u, sh);
         if (sh->abort) return;
+        PD_STAMP(role, 1);
         pd_xload<0, 2, 3>(xa, MT, x0, x1);
         PD_PIN();
         pd_mma<2, 0, 1, 3>(x0, x1, W.x1, a0, a1);
+        PD_STAMP(role, 2);
         pd_wait_flags(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);
         if (sh->abort) return;
+        PD_STAMP(role, 3);
         pd_xload<2, 3, 3>(xa, MT, x0, x1);
         PD_PIN();
         pd_mma<1, 2, 1, 3>(x0, x1, W.x1, a0, a1);
     } else {
         pd_wait_flags(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);      // (a chain's context flag is set after its prenet flag)
         if (sh->abort) return;
+        PD_STAMP(role, 3);
         pd_xload<0, 3, 3>(xa, MT, x0, x1);
         PD_PIN();
         pd_mma<3, 0, 1, 3>(x0, x1, W.x1, a0, a1);
@@ -241,13 +253,14 @@ __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
     const float z = pd_reduce<8>(lds, p1v);
     pd_gates_store(z, c1v, A.h1[par], tile, A.B, MT);
+    PD_STAMP(role, 4);
     pd_arrive(A.ctl + PD_CNT3);
 }
 
 // LSTM cell 2: z = h1_t . W2x + part2; then, from the same fragments, recurrent halves of cell 1 for the NEXT step: a chain
 // workgroup's (help_tile >= 0, published for it) and this workgroup's own (with_rec1)
 __device__ __forceinline__ void pd_cell2(const PersistDecodeArgs& A, PdW& W, int t, int tile, float* lds, float& c2v, float p2v, float& p1_next, bool with_rec1,
-                                        PdShared* sh, int help_tile, bool stream_h1, bool stream_x2) {
+                                        PdShared* sh, int help_tile, bool stream_h1, bool stream_x2, int role = 2) {
     const int par = t & 1, MT = A.MT;
     if (stream_x2) pd_load_tile<8>(A.w2x, tile, W.x2);          // (the chain role: these registers belong to the chain's operands until here)
     float4 wu[8];
@@ -255,15 +268,19 @@ __device__ __forceinline__ void pd_cell2(const PersistDecodeArgs& A, PdW& W, int
     if (stream_h1) pd_load_tile<8>(A.w1h, tile, W.h1);          // (layer-2 helpers keep W2h resident and stream their own W1h)
     pd_wait_count(A, A.ctl + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
     if (sh->abort) return;
+    PD_STAMP(role, 5);
     float4 x0[8], x1[8];
     pd_xload<0, 8, 8>(A.h1[par], MT, x0, x1);
     PD_PIN();
     f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
     pd_mma<8, 0, 1, 8>(x0, x1, W.x2, a0, a1);
+    PD_STAMP(role, 6);
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
     const float z = pd_reduce<8>(lds, p2v);
     pd_gates_store(z, c2v, A.h2[par], tile, A.B, MT);
+    PD_STAMP(role, 7);
     pd_arrive(A.ctl + PD_CNT4);
+    PD_STAMP(role, 8);
     const int col = threadIdx.x & 15;
     if (help_tile >= 0) {       // (the chain workgroup's half first: it is waited for sooner than this workgroup's own)
         const float v = pd_rec_tile<true>(x0, x1, wu, A.b1h[help_tile * 16 + col], lds);
@@ -301,6 +318,7 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
     const int par = t & 1, MT = A.MT;
     pd_wait_count(A, A.ctl + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
     if (sh->abort) return;
+    PD_STAMP(1, 9);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const auto rh = gt_rsrc(A.h2[par], 0x7FFFF000u);
@@ -321,6 +339,7 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].z, wp[i].z, a0, 0, 0, 0);
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].w, wp[i].w, a0, 0, 0, 0);
     }
+    PD_STAMP(1, 10);
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
     const float v = pd_reduce<8>(lds, A.bp[ptile * 16 + (threadIdx.x & 15)]);
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
@@ -338,6 +357,7 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
             A.stop[(size_t)grow * A.steps + t] = v;
         }
     }
+    PD_STAMP(1, 11);
 }
 
 // ---- the per-utterance chain (front_lean.h's arithmetic; every thread plays launch-path threads tid and tid + 512)
@@ -371,11 +391,21 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
         rba = (w0 >> ((wave & 1) * 16)) & 0xFFFFu;
         rbb = (w1 >> ((wave & 1) * 16)) & 0xFFFFu;
     }
+    // (a dropped row is skipped by a wave-uniform branch, not requested out of range: an out-of-range buffer load still costs the
+    // CU's address pipe 85 % of a real one -- tools/oob_cost.hip -- and the pipe time of these 32 requests per wave is what decides
+    // whether the weights are there when the projection's hand-off arrives.  The matching FMAs are skipped too: they would add
+    // x = 0 times anything.)
     float4 ra[16], rb[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) ra[i] = gt_bload4(rsW1, ((rba >> i) & 1u) ? (uint32_t)lane * 16u : GT_OOB, (uint32_t)((16 * wave + i) * PD_P * 4));
+    for (int i = 0; i < 16; ++i) {
+        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((rba >> i) & 1u) ra[i] = gt_bload4(rsW1, (uint32_t)lane * 16u, (uint32_t)((16 * wave + i) * PD_P * 4));
+    }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) rb[i] = gt_bload4(rsW1, ((rbb >> i) & 1u) ? (uint32_t)lane * 16u : GT_OOB, (uint32_t)((16 * (wave + 8) + i) * PD_P * 4));
+    for (int i = 0; i < 16; ++i) {
+        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((rbb >> i) & 1u) rb[i] = gt_bload4(rsW1, (uint32_t)lane * 16u, (uint32_t)((16 * (wave + 8) + i) * PD_P * 4));
+    }
     // small per-step operands: noise row, injected keep masks (parity mode)
     float nzv = 0.f, k0 = 1.f, k1 = 1.f;
     if (R.noisy && tid < Tv) nzv = A.noise[((size_t)t * A.B + b) * TvFull + tid];
@@ -385,6 +415,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
         k1 = m[(size_t)A.B * PD_P + (size_t)b * PD_P + tid];
     }
     PD_PIN();
+    PD_STAMP(0, 13);
     // ---- S1: this utterance's row of prenet-0 pre-activations (granules tagged with the step they are for)
     if (tid < PD_P) {
         uint2 g = pd_ld2_sc1(A.z0g + (size_t)b * PD_P + tid);
@@ -406,6 +437,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
     if (tid < Tv) L.nz[tid] = A.sigmoid_noise * nzv;
     __syncthreads();
     if (sh->abort) return;
+    PD_STAMP(0, 14);
     // ---- prenet layer 1 (Taco2.py:262-283): two launch-path threads' 16-row sums each.  The query weights (Steps.py:122) are
     // requested into the first half's registers as soon as it is consumed: launch-path thread = (4 output columns cgq, k-part kp of
     // 8 rows), this thread plays kp = tid / 32 and 16 + tid / 32; rows whose input (mask 1) is dropped are not requested.
@@ -427,10 +459,20 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
         }
         PD_PIN4(acc);
         *reinterpret_cast<float4*>(L.partial + wave * PD_P + 4 * lane) = acc;
+        {   // (a row is requested when either half of the wave keeps it: the two halves are different k-parts)
+            const uint32_t ua = (uint32_t)__builtin_amdgcn_readlane((int)qba, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qba, 32);
+            const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)qbb, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qbb, 32);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) qa[i] = gt_bload4(rsWq, ((qba >> i) & 1u) ? (uint32_t)cgq * 16u : GT_OOB, (uint32_t)((8 * kpa + i) * PD_A * 4));
+            for (int i = 0; i < 8; ++i) {
+                qa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((ua >> i) & 1u) qa[i] = gt_bload4(rsWq, ((qba >> i) & 1u) ? (uint32_t)cgq * 16u : GT_OOB, (uint32_t)((8 * kpa + i) * PD_A * 4));
+            }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) qa[8 + i] = gt_bload4(rsWq, ((qbb >> i) & 1u) ? (uint32_t)cgq * 16u : GT_OOB, (uint32_t)((8 * kpb + i) * PD_A * 4));
+            for (int i = 0; i < 8; ++i) {
+                qa[8 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((ub >> i) & 1u) qa[8 + i] = gt_bload4(rsWq, ((qbb >> i) & 1u) ? (uint32_t)cgq * 16u : GT_OOB, (uint32_t)((8 * kpb + i) * PD_A * 4));
+            }
+        }
         PD_PIN();
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -442,7 +484,9 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
         PD_PIN4(acc);
         *reinterpret_cast<float4*>(L.partial + (wave + 8) * PD_P + 4 * lane) = acc;
     }
+    PD_STAMP(0, 23);
     __syncthreads();
+    PD_STAMP(0, 15);
     if (tid < PD_P) {
         const float v = fmaxf(reduce_partial(L.partial, 16, PD_P, tid) + R.bias1, 0.f) * L.ks1[tid];
         L.y1[tid] = v;
@@ -465,6 +509,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
             if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (l2 == 0) pd_give_up(A, sh, false); break; }
         }
     }
+    PD_STAMP(0, 16);
     // ---- query projection
     {
         float x[8];
@@ -495,6 +540,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
     }
     if (tid < PD_A) L.qs[tid] = reduce_partial(L.partial, 32, PD_A, tid) + R.biasq;
     __syncthreads();
+    PD_STAMP(0, 17);
     // ---- scores (Steps.py:126-152): 8 lanes per memory row, 4 x 16-byte pieces each; rows tid / 8 and 64 + tid / 8
 #pragma unroll 1
     for (int hh = 0; hh < 2; ++hh) {
@@ -515,6 +561,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
         if (li == 0 && row < Tv) L.sc[row] = s + R.sbias;
     }
     __syncthreads();
+    PD_STAMP(0, 18);
     // ---- noise + sigmoid + alignment: SMA (Steps.py:215-229) or BMA (Steps.py:168-199)
     if (A.att_type == GSTTACO_ATT_SMA) {
         if (tid < Tv) {
@@ -551,6 +598,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
         }
     }
     __syncthreads();
+    PD_STAMP(0, 19);
     if (tid < TvFull) A.align[(size_t)b * A.ld_align + (size_t)t * TvFull + tid] = tid < Tv ? L.al[tid] : 0.f;
     // ---- context (Steps.py:160-166): lane = channel, 8 row groups (this thread plays groups tid / 128 and 4 + tid / 128)
     {
@@ -587,6 +635,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
         pd_drain();
         if (tid == 0) pd_st1_sc1(A.ctl + PD_F_C + b * 32, (uint32_t)t + 1u);
     }
+    PD_STAMP(0, 20);
 }
 
 // ====================================================================================================================== roles
@@ -623,6 +672,7 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
     }
     __syncthreads();
     for (int t = 0; t < A.steps; ++t) {
+        PD_STAMP(0, 0);
         if (live) {
             pd_chain(A, L, R, t, b, sh, p1v);
             if (sh->abort) return;
@@ -634,7 +684,7 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
             const int e = tid & 3;
             p1v = e == 0 ? d1.x : e == 1 ? d1.y : e == 2 ? d1.z : d1.w;
         }
-        pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, false, true);
+        pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, false, true, 0);
         if (sh->abort) return;
         if (t > 0) {        // the layer-2 half from its helper, in the shadow of the wait for h1 (one flag, then one 16-byte load per thread)
             pd_wait_flags(A, A.ctl + PD_F_H + (32 + tile) * 32, 1, (uint32_t)t, sh);
@@ -645,7 +695,7 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
             p2v = e == 0 ? d2.x : e == 1 ? d2.y : e == 2 ? d2.z : d2.w;
         }
         float unused = 0.f;
-        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, true);
+        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, true, 0);
         if (sh->abort) return;
     }
 }
@@ -662,10 +712,11 @@ __device__ __forceinline__ void pd_run_proj(const PersistDecodeArgs& A, float* l
     float c1v = 0.f, c2v = 0.f, p1v = A.b1h[tile * 16 + col], p2v = A.b2h[tile * 16 + col];
     for (int t = 0; t < A.steps; ++t) {
         const int par = t & 1;
-        pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, true);
+        PD_STAMP(1, 0);
+        pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, true, false, 1);
         if (sh->abort) return;
         float unused = 0.f;
-        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, false);
+        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, false, 1);
         if (sh->abort) return;
         pd_proj(A, wpj, t, ptile, pmt, lds, sh);
         if (sh->abort) return;
@@ -691,15 +742,19 @@ __device__ __forceinline__ void pd_run_plain(const PersistDecodeArgs& A, float* 
     float c1v = 0.f, c2v = 0.f, p1v = A.b1h[tile * 16 + col], p2v = A.b2h[tile * 16 + col];
     for (int t = 0; t < A.steps; ++t) {
         const int par = t & 1;
+        PD_STAMP(2, 0);
         pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, true);
         if (sh->abort) return;
         pd_cell2(A, W, t, tile, lds, c2v, p2v, p1v, true, sh, HELP == 1 ? help_tile : -1, HELP == 2, false);
+        PD_STAMP(2, 12);
         if (sh->abort) return;
         if (t + 1 == A.steps) break;
         if (HELP == 1) pd_load_tile<8>(A.w2h, tile, W.h2);      // (streamed: arrives during the wait)
         pd_wait_count(A, A.ctl + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
         if (sh->abort) return;
+        PD_STAMP(2, 13);
         p2v = pd_rec2(A, t, A.h2[par], W.h2, tile, HELP == 2 ? help_tile : -1, lds);        // for step t + 1
+        PD_STAMP(2, 14);
     }
 }
 

@@ -246,9 +246,11 @@ int gsttaco_set_profiling(gsttaco_ctx* ctx, int every);
 /* After the stream has been synchronised by the caller: average duration (ms) of the bracketed
  * launches of decode-LSTM layer `layer` (0/1) and how many were bracketed. */
 int gsttaco_get_profile(gsttaco_ctx* ctx, int layer, float* avg_ms, int* count);
-/* Diagnostic (GSTTACO_STAMPS=1): 3 x 16 phase stamps (100 MHz ticks) of workgroup 0 of the fused front kernel
- * and the two decode LSTM kernels at the middle decode step of the last replay.  Synchronises the device. */
-int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out48);
+/* Diagnostic (GSTTACO_STAMPS=1): 96 words of phase stamps (100 MHz ticks) at the middle decode step of the last replay.  Launch
+ * path: the first 3 x 16 = workgroup 0 of the fused front kernel and of the two decode LSTM kernels; persistent decode launch:
+ * 3 x 32 = its chain workgroup 0, projection workgroup 32 and plain workgroup 255 (tools/stamps.py, tools/stamps_persist.py).
+ * Synchronises the device. */
+int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out96);
 /* Three launches hand data between their workgroups INSIDE the kernel and therefore need those workgroups resident together: the
  * persistent BiLSTM launch (one launch for all time steps of the encoder's / vocoder's Bidirectional LSTM, reference
  * Taco2.py:39-43, 394-398; the 32 workgroups of each of its groups), the persistent decode launch (the whole decoder loop,

@@ -15,7 +15,7 @@ m.Restore(weights=w)
 for i in range(3):
     m.Inference_Step(inputs["tokens"], None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"], seed=i)
 torch.cuda.synchronize()
-buf = (ctypes.c_uint64 * 48)()
+buf = (ctypes.c_uint64 * 96)()
 m.ctx.check(m.ctx.lib.gsttaco_debug_stamps(m.ctx.handle, buf))
 names = {0: "front", 1: "lstm1", 2: "lstm2"}
 for k in range(3):

@@ -1,0 +1,31 @@
+"""Diagnostic: phase stamps of the persistent decode launch at the middle decode step (GSTTACO_STAMPS=1): chain workgroup 0,
+projection workgroup 32, plain workgroup 255 (csrc/persist_decode.hip PD_STAMP)."""
+import ctypes, os, sys
+os.environ["GSTTACO_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gst_tacotron_amd import synthetic, weights
+from gst_tacotron_amd.model import GST_Tacotron
+hp, inputs = synthetic.config_inputs("cfg2", batch=32)
+w = weights.synthetic_weights(hp, seed=0)
+m = GST_Tacotron(hyper_parameters=hp, max_batch=32, max_tokens=128, max_ref_frames=257)
+m.Restore(weights=w)
+for i in range(3):
+    m.Inference_Step(inputs["tokens"], None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"], seed=i)
+torch.cuda.synchronize()
+assert m.decode_counters()[0] > 0, "the persistent decode launch was not taken"
+buf = (ctypes.c_uint64 * 96)()
+m.ctx.check(m.ctx.lib.gsttaco_debug_stamps(m.ctx.handle, buf))
+names = ["chain WG 0", "proj  WG 32", "plain WG 255"]
+legend = {0: "step start", 1: "prenet flags seen", 2: "prenet part multiplied", 3: "context flags seen", 4: "cell 1 done (h1 stored)", 5: "h1 arrivals seen",
+          6: "cell 2 MFMAs done", 7: "h2 stored", 8: "h2 arrival counted", 9: "h2 arrivals seen (projection)", 10: "projection MFMAs done",
+          11: "projection published", 12: "recurrent half 1 done", 13: "h2 arrivals seen (recurrent half)", 14: "recurrent half 2 done",
+          16: "prenet published", 13 + 100: "", 17: "query done", 18: "scores done", 19: "alignment done", 20: "context published",
+          23: "prenet-1 sums stored", 15: "prenet-1 barrier passed"}
+chain_legend = dict(legend); chain_legend.update({13: "weights requested", 14: "z0 arrived, y0 in LDS"})
+for r in range(3):
+    t0 = buf[r * 32]
+    st = sorted((buf[r * 32 + i], i) for i in range(1, 32) if buf[r * 32 + i])
+    lg = chain_legend if r == 0 else legend
+    print(names[r], "(us since its step start):", ", ".join("[%d %s] %.2f" % (i, lg.get(i, ""), (v - t0) / 100.0) for v, i in st))
+print("step starts relative to chain WG 0's (us): proj %.2f plain %.2f" % ((buf[32] - buf[0]) / 100.0, (buf[64] - buf[0]) / 100.0))

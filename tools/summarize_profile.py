@@ -63,7 +63,7 @@ if os.path.exists(bl) and res:
     line = json.loads(open(bl).read())
     rows_chk = []
     for k, v in ((line.get("roofline") or {}).get("decode_step") or {}).get("kernels", {}).items():
-        sym = v["name"].split(" ")[0].split("<")[0]
+        sym = v["name"].split(" ")[0].split("<")[0].rstrip(",")
         hits = [(n, r) for n, r in res.items() if sym in n and r["dispatches"] >= 2]
         if not hits:
             continue
