@@ -550,6 +550,7 @@ hipError_t gt_conv5_bf16_init() {
 // Applies to: taps == 5, pad_before == 2, Cin % 32 == 0, no pooling, no 2-D mode.
 // Transform rows at compile time.  MO = outputs per tile: 2 -> F(2,5), points 0, +-1, +-1/2, inf (6 GEMMs per 2 outputs, 0.6x
 // the multiplications of the direct sum); 4 -> F(4,5), points 0, +-1, +-1/2, +-2, inf (8 GEMMs per 4 outputs, 0.4x).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int MO>
 struct Wino {
     static constexpr int ALPHA = MO + 4;
@@ -611,13 +612,16 @@ __device__ __forceinline__ void wino_issue_b(const ConvGemmArgs& A, __amdgpu_buf
 // ... and TRANSFORMED once it has arrived: V_XI = sum_tap BT[XI][tap] d[tap]
 template <int MO, int XI>
 __device__ __forceinline__ float4 wino_xform(const float4 (&d)[Wino<MO>::ALPHA]) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x2 lo = {0.f, 0.f}, hi = {0.f, 0.f};
 #pragma unroll
     for (int tap = 0; tap < Wino<MO>::ALPHA; ++tap) {
         const float cf = Wino<MO>::bt(XI, tap);
-        if (cf != 0.f) { v.x += cf * d[tap].x; v.y += cf * d[tap].y; v.z += cf * d[tap].z; v.w += cf * d[tap].w; }
+        // (explicit fma: left to the compiler, which products are contracted differs from one instantiation to the next; PACKED fma:
+        // the fp32 matrix instructions run on the vector ALU's own multipliers -- tools/mfma_rate.hip: a wave's VALU instructions
+        // add to its MFMA time instead of hiding under it -- so the transform's instruction count is paid in full)
+        if (cf != 0.f) { lo = __builtin_elementwise_fma((f32x2){cf, cf}, (f32x2){d[tap].x, d[tap].y}, lo); hi = __builtin_elementwise_fma((f32x2){cf, cf}, (f32x2){d[tap].z, d[tap].w}, hi); }
     }
-    return v;
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 
 #ifdef GT_WINO_STAMPS          // tools/wino_bench.hip: one cycle stamp per step of workgroup 0, wave 0

@@ -1,0 +1,112 @@
+// Ceiling of the fp32 matrix pipe as the Winograd kernels use it: W waves per SIMD, C independent accumulator chains per wave of
+// v_mfma_f32_32x32x2_f32 (or 16x16x4), nothing else in the loop.  Prints TFLOP/s over the whole chip and cycles per MFMA per SIMD.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/mfma_rate tools/mfma_rate.hip && tools/mfma_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+template <int C, int NT>
+__global__ __launch_bounds__(NT) void k32(float* out, int iters, unsigned long long* cyc) {
+    f32x16 acc[C];
+    for (int c = 0; c < C; ++c) for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) for (int e = 0; e < 16; ++e) s += acc[c][e];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <int C, int NT>
+__global__ __launch_bounds__(NT) void k16(float* out, int iters, unsigned long long* cyc) {
+    f32x4 acc[C];
+    for (int c = 0; c < C; ++c) for (int e = 0; e < 4; ++e) acc[c][e] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) for (int e = 0; e < 4; ++e) s += acc[c][e];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+// ... and with V independent VALU fmas (and optionally one LDS read) issued between consecutive MFMAs of ONE wave per SIMD: does the wave's
+// other work run in the shadow of its own MFMAs?
+template <int V, int LDSR, int NT>
+__global__ __launch_bounds__(NT) void kmix(float* out, int iters, unsigned long long* cyc) {
+    __shared__ float lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += NT) lds[i] = i * 1e-4f;
+    __syncthreads();
+    f32x16 acc[4];
+    for (int c = 0; c < 4; ++c) for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    float w[16];
+    for (int i = 0; i < 16; ++i) w[i] = a + i;
+    int ix = threadIdx.x & 1023;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[u & 3], 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < V; ++v) w[v & 15] = __builtin_fmaf(w[v & 15], 1.0001f, 0.5f);
+            if (LDSR) { b += lds[ix]; ix = (ix + 64) & 1023; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int c = 0; c < 4; ++c) for (int e = 0; e < 16; ++e) s += acc[c][e];
+    for (int i = 0; i < 16; ++i) s += w[i];
+    out[blockIdx.x * NT + threadIdx.x] = s + b;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <typename K>
+static void run(const char* name, K kern, int nt, int chains, double flop_per_mfma, float* out, unsigned long long* cyc) {
+    const int iters = 4000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(nt), 0, 0, out, 100, cyc);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(nt), 0, 0, out, iters, cyc);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    const double mfma_per_simd = (double)iters * 8 * chains * (nt / 256.0);
+    printf("%-44s %7.1f us  %6.1f TFLOP/s  %6.1f s_memtime ticks per MFMA and SIMD  (%.0f ticks/us)\n", name, ms * 1e3,
+           256.0 * (nt / 64) * iters * 8 * chains * flop_per_mfma / (ms * 1e-3) * 1e-12, (double)c / mfma_per_simd, (double)c / (ms * 1e3));
+}
+int main() {
+    float* out; unsigned long long* cyc; CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&cyc, 8));
+    run("32x32x2  1 wave/SIMD, 1 chain", k32<1, 256>, 256, 1, 4096, out, cyc);
+    run("32x32x2  1 wave/SIMD, 2 chains", k32<2, 256>, 256, 2, 4096, out, cyc);
+    run("32x32x2  1 wave/SIMD, 4 chains", k32<4, 256>, 256, 4, 4096, out, cyc);
+    run("32x32x2  1 wave/SIMD, 16 chains (256 acc)", k32<16, 256>, 256, 16, 4096, out, cyc);
+    run("32x32x2  2 waves/SIMD, 1 chain", k32<1, 512>, 512, 1, 4096, out, cyc);
+    run("32x32x2  2 waves/SIMD, 2 chains", k32<2, 512>, 512, 2, 4096, out, cyc);
+    run("32x32x2  2 waves/SIMD, 8 chains", k32<8, 512>, 512, 8, 4096, out, cyc);
+    run("16x16x4  1 wave/SIMD, 1 chain", k16<1, 256>, 256, 1, 2048, out, cyc);
+    run("16x16x4  1 wave/SIMD, 4 chains", k16<4, 256>, 256, 4, 2048, out, cyc);
+    run("16x16x4  2 waves/SIMD, 4 chains", k16<4, 512>, 512, 4, 2048, out, cyc);
+    run("32x32x2 1 wave/SIMD + 4 fma per MFMA", kmix<4, 0, 256>, 256, 1, 4096, out, cyc);
+    run("32x32x2 1 wave/SIMD + 8 fma per MFMA", kmix<8, 0, 256>, 256, 1, 4096, out, cyc);
+    run("32x32x2 1 wave/SIMD + 12 fma per MFMA", kmix<12, 0, 256>, 256, 1, 4096, out, cyc);
+    run("32x32x2 1 wave/SIMD + 16 fma per MFMA", kmix<16, 0, 256>, 256, 1, 4096, out, cyc);
+    run("32x32x2 1 wave/SIMD + 24 fma per MFMA", kmix<24, 0, 256>, 256, 1, 4096, out, cyc);
+    run("32x32x2 1 wave/SIMD + 4 fma + LDS read", kmix<4, 1, 256>, 256, 1, 4096, out, cyc);
+    run("32x32x2 2 waves/SIMD + 8 fma per MFMA", kmix<8, 0, 512>, 512, 1, 4096, out, cyc);
+    run("32x32x2 2 waves/SIMD + 16 fma per MFMA", kmix<16, 0, 512>, 512, 1, 4096, out, cyc);
+    return 0;
+}
