@@ -373,6 +373,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
         const float v = fmaxf(reduce_partial(partial, g1.kparts, P1, c) + sb1[c], 0.f) * sk1[c];
         y1[c] = v;
         P.xa[gt_blk_off(b, c, P.MT)] = v;           // LSTM-1 input (blocked), k in [0, P1)
+        if (P.xah) P.xah[gt_blk_off_h(b, c, P.MT)] = gt_bf16_bits(v);
     }
     __syncthreads();
     GT_STAMP(P.dbg, 3);
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
 #pragma unroll
         for (int w = 0; w < CPARTS; ++w) z += v[w];
         P.xa[gt_blk_off(b, P1 + a, P.MT)] = z;      // context, k in [P1, P1+A)
+        if (P.xah) P.xah[gt_blk_off_h(b, P1 + a, P.MT)] = gt_bf16_bits(z);
     }
     GT_STAMP(P.dbg, 7);
     if (b < P.utt_jobs) {       // (see gt_dec_front_lean_kernel)

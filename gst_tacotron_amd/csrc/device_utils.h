@@ -131,6 +131,14 @@ __device__ __forceinline__ float4 gt_bload4_sc1(__amdgpu_buffer_rsrc_t rs, uint3
     return r;
 }
 
+// fp32 -> bf16 bits, round to nearest even: what the bf16 GEMM bodies do to an activation on its way into the MFMA
+__device__ __forceinline__ uint16_t gt_bf16_bits(const float v) {
+    const __bf16 h = (__bf16)v;
+    uint16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+
 // diagnostic: phase stamp (constant 100 MHz counter) written by thread 0 of block 0 when dbg != NULL
 #define GT_STAMP(dbg, slot)                                                                    \
     do {                                                                                       \

@@ -170,6 +170,7 @@ __device__ __forceinline__ void gt_front_lean(const DecFrontArgs& P, float* smem
         const float v = fmaxf(reduce_partial(partial, g1.kparts, P1, tid) + sb1[tid], 0.f) * sk1[tid];
         y1[tid] = v;
         P.xa[gt_blk_off(b, tid, P.MT)] = v;          // LSTM-1 input (blocked), k in [0, P1)
+        if (P.xah) P.xah[gt_blk_off_h(b, tid, P.MT)] = gt_bf16_bits(v);
     }
     __syncthreads();
     GT_LSTAMP(3);
@@ -303,6 +304,7 @@ __device__ __forceinline__ void gt_front_lean(const DecFrontArgs& P, float* smem
 #pragma unroll
         for (int w = 0; w < CPARTS; ++w) z += v[w];
         P.xa[gt_blk_off(b, P1 + tid, P.MT)] = z;     // context, k in [P1, P1+A)
+        if (P.xah) P.xah[gt_blk_off_h(b, P1 + tid, P.MT)] = gt_bf16_bits(z);
     }
     GT_LSTAMP(7);
 }

@@ -201,6 +201,8 @@ struct gsttaco_ctx {
     float *w_gconv[2] = {nullptr, nullptr}, *w_gst = nullptr, *w_rowbias = nullptr, *w_pm = nullptr;
     float *w_p1 = nullptr, *w_xa = nullptr, *w_q = nullptr, *w_h1[2] = {nullptr, nullptr},
           *w_h2[2] = {nullptr, nullptr}, *w_c1 = nullptr, *w_c2 = nullptr;
+    // bf16 mirrors of the blocked decoder activations (kernels.h gt_blk_off_h): mixed precision, batches above 32 rows
+    uint16_t *w_xa_h = nullptr, *w_h1_h[2] = {nullptr, nullptr}, *w_h2_h[2] = {nullptr, nullptr};
     float *w_pre = nullptr, *w_stop = nullptr, *w_align = nullptr, *w_post[2] = {nullptr, nullptr},
           *w_mel = nullptr;
     size_t zero_floats = 0;
@@ -841,6 +843,17 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     const int64_t ld_pre = (int64_t)steps * r * mel;
     HIPCHECK(c, gt_launch_zero(c->w_h1[1], (size_t)MT * 16 * H1, s));
     HIPCHECK(c, gt_launch_zero(c->w_h2[1], (size_t)MT * 16 * H2, s));
+    // Mixed precision above 32 rows: the producers of the blocked activations (front launch: prenet output + context; LSTM launches:
+    // h1, h2) also write bf16 MIRRORS, which the bf16 multi-chunk GEMM bodies read instead -- half the activation bytes through
+    // each CU's load pipe, which is what bounds those launches (EXPERIMENTS round 4), and no conversion per consumer.  Only when
+    // every producer and consumer of the step is one that knows about mirrors (lean paths below).
+    const bool mirror = B > 32 && c->w_xa_h != nullptr && c->fused_front && c->split_rec && c->lean && c->keep_x_weights &&
+                        g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv) &&
+                        gt_lstm_x_supported(c->lstm_x[0].nkb) && gt_lstm_x_supported(c->lstm_x[1].nkb) && c->lstm_h[0].nkb == 64 && c->lstm_h[1].nkb == 64;
+    if (mirror) {
+        HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_h1_h[1]), (size_t)MT * 16 * H1 / 2, s));
+        HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_h2_h[1]), (size_t)MT * 16 * H2 / 2, s));
+    }
     HIPCHECK(c, gt_launch_zero(c->w_c1, (size_t)B * H1, s));
     HIPCHECK(c, gt_launch_zero(c->w_c2, (size_t)B * H2, s));
     if (g.att_type == GSTTACO_ATT_LSA) HIPCHECK(c, gt_launch_zero(c->w_lsa_state, (size_t)B * Tv, s));   // Layers.py:356
@@ -956,6 +969,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             f.noise = has_noise ? c->w_noise + (size_t)t * B * Tv : nullptr; f.ldnoise = Tv;
             f.align = c->w_align + (size_t)t * Tv; f.ldalign = (int64_t)steps * Tv;
             f.xa = xa_t; f.MT = MT;
+            f.xah = mirror ? c->w_xa_h : nullptr;
             f.B = B; f.Tv = Tv; f.mel = mel; f.P0 = P0; f.P1 = P1; f.A = att; f.type = g.att_type;
             f.sigmoid_noise = g.sigmoid_noise;
             f.tok_len = tlen;
@@ -977,8 +991,10 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 f.n_workers = B < c->n_cu * 3 / 4 ? c->n_cu - B : c->n_cu / 4;
                 f.worker_tiles = c->worker_tiles;
                 f.lean_rec = (c->lean && f.rec[0].bf16 == f.rec[1].bf16 && f.rec[0].nkb == 64 && f.rec[1].nkb == 64) ? (f.rec[0].bf16 ? 2 : 1) : 0;
-                for (int layer = 0; layer < 2; ++layer)
+                for (int layer = 0; layer < 2; ++layer) {
                     f.lrec[layer] = LeanPartialArgs{f.rec[layer].wp, f.rec[layer].bias, f.rec[layer].seg[0].ptr, f.rec[layer].partial_out, MT};
+                    if (mirror && f.lean_rec == 2) f.lrec[layer].xh = layer == 0 ? c->w_h1_h[p ^ 1] : c->w_h2_h[p ^ 1];
+                }
                 // from step 1 on, the projection kernel of the previous step already did layer-2 tiles [0, co_tiles)
                 if (t > 0 && c->proj.nkb >= 32) f.rec_begin[1] = co_tiles;
                 {
@@ -1045,6 +1061,10 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 unsigned long long* dbg = (c->stamps && t == steps / 2) ? c->w_dbg + 16 * (1 + layer) : nullptr;
                 (layer == 0 ? fa.l1 : fa.l2) = LstmXArgs{L.wp, layer == 0 ? xa_t : c->w_h1[p], c->w_part[layer], layer == 0 ? c->w_c1 : c->w_c2, hb[p],
                                                          nullptr, dbg, B, MT, layer == 0 ? H1 : H2, 0, L.nkb};
+                if (mirror) {
+                    (layer == 0 ? fa.l1 : fa.l2).xh = layer == 0 ? c->w_xa_h : c->w_h1_h[p];
+                    (layer == 0 ? fa.l1 : fa.l2).hh = layer == 0 ? c->w_h1_h[p] : c->w_h2_h[p];
+                }
             }
             fa.arrive = c->w_arrive + (size_t)t * 256;
             fa.err = c->w_err;
@@ -1084,6 +1104,10 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             if (prof) { int rce = prof_begin(layer); if (rce) return rce; }
             if (split && c->lean && c->keep_x_weights && gt_lstm_x_supported(k.nkb)) {
                 LstmXArgs la{k.wp, k.seg[0].ptr, k.partial_in, k.c, k.h, nullptr, k.dbg, B, MT, H, 0, k.nkb};
+                if (mirror) {
+                    la.xh = layer == 0 ? c->w_xa_h : c->w_h1_h[p];
+                    la.hh = layer == 0 ? c->w_h1_h[p] : c->w_h2_h[p];
+                }
                 HIPCHECK(c, gt_launch_lstm_x(la, k.nkb, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2, k.bf16 != 0, s));
             } else
             HIPCHECK(c, launch_skinny(c, EPI_LSTM, k, nullptr, (H + 3) / 4, s, layer == 0 ? TAG_DEC_LSTM1 : TAG_DEC_LSTM2));
@@ -1122,6 +1146,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                 ProjArgs pa{k.wp, k.bias, k.seg[0].ptr, k.seg[1].ptr, k.seg[0].nkb, B, MT, k.N, k.n_split, k.n_valid2, k.col3,
                             k.out, k.ldo, k.out2, k.ldo2, k.out3, k.ldo3,
                             (c->stamps && t == steps / 2) ? c->w_dbg + 40 : nullptr};
+                if (mirror) { pa.xah = c->w_h2_h[p]; pa.xbh = c->w_xa_h + (size_t)(P1 / 32) * MT * 512; }
                 HIPCHECK(c, gt_launch_proj_lean(pa, PJ.ntiles, rk.wp, rk.bias, rk.seg[0].ptr, rk.partial_out, 0, co_tiles,
                                                 c->co_worker_tiles, k.bf16 != 0, s));
             } else
@@ -1926,6 +1951,19 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     const size_t Bp = (B + 15) / 16 * 16;       // blocked activation buffers hold whole 16-row tiles
     if ((rc = fa(&c->w_xa, Bp * (c->P1 + c->att)))) return rc;
     HIPCHECK(c, hipMemset(c->w_xa, 0, Bp * (c->P1 + c->att) * sizeof(float)));
+    if (c->lstm_x[0].bf16 && c->lstm_x[1].bf16 && c->lstm_h[0].bf16 && c->lstm_h[1].bf16 && c->proj.bf16 && Bp > 32 &&
+        (c->P1 + c->att) % 32 == 0 && c->P1 % 32 == 0 && c->H1 % 32 == 0 && c->H2 % 32 == 0) {
+        float* t = nullptr;
+        if ((rc = fa(&t, Bp * (c->P1 + c->att) / 2))) return rc;
+        c->w_xa_h = reinterpret_cast<uint16_t*>(t);
+        HIPCHECK(c, hipMemset(t, 0, Bp * (c->P1 + c->att) * 2));
+        for (int i = 0; i < 2; ++i) {
+            if ((rc = fa(&t, Bp * c->H1 / 2))) return rc;
+            c->w_h1_h[i] = reinterpret_cast<uint16_t*>(t);
+            if ((rc = fa(&t, Bp * c->H2 / 2))) return rc;
+            c->w_h2_h[i] = reinterpret_cast<uint16_t*>(t);
+        }
+    }
     if ((rc = fa(&c->w_q, B * c->att))) return rc;
     for (int i = 0; i < 2; ++i) {
         if ((rc = fa(&c->w_h1[i], Bp * c->H1))) return rc;

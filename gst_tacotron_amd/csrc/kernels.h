@@ -21,6 +21,14 @@ __host__ __device__ inline size_t gt_blk_off(int row, int k, int MT) {
     return (((size_t)(k >> 4) * MT + (row >> 4)) << 8) + (size_t)(((((k & 15) >> 2) << 4) + (row & 15)) * 4 + (k & 3));
 }
 
+// bf16 MIRROR of a blocked activation buffer (mixed precision, batches above 32 rows): [K/32][MT][64 lanes][8 bf16], lane l of 32-k
+// block j and M-tile mt holds row 16 mt + (l & 15), slot i <-> k = 32 j + 16 (i >> 2) + 4 (l >> 4) + (i & 3): exactly the A operand of
+// v_mfma_f32_16x16x32_bf16 the consumers used to assemble from two fp32 fragments (lean_body.h), rounded (RNE) once by the producer
+// instead of by every consumer.  Offset in bf16 elements.
+__host__ __device__ inline size_t gt_blk_off_h(int row, int k, int MT) {
+    return ((((size_t)(k >> 5) * MT + (row >> 4)) << 6) + (size_t)((((k & 15) >> 2) << 4) + (row & 15))) * 8 + (size_t)((((k >> 4) & 1) << 2) + (k & 3));
+}
+
 struct SkinnyArgs {
     const float* wp;    // packed weights [ntiles][nkb][64 lanes][4]; when `bf16`: bf16 [ntiles][ceil(nkb/2)][64 lanes][8]
     const float* bias;  // [ntiles*16] in packed column order
@@ -62,6 +70,7 @@ struct LeanPartialArgs {
     const float* x;             // blocked state [NKB][MT][64][4]
     float* partial_out;         // [tile][MT*16 rows][16 cols]
     int MT;
+    const uint16_t* xh = nullptr;   // bf16 mirror of x (gt_blk_off_h) or NULL: read instead of x by the bf16 multi-chunk bodies
 };
 
 enum { TAG_GENERIC = 0, TAG_DEC_LSTM1 = 1, TAG_DEC_LSTM2 = 2, TAG_ENC_BILSTM = 3 };
@@ -85,6 +94,8 @@ struct LstmXArgs {
     unsigned long long* dbg;
     int M, MT, H, t_index;
     int nkb;                    // K / 16 (the bf16 variant's 32-k blocks need not fill NW x KPW)
+    const uint16_t* xh = nullptr;   // bf16 mirror of x or NULL (read by the bf16 multi-chunk body instead of x)
+    uint16_t* hh = nullptr;         // bf16 mirror of h or NULL (written beside h)
 };
 bool gt_lstm_x_supported(int nkb);
 // Both cells in one launch with an in-kernel hand-off of h1 (skinny_gemm.hip gt_lstm12_kernel): fp32, batch <= 32.
@@ -153,6 +164,7 @@ struct ProjArgs {
     float* out2; int64_t ldo2;
     float* out3; int64_t ldo3;
     unsigned long long* dbg;                        // diagnostic stamps (8 slots) or NULL
+    const uint16_t* xah = nullptr; const uint16_t* xbh = nullptr;   // bf16 mirrors of xa / xb or NULL (gt_proj_mc_kernel<true>)
 };
 bool gt_proj_lean_supported(int nkb_main, int nkb_co);
 hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp, const float* co_bias, const float* co_x,
@@ -271,6 +283,7 @@ struct DecFrontArgs {
     int keep_hash;                  // throughput mode at dropout rate 0.5 and the reference's prenet / attention sizes: rows of
                                     // the prenet-1 / query weights that the (hashed) keep decisions zero are not requested
     int lean_front;                 // 1: the lean utterance path (front_lean.h) where its preconditions hold; 0: the general kernel
+    uint16_t* xah;                  // bf16 mirror of xa (gt_blk_off_h), written beside it, or NULL
 };
 bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv);
 hipError_t gt_dec_front_init();

@@ -25,6 +25,8 @@ struct LeanX {
     const float* xa;
     const float* xb;
     int nkb_a;
+    const uint16_t* ha = nullptr;       // bf16 mirrors of the two segments (kernels.h gt_blk_off_h) or NULL
+    const uint16_t* hb = nullptr;
 };
 
 // Activation fragment of k-block `kb` (wave-uniform), M-tile `mt`: one 16-byte load per lane.  GT_X_SC1 (default): as sc1
@@ -44,6 +46,21 @@ __device__ __forceinline__ LeanXR gt_x_rsrc(const LeanX& X) {
     return LeanXR{gt_rsrc(X.xa, 0x7FFFF000u), gt_rsrc(X.xb, 0x7FFFF000u)};
 #else
     return LeanXR{};
+#endif
+}
+// The bf16 mirror's fragment of 32-k block `kb32` (wave-uniform; nkb_a even), M-tile `mt`: 8 bf16 per lane, the MFMA's A operand as is.
+__device__ __forceinline__ u32x4 gt_xload_h(const LeanX& X, const int kb32, const int MT, const int mt) {
+    const int lane = threadIdx.x & 63;
+    const bool first = 2 * kb32 < X.nkb_a;
+    const uint16_t* base = first ? X.ha : X.hb;
+    const uint32_t soff = (uint32_t)(((first ? kb32 : kb32 - (X.nkb_a >> 1)) * MT + mt) * 1024);
+#if GT_X_SC1
+    const auto t = __builtin_amdgcn_raw_buffer_load_b128(gt_rsrc(base, 0x7FFFF000u), lane * 16, (int)soff, 16);
+    u32x4 r;
+    __builtin_memcpy(&r, &t, 16);
+    return r;
+#else
+    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(base) + soff + lane * 16);
 #endif
 }
 __device__ __forceinline__ float4 gt_xload(const LeanXR& R, const LeanX& X, const int kb, const int MT, const int mt) {
@@ -115,7 +132,8 @@ __device__ __forceinline__ void gt_lean_core(const float* __restrict__ wp, const
 // activations of the two 16-blocks (2j, 2j+1) are rounded to bf16 (RNE) on their way into the MFMA -- exactly what the
 // general body does, in the same order, so the results are bitwise the same.  KPW32 = 32-k blocks per wave (guarded by
 // nkb32, so 36 blocks on 8 waves is fine); nkb_a (in 16-blocks) must be even.
-template <int NW, int KPW32, int NT, bool NTW, bool ONE_M = false>
+// XH: the activations come from the bf16 mirrors (X.ha / X.hb): one 16-byte fragment per 32 k instead of two, no conversion.
+template <int NW, int KPW32, int NT, bool NTW, bool ONE_M = false, bool XH = false>
 __device__ __forceinline__ void gt_lean_core_bf16(const float* __restrict__ wp, const int tile0, const int ntile, const LeanX X, const int MT,
                                                   const int mchunk, const int nkb32, f32x4 (&acc0)[NT], f32x4 (&acc1)[NT]) {
     const int lane = threadIdx.x & 63;
@@ -124,14 +142,18 @@ __device__ __forceinline__ void gt_lean_core_bf16(const float* __restrict__ wp, 
     const uint4* wl = reinterpret_cast<const uint4*>(wp) + ((size_t)tile0 * nkb32 + wave) * 64 + lane;
     const LeanXR XR = gt_x_rsrc(X);
     uint4 b[KPW32][NT];
-    float4 x0[KPW32][2], x1[KPW32][2];
+    float4 x0[XH ? 1 : KPW32][2], x1[XH ? 1 : KPW32][2];
+    u32x4 h0[XH ? KPW32 : 1], h1[XH ? KPW32 : 1];
 #pragma unroll
     for (int i = 0; i < KPW32; ++i) {
         const int kb32 = wave + i * NW;                     // wave-uniform
 #pragma unroll
         for (int j = 0; j < NT; ++j) b[i][j] = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (XH) { h0[i] = u32x4{0u, 0u, 0u, 0u}; h1[i] = u32x4{0u, 0u, 0u, 0u}; }
+        else {
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) { x0[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f); x1[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            for (int hf = 0; hf < 2; ++hf) { x0[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f); x1[i][hf] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        }
         if (kb32 < nkb32) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -145,11 +167,16 @@ __device__ __forceinline__ void gt_lean_core_bf16(const float* __restrict__ wp, 
                     }
                 }
             }
+            if constexpr (XH) {
+                h0[i] = gt_xload_h(X, kb32, MT, mt0);
+                if (!ONE_M) h1[i] = gt_xload_h(X, kb32, MT, mt1);
+            } else {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                const int kb = 2 * kb32 + hf;
-                x0[i][hf] = gt_xload(XR, X, kb, MT, mt0);
-                if (!ONE_M) x1[i][hf] = gt_xload(XR, X, kb, MT, mt1);
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int kb = 2 * kb32 + hf;
+                    x0[i][hf] = gt_xload(XR, X, kb, MT, mt0);
+                    if (!ONE_M) x1[i][hf] = gt_xload(XR, X, kb, MT, mt1);
+                }
             }
         }
     }
@@ -159,11 +186,16 @@ __device__ __forceinline__ void gt_lean_core_bf16(const float* __restrict__ wp, 
     for (int i = 0; i < KPW32; ++i) {
         if (wave + i * NW < nkb32) {
             bf16x8 a0, a1;
-            a0[0] = (__bf16)x0[i][0].x; a0[1] = (__bf16)x0[i][0].y; a0[2] = (__bf16)x0[i][0].z; a0[3] = (__bf16)x0[i][0].w;
-            a0[4] = (__bf16)x0[i][1].x; a0[5] = (__bf16)x0[i][1].y; a0[6] = (__bf16)x0[i][1].z; a0[7] = (__bf16)x0[i][1].w;
-            if (!ONE_M) {
-                a1[0] = (__bf16)x1[i][0].x; a1[1] = (__bf16)x1[i][0].y; a1[2] = (__bf16)x1[i][0].z; a1[3] = (__bf16)x1[i][0].w;
-                a1[4] = (__bf16)x1[i][1].x; a1[5] = (__bf16)x1[i][1].y; a1[6] = (__bf16)x1[i][1].z; a1[7] = (__bf16)x1[i][1].w;
+            if constexpr (XH) {
+                __builtin_memcpy(&a0, &h0[i], 16);
+                __builtin_memcpy(&a1, &h1[i], 16);
+            } else {
+                a0[0] = (__bf16)x0[i][0].x; a0[1] = (__bf16)x0[i][0].y; a0[2] = (__bf16)x0[i][0].z; a0[3] = (__bf16)x0[i][0].w;
+                a0[4] = (__bf16)x0[i][1].x; a0[5] = (__bf16)x0[i][1].y; a0[6] = (__bf16)x0[i][1].z; a0[7] = (__bf16)x0[i][1].w;
+                if (!ONE_M) {
+                    a1[0] = (__bf16)x1[i][0].x; a1[1] = (__bf16)x1[i][0].y; a1[2] = (__bf16)x1[i][0].z; a1[3] = (__bf16)x1[i][0].w;
+                    a1[4] = (__bf16)x1[i][1].x; a1[5] = (__bf16)x1[i][1].y; a1[6] = (__bf16)x1[i][1].z; a1[7] = (__bf16)x1[i][1].w;
+                }
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -300,7 +332,8 @@ __device__ __forceinline__ void gt_lean_mc_load_w(const float* __restrict__ wp, 
 
 // PRE: the weight fragments were requested by the caller (gt_lean_mc_load_w) -- the fused LSTM launch does that before it waits
 // for the other workgroups' layer-1 state -- and only the activations are requested here.
-template <int NW, int KPW, int NT, bool BF16, bool NTW, bool PRE, class Pre, class Epi>
+// XH (bf16 only): the activations come from the bf16 mirrors (X.ha, X.hb).
+template <int NW, int KPW, int NT, bool BF16, bool NTW, bool PRE, bool XH, class Pre, class Epi>
 __device__ __forceinline__ void gt_lean_mc_impl(const float* __restrict__ wp, const int tile0, const int ntile, const LeanX X, const int nkb32,
                                                 const int MT, const int c0, const int c1, float* lds, Pre pre, Epi epi,
                                                 unsigned long long* dbg, LeanW<KPW, NT, BF16>& WPRE) {
@@ -310,12 +343,24 @@ __device__ __forceinline__ void gt_lean_mc_impl(const float* __restrict__ wp, co
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if constexpr (BF16) {
         u32x4 (&b)[KPW][NT] = WPRE.h;
-        float4 xa[KPW][2], xb[KPW][2];
+        float4 xa[XH ? 1 : KPW][2], xb[XH ? 1 : KPW][2];
+        u32x4 ha[XH ? KPW : 1], hb[XH ? KPW : 1];
         const u32x4* wl = reinterpret_cast<const u32x4*>(wp) + ((size_t)tile0 * nkb32 + wave) * 64 + lane;
         const LeanXR XR = gt_x_rsrc(X);
         auto xld = [&](const int i, const int hf, const int mt) {
             const int kb32 = (wave + i * NW < nkb32) ? wave + i * NW : wave;    // wave-uniform; past the end: re-read, never multiplied
             return gt_xload(XR, X, 2 * kb32 + hf, MT, mt);
+        };
+        // k-block i's fragments of M-tiles ma / mb: two fp32 fragments each, or one bf16 fragment each from the mirrors
+        auto xreq = [&](const int i, const int ma, const int mb) {
+            if constexpr (XH) {
+                const int kb32 = (wave + i * NW < nkb32) ? wave + i * NW : wave;
+                ha[i] = gt_xload_h(X, kb32, MT, ma);
+                hb[i] = gt_xload_h(X, kb32, MT, mb);
+            } else {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) { xa[i][hf] = xld(i, hf, ma); xb[i][hf] = xld(i, hf, mb); }
+            }
         };
         {
             const int ma = 2 * c0, mb = min(2 * c0 + 1, MT - 1);
@@ -329,8 +374,7 @@ __device__ __forceinline__ void gt_lean_mc_impl(const float* __restrict__ wp, co
                         b[i][j] = NTW ? __builtin_nontemporal_load(src) : *src;
                     }
                 }
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) { xa[i][hf] = xld(i, hf, ma); xb[i][hf] = xld(i, hf, mb); }
+                xreq(i, ma, mb);
             }
         }
         GT_PIN_ORDER();
@@ -347,10 +391,15 @@ __device__ __forceinline__ void gt_lean_mc_impl(const float* __restrict__ wp, co
             for (int i = 0; i < KPW; ++i) {
                 if (wave + i * NW < nkb32) {
                     bf16x8 a0, a1;
-                    a0[0] = (__bf16)xa[i][0].x; a0[1] = (__bf16)xa[i][0].y; a0[2] = (__bf16)xa[i][0].z; a0[3] = (__bf16)xa[i][0].w;
-                    a0[4] = (__bf16)xa[i][1].x; a0[5] = (__bf16)xa[i][1].y; a0[6] = (__bf16)xa[i][1].z; a0[7] = (__bf16)xa[i][1].w;
-                    a1[0] = (__bf16)xb[i][0].x; a1[1] = (__bf16)xb[i][0].y; a1[2] = (__bf16)xb[i][0].z; a1[3] = (__bf16)xb[i][0].w;
-                    a1[4] = (__bf16)xb[i][1].x; a1[5] = (__bf16)xb[i][1].y; a1[6] = (__bf16)xb[i][1].z; a1[7] = (__bf16)xb[i][1].w;
+                    if constexpr (XH) {
+                        __builtin_memcpy(&a0, &ha[i], 16);
+                        __builtin_memcpy(&a1, &hb[i], 16);
+                    } else {
+                        a0[0] = (__bf16)xa[i][0].x; a0[1] = (__bf16)xa[i][0].y; a0[2] = (__bf16)xa[i][0].z; a0[3] = (__bf16)xa[i][0].w;
+                        a0[4] = (__bf16)xa[i][1].x; a0[5] = (__bf16)xa[i][1].y; a0[6] = (__bf16)xa[i][1].z; a0[7] = (__bf16)xa[i][1].w;
+                        a1[0] = (__bf16)xb[i][0].x; a1[1] = (__bf16)xb[i][0].y; a1[2] = (__bf16)xb[i][0].z; a1[3] = (__bf16)xb[i][0].w;
+                        a1[4] = (__bf16)xb[i][1].x; a1[5] = (__bf16)xb[i][1].y; a1[6] = (__bf16)xb[i][1].z; a1[7] = (__bf16)xb[i][1].w;
+                    }
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         bf16x8 bw;
@@ -360,8 +409,7 @@ __device__ __forceinline__ void gt_lean_mc_impl(const float* __restrict__ wp, co
                     }
                 }
                 GT_PIN_ORDER();
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) { xa[i][hf] = xld(i, hf, ma); xb[i][hf] = xld(i, hf, mb); }
+                xreq(i, ma, mb);
                 GT_PIN_ORDER();
             }
             if (mc == c0) GT_STAMP(dbg, 2);
@@ -455,7 +503,8 @@ __device__ __forceinline__ void gt_lean_mc(const float* __restrict__ wp, const i
                                            const int MT, const int c0, const int c1, float* lds, Pre pre, Epi epi,
                                            unsigned long long* dbg = nullptr) {
     LeanW<KPW, NT, BF16> W;
-    gt_lean_mc_impl<NW, KPW, NT, BF16, NTW, false>(wp, tile0, ntile, X, nkb32, MT, c0, c1, lds, pre, epi, dbg, W);
+    if (BF16 && X.ha) gt_lean_mc_impl<NW, KPW, NT, BF16, NTW, false, BF16>(wp, tile0, ntile, X, nkb32, MT, c0, c1, lds, pre, epi, dbg, W);
+    else gt_lean_mc_impl<NW, KPW, NT, BF16, NTW, false, false>(wp, tile0, ntile, X, nkb32, MT, c0, c1, lds, pre, epi, dbg, W);
 }
 
 // Recurrent-half worker job over chunks [c0, c1): gt_lean_partial's result for each, the job's weights read once.
@@ -487,6 +536,6 @@ __device__ __forceinline__ void gt_lean_partial_mc(const LeanPartialArgs& A, con
         }
     };
     // fp32: default cache policy, bf16: non-temporal -- as in gt_lean_partial
-    gt_lean_mc<NW, KPW, NT, BF16, BF16>(A.wp, tile0, ntile, LeanX{A.x, A.x, BF16 ? 2 * NW * KPW : NW * KPW}, NW * KPW, A.MT, c0, c1, lds,
-                                        [](int) {}, epi);
+    gt_lean_mc<NW, KPW, NT, BF16, BF16>(A.wp, tile0, ntile, LeanX{A.x, A.x, BF16 ? 2 * NW * KPW : NW * KPW, A.xh, A.xh}, NW * KPW, A.MT, c0, c1,
+                                        lds, [](int) {}, epi);
 }

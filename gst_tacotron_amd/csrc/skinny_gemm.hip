@@ -173,6 +173,9 @@ __device__ __forceinline__ uint32_t gt_ldu_sc1(const uint32_t* p) {
 // fused launches are in flight (several decode loops could each hold part of the chip and wait for the rest).  The wait is bounded all the same: a give-up raises the
 // host-mapped error word (gsttaco_synchronize reports it, the next call falls back to two launches).
 // ======================================================================================================================
+__device__ __forceinline__ void gt_sth_sc1(uint16_t* p, const uint16_t v) {
+    asm volatile("global_store_short %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"((uint32_t)v) : "memory");
+}
 __device__ __forceinline__ void gt_st1_sc1(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
@@ -340,11 +343,16 @@ __device__ __forceinline__ void gt_lstm_x_mc_body(const LstmXArgs& A, const int 
                 }
                 if (WT) gt_st1_sc1(A.h + gt_blk_off(grow, unit, MT), hv);
                 else A.h[gt_blk_off(grow, unit, MT)] = hv;
+                if (A.hh) {                                          // bf16 mirror for the next GEMMs' bf16 bodies
+                    if (WT) gt_sth_sc1(A.hh + gt_blk_off_h(grow, unit, MT), gt_bf16_bits(hv));
+                    else A.hh[gt_blk_off_h(grow, unit, MT)] = gt_bf16_bits(hv);
+                }
             }
         }
     };
-    gt_lean_mc_impl<NW, KPW, 2, BF16, false, PRE>(A.wp, tile0, ntile, LeanX{A.x, A.x, BF16 ? A.nkb : NW * KPW}, (A.nkb + 1) >> 1, MT, c0, c1, lds,
-                                                  pre, epi, A.dbg, W);
+    const LeanX X{A.x, A.x, BF16 ? A.nkb : NW * KPW, A.xh, A.xh};
+    if (BF16 && A.xh) gt_lean_mc_impl<NW, KPW, 2, BF16, false, PRE, BF16>(A.wp, tile0, ntile, X, (A.nkb + 1) >> 1, MT, c0, c1, lds, pre, epi, A.dbg, W);
+    else gt_lean_mc_impl<NW, KPW, 2, BF16, false, PRE, false>(A.wp, tile0, ntile, X, (A.nkb + 1) >> 1, MT, c0, c1, lds, pre, epi, A.dbg, W);
 }
 
 // which (pair, chunk range) a workgroup of the 1-D grid owns: the two workgroups of a pair sit 8 block indices apart
@@ -564,7 +572,8 @@ __global__ __launch_bounds__(512) void gt_proj_mc_kernel(ProjArgs P, LeanPartial
     const int gcol = tile * 16 + col;
     const float bias = P.bias[gcol];
     f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (BF16) gt_lean_core_bf16<NW, 5, 1, false>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mc, 36, acc0, acc1);
+    if (BF16 && P.xah && P.xbh) gt_lean_core_bf16<NW, 5, 1, false, false, BF16>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a, P.xah, P.xbh}, P.MT, mc, 36, acc0, acc1);
+    else if (BF16) gt_lean_core_bf16<NW, 5, 1, false>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mc, 36, acc0, acc1);
     else gt_lean_core<NW, 9, 1, false>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mc, acc0, acc1);
     gt_lean_spill<NW, 1>(lds, acc0, acc1);
     __syncthreads();
@@ -586,6 +595,7 @@ hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp
                                float* co_out, int co_begin, int co_end, int tiles_per_worker, bool bf16, hipStream_t stream) {
     const int nco = co_end > co_begin ? co_end - co_begin : 0;
     LeanPartialArgs co{co_wp, co_bias, co_x, co_out, m.MT};
+    if (co_x == m.xa) co.xh = m.xah;          // the workers multiply the same h2 the projection reads: its bf16 mirror, if there is one
     if (m.M > 32) {
         const int n_mc = ntiles * ((m.M + 31) / 32);
         const dim3 g(n_mc + (nco + 1) / 2 * ((m.M + 31) / 32));

@@ -74,6 +74,58 @@ __global__ __launch_bounds__(NT) void kmix(float* out, int iters, unsigned long 
     out[blockIdx.x * NT + threadIdx.x] = s + b;
     if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
 }
+
+// ... and 16x16x4 MFMAs whose B operands come from LDS (two ds_read_b128 per 8 MFMAs, requested one step ahead) and, with XG, whose A
+// operand comes from memory (one 16-byte load per lane per 8 MFMAs, 8 steps ahead): the M-split decode body's inner loop (msplit_body.h).
+template <int XG, int NT>
+__global__ __launch_bounds__(NT) void kfeed(float* out, const float* __restrict__ xg, int iters, unsigned long long* cyc) {
+    __shared__ __attribute__((aligned(16))) float lds[32768];            // 128 KB
+    for (int i = threadIdx.x; i < 32768; i += NT) lds[i] = i * 1e-5f;
+    __syncthreads();
+    f32x4 acc[2][8];
+    for (int c = 0; c < 16; ++c) for (int e = 0; e < 4; ++e) acc[c >> 3][c & 7][e] = 0.f;
+    const int lane = threadIdx.x & 63;
+    const float4* wl = reinterpret_cast<const float4*>(lds) + lane;
+    const float4* xp = reinterpret_cast<const float4*>(xg) + (size_t)(blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * 64 * 64 + lane;
+    float4 x[8];
+    for (int i = 0; i < 8; ++i) x[i] = XG ? xp[i * 64] : make_float4(lane * 1e-3f, 0.5f, 0.25f, 0.125f);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        float4 b[2][2];
+        b[0][0] = wl[0]; b[0][1] = wl[64];
+#pragma unroll
+        for (int kb = 0; kb < 64; ++kb) {
+            if (kb + 1 < 64) { b[(kb + 1) & 1][0] = wl[((kb + 1) * 2) * 64]; b[(kb + 1) & 1][1] = wl[((kb + 1) * 2 + 1) * 64]; }
+            const float4 xv = x[kb % 8];
+            for (int t = 0; t < 2; ++t) acc[t][kb % 8] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.x, b[kb & 1][t].x, acc[t][kb % 8], 0, 0, 0);
+            for (int t = 0; t < 2; ++t) acc[t][kb % 8] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.y, b[kb & 1][t].y, acc[t][kb % 8], 0, 0, 0);
+            for (int t = 0; t < 2; ++t) acc[t][kb % 8] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.z, b[kb & 1][t].z, acc[t][kb % 8], 0, 0, 0);
+            for (int t = 0; t < 2; ++t) acc[t][kb % 8] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv.w, b[kb & 1][t].w, acc[t][kb % 8], 0, 0, 0);
+            if (XG && kb + 8 < 64) x[kb % 8] = xp[(kb + 8) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (XG) for (int i = 0; i < 8; ++i) x[i] = xp[i * 64];
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int c = 0; c < 16; ++c) for (int e = 0; e < 4; ++e) s += acc[c >> 3][c & 7][e];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <typename K>
+static void runfeed(const char* name, K kern, int nt, float* out, const float* xg, unsigned long long* cyc) {
+    const int iters = 40;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(nt), 0, 0, out, xg, 2, cyc);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(nt), 0, 0, out, xg, iters, cyc);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    const double mfma_per_simd = (double)iters * 512 * (nt / 256.0);
+    printf("%-44s %7.1f us  %6.1f TFLOP/s  %6.1f s_memtime ticks per MFMA and SIMD  (%.0f ticks/us)\n", name, ms * 1e3,
+           256.0 * (nt / 64) * iters * 512 * 2048.0 / (ms * 1e-3) * 1e-12, (double)c / mfma_per_simd, (double)c / (ms * 1e3));
+}
 template <typename K>
 static void run(const char* name, K kern, int nt, int chains, double flop_per_mfma, float* out, unsigned long long* cyc) {
     const int iters = 4000;
@@ -108,5 +160,10 @@ int main() {
     run("32x32x2 1 wave/SIMD + 4 fma + LDS read", kmix<4, 1, 256>, 256, 1, 4096, out, cyc);
     run("32x32x2 2 waves/SIMD + 8 fma per MFMA", kmix<8, 0, 512>, 512, 1, 4096, out, cyc);
     run("32x32x2 2 waves/SIMD + 16 fma per MFMA", kmix<16, 0, 512>, 512, 1, 4096, out, cyc);
+    float* xg; CK(hipMalloc(&xg, (size_t)256 * 8 * 64 * 64 * 16));
+    CK(hipMemset(xg, 0, (size_t)256 * 8 * 64 * 64 * 16));
+    runfeed("16x16x4 B from LDS, 1 wave/SIMD", kfeed<0, 256>, 256, out, xg, cyc);
+    runfeed("16x16x4 B from LDS, 2 waves/SIMD", kfeed<0, 512>, 512, out, xg, cyc);
+    runfeed("16x16x4 B from LDS + A from memory, 2 waves/SIMD", kfeed<1, 512>, 512, out, xg, cyc);
     return 0;
 }
