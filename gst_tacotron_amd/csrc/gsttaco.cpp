@@ -141,6 +141,7 @@ struct gsttaco_ctx {
     int co_tiles = -1;           // layer-2 recurrent tiles computed beside the projection (the rest beside the front end); -1 = by batch size
     int worker_tiles = 2;        // tiles per worker job in the front launch (2: pairs sharing one activation pass)
     int co_worker_tiles = 1;     // the same for the projection launch's workers
+    int proj_both_m = 0;         // projection launch at 17..32 rows: one workgroup per tile over both M-tiles (GSTTACO_PROJ_BOTH_M, debug builds)
     int wino = 4;                // Winograd for the 5-tap Conv1D layers that fill the chip: 4 = F(4,5) where its grid fills the chip and F(2,5)
                                  // otherwise, 2 = F(2,5) only, 0 = implicit GEMM only (GSTTACO_WINO)
     bool bilstm_persist = true;  // one persistent launch per BiLSTM instead of one per time step (GSTTACO_BILSTM_PERSIST=0: per step)
@@ -1147,6 +1148,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                             k.out, k.ldo, k.out2, k.ldo2, k.out3, k.ldo3,
                             (c->stamps && t == steps / 2) ? c->w_dbg + 40 : nullptr};
                 if (mirror) { pa.xah = c->w_h2_h[p]; pa.xbh = c->w_xa_h + (size_t)(P1 / 32) * MT * 512; }
+                pa.both_m = (c->proj_both_m && B > 16 && B <= 32) ? 1 : 0;
                 HIPCHECK(c, gt_launch_proj_lean(pa, PJ.ntiles, rk.wp, rk.bias, rk.seg[0].ptr, rk.partial_out, 0, co_tiles,
                                                 c->co_worker_tiles, k.bf16 != 0, s));
             } else
@@ -1633,6 +1635,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->co_tiles = env_int("GSTTACO_CO_TILES", -1);
     c->worker_tiles = env_int("GSTTACO_WORKER_TILES", 2);
     c->co_worker_tiles = env_int("GSTTACO_CO_WORKER_TILES", 1);
+    c->proj_both_m = env_int("GSTTACO_PROJ_BOTH_M", 0);
     c->keep_hash = env_int("GSTTACO_KEEP_HASH", 1) != 0;
     if (const char* e = getenv("GSTTACO_SCHED")) {      // "unit_fp32,unit_bf16,chain" in microseconds (cost model of plan_front_jobs)
         double a = 0, b = 0, d = 0;

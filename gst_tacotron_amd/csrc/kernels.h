@@ -165,6 +165,8 @@ struct ProjArgs {
     float* out3; int64_t ldo3;
     unsigned long long* dbg;                        // diagnostic stamps (8 slots) or NULL
     const uint16_t* xah = nullptr; const uint16_t* xbh = nullptr;   // bf16 mirrors of xa / xb or NULL (gt_proj_mc_kernel<true>)
+    int both_m = 0;     // batches of 17..32 rows: ONE workgroup per tile multiplies both 16-row M-tiles (the tile's weights leave the
+                        // memory side once) instead of one workgroup per (tile, M-tile)
 };
 bool gt_proj_lean_supported(int nkb_main, int nkb_co);
 hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp, const float* co_bias, const float* co_x,

@@ -518,17 +518,25 @@ __global__ __launch_bounds__(512) void gt_proj_lean_kernel(ProjArgs P, LeanParti
         return;
     }
     GT_STAMP(P.dbg, 0);
-    // main tiles: one workgroup per (tile, 16-row M-tile) -- 27 tiles would leave most CUs idle, so the rows are split
+    // main tiles: one workgroup per (tile, 16-row M-tile) -- 27 tiles would leave most CUs idle, so the rows are split; or
+    // (P.both_m) one workgroup per tile and both M-tiles: the same sums per output, the tile's weights requested once
     int tile, mt;
-    gt_pair_map((int)blockIdx.x, n_main, P.MT, tile, mt);
-    const int row = (threadIdx.x >> 4) & 15, col = threadIdx.x & 15, half = threadIdx.x >> 8;   // waves 0-3 / 4-7 reduce half the partials each
+    if (P.both_m) { tile = (int)blockIdx.x; mt = 0; }
+    else gt_pair_map((int)blockIdx.x, n_main, P.MT, tile, mt);
+    const int col = threadIdx.x & 15;
+    const int row = P.both_m ? (threadIdx.x >> 4) : ((threadIdx.x >> 4) & 15), half = P.both_m ? 0 : (threadIdx.x >> 8);   // one M-tile: waves 0-3 reduce
     const int gcol = tile * 16 + col;
     const float bias = P.bias[gcol];
     f32x4 acc0[1] = {f32x4{0.f, 0.f, 0.f, 0.f}}, acc1[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (BF16) gt_lean_core_bf16<NW, 5, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, 36, acc0, acc1);
-    else gt_lean_core<NW, 9, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, acc0, acc1);
+    if (P.both_m) {
+        if (BF16) gt_lean_core_bf16<NW, 5, 1, false, false>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, 0, 36, acc0, acc1);
+        else gt_lean_core<NW, 9, 1, false, false>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, 0, acc0, acc1);
+    } else {
+        if (BF16) gt_lean_core_bf16<NW, 5, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, 36, acc0, acc1);
+        else gt_lean_core<NW, 9, 1, false, true>(P.wp, tile, 1, LeanX{P.xa, P.xb, P.nkb_a}, P.MT, mt, acc0, acc1);
+    }
     GT_STAMP(P.dbg, 1);
-    gt_lean_spill<NW, 1>(lds, acc0, acc1);          // (rows 16..31 of the slab are unused zeros)
+    gt_lean_spill<NW, 1>(lds, acc0, acc1);          // (one M-tile: rows 16..31 of the slab are unused zeros)
     __syncthreads();
     GT_STAMP(P.dbg, 2);
     const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
@@ -603,7 +611,7 @@ hipError_t gt_launch_proj_lean(const ProjArgs& m, int ntiles, const float* co_wp
         else hipLaunchKernelGGL((gt_proj_mc_kernel<false>), g, dim3(512), 0, stream, m, co, n_mc, co_begin, co_end);
         return hipGetLastError();
     }
-    const int n_main = ntiles * m.MT;
+    const int n_main = m.both_m ? ntiles : ntiles * m.MT;
     const dim3 g2(n_main + (nco + 1) / 2), g1(n_main + nco * m.MT);
     if (tiles_per_worker == 2) {
         if (bf16) hipLaunchKernelGGL((gt_proj_lean_kernel<2, true>), g2, dim3(512), 0, stream, m, co, n_main, co_begin, co_end);
