@@ -38,7 +38,12 @@ constexpr int PD_P = 256, PD_A = 128, PD_H = 1024, PD_TV = 128, PD_LDV = PD_A + 
 constexpr int PD_KBP = PD_P / 16, PD_KBC = PD_A / 16, PD_KBH = PD_H / 16, PD_KBPJ = PD_KBH + PD_KBC;
 constexpr uint32_t PD_SPIN_MAX = 1u << 20;
 
-// control words (zeroed before every launch): a 128-byte line per flag / counter shard
+// control words (zeroed before every launch): a 128-byte line per counter shard and per chain-tile flag, two utterance flags per line
+#ifndef PD_FS
+#define PD_FS 16       // words between the per-utterance prenet / context flags.  Same-box A/B (profiles/r04_ab.txt): 32 (a line each, 32
+                       // requests per poll) 20.5-20.7 us per step, 16 (two per line) 20.4, 8: 20.9-21.2, 1 (all 32 in ONE line, a poll is one
+                       // request): 24.2 -- 32 writers and 256 pollers on one line queue at its memory channel
+#endif
 constexpr int PD_F_P = 0, PD_F_C = 32 * 32, PD_CNT3 = 2 * 32 * 32, PD_CNT4 = PD_CNT3 + 256, PD_F_H = PD_CNT4 + 256, PD_CTL_WORDS = PD_F_H + 64 * 32;
 
 __device__ __forceinline__ uint32_t pd_ld_sc1(const uint32_t* p) {
@@ -80,12 +85,13 @@ __device__ __forceinline__ void pd_give_up(const PersistDecodeArgs& A, PdShared*
     sh->abort = 1;
 }
 // flags [n] (a line each) all >= want
+template <int STRIDE = 32>
 __device__ __forceinline__ void pd_wait_flags(const PersistDecodeArgs& A, const uint32_t* f, int n, uint32_t want, PdShared* sh) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         uint32_t spins = 0;
         for (;;) {
-            const uint32_t v = lane < n ? pd_ld_sc1(f + lane * 32) : want;
+            const uint32_t v = lane < n ? pd_ld_sc1(f + lane * STRIDE) : want;
             if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(v >= want))) == 64) break;
             if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
             if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
@@ -229,21 +235,21 @@ __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int
     f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
     float4 x0[3], x1[3];
     if (split) {
-        pd_wait_flags(A, A.ctl + PD_F_P, A.B, (uint32_t)t + 1u, sh);
+        pd_wait_flags<PD_FS>(A, A.ctl + PD_F_P, A.B, (uint32_t)t + 1u, sh);
         if (sh->abort) return;
         PD_STAMP(role, 1);
         pd_xload<0, 2, 3>(xa, MT, x0, x1);
         PD_PIN();
         pd_mma<2, 0, 1, 3>(x0, x1, W.x1, a0, a1);
         PD_STAMP(role, 2);
-        pd_wait_flags(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);
+        pd_wait_flags<PD_FS>(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);
         if (sh->abort) return;
         PD_STAMP(role, 3);
         pd_xload<2, 3, 3>(xa, MT, x0, x1);
         PD_PIN();
         pd_mma<1, 2, 1, 3>(x0, x1, W.x1, a0, a1);
     } else {
-        pd_wait_flags(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);      // (a chain's context flag is set after its prenet flag)
+        pd_wait_flags<PD_FS>(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);      // (a chain's context flag is set after its prenet flag)
         if (sh->abort) return;
         PD_STAMP(role, 3);
         pd_xload<0, 3, 3>(xa, MT, x0, x1);
@@ -497,7 +503,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
     if (tid < 64) {
         pd_st4_sc1(xa + gt_blk_off(b, 4 * tid, MT), *reinterpret_cast<const float4*>(L.y1 + 4 * tid));
         pd_drain();
-        if (tid == 0) pd_st1_sc1(A.ctl + PD_F_P + b * 32, (uint32_t)t + 1u);
+        if (tid == 0) pd_st1_sc1(A.ctl + PD_F_P + b * PD_FS, (uint32_t)t + 1u);
     }
     if (t > 0 && tid >= PD_NT - 64) {        // the last wave, meanwhile: this tile's layer-1 recurrent half from its helper must show step t
         const int l2 = tid & 63;
@@ -633,7 +639,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
             pd_st4_sc1(xa + gt_blk_off(b, PD_P + 4 * tid, MT), make_float4(c[0], c[1], c[2], c[3]));
         }
         pd_drain();
-        if (tid == 0) pd_st1_sc1(A.ctl + PD_F_C + b * 32, (uint32_t)t + 1u);
+        if (tid == 0) pd_st1_sc1(A.ctl + PD_F_C + b * PD_FS, (uint32_t)t + 1u);
     }
     PD_STAMP(0, 20);
 }
