@@ -393,29 +393,54 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // (the next slice's 260 rows are staged in two halves -- requested at taps 0 / 2, stored at taps 1 / 3 -- so that only five
-    // float4 of them are ever live beside the 128 accumulator registers: with all nine the weight staging registers went
+    // pieces of them are ever live beside the 128 accumulator registers: with all nine the weight staging registers went
     // through scratch, and a scratch store waits for the loads it saves)
+    // Every row piece is an UNCONDITIONAL buffer load: a row outside the utterance (SAME padding, masked mode, the tile's tail) gets an
+    // out-of-range offset and reads as zero.  As loads under `if (row in range)` each one was waited for on the spot (vmcnt(0) at the
+    // end of its branch: the bf16 form converts right there) -- five dependent memory latencies at taps 0 and 2 of every slice, more
+    // than the slice's MFMA time (round 4: 205 -> see DESIGN 3.4 per 512 -> 512 layer).  bf16 input: the 8 bytes go to LDS as they are.
     constexpr int A_H0 = (A_F4 + 1) / 2;
-    float4 ra[A_H0];
+    constexpr int AE = XB ? 2 : 4;                               // bytes per input element
+    // (the resource starts pad_before rows BEFORE the tensor, so that the offset of frame -pad_before of utterance 0 is 0 and no
+    // per-thread base is negative; those rows are never requested: their pieces get the out-of-range offset)
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(A.x)) - (size_t)A.pad_before * A.Cin * AE, 0,
+                                                        (int)(((size_t)A.B * A.T + A.pad_before) * A.Cin * AE), 0x00020000);
+    // this thread's pieces: rows (tid >> 4) + 32 j, channel quad tid & 15; the row part of the address is a per-thread base + a scalar
+    const int row0 = tid >> 4, tt0 = t0 - A.pad_before + row0;
+    const uint32_t abase = (uint32_t)((((int64_t)b * A.T + t0 + row0) * A.Cin + (tid & 15) * 4) * AE);
+    float4 ra[XB ? 1 : A_H0];
+    uint2 rh[XB ? A_H0 : 1];
     u32x4 rb[B_U4];
     auto load_a = [&](const int k0, const int half) {
 #pragma unroll
         for (int i = 0; i < A_H0; ++i) {
-            const int f = tid + (half * A_H0 + i) * 512;
-            const int row = f >> 4, t = t0 - A.pad_before + row;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < C5_AR && t >= 0 && t < len) ra[i] = gt_act_load4(A.x, ((int64_t)b * A.T + t) * A.Cin + k0 + (f & 15) * 4, XB);
+            const int j = half * A_H0 + i;
+            const int row = row0 + 32 * j, t = tt0 + 32 * j;
+            // (Cin not a multiple of the 64-channel slice -- the postnet's 80 -> 512 layer: channels past Cin read as zero, so the
+            // weights they meet, the next tap's or the K padding, do not matter)
+            const uint32_t vo = (row < C5_AR && t >= 0 && t < len && k0 + (tid & 15) * 4 < A.Cin) ? abase : 0x80000000u;
+            const int so = (32 * j * A.Cin + k0) * AE;
+            if constexpr (XB) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, (int)vo, so, 0);
+                __builtin_memcpy(&rh[i], &v, 8);
+            } else {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo, so, 0);
+                __builtin_memcpy(&ra[i], &v, 16);
+            }
         }
     };
     auto store_a = [&](const int buf, const int half) {
 #pragma unroll
         for (int i = 0; i < A_H0; ++i) {
-            const int f = tid + (half * A_H0 + i) * 512;
-            const int row = f >> 4;
+            const int row = row0 + 32 * (half * A_H0 + i);
             if (row < C5_AR) {
-                bf16x4 h;
-                h[0] = (__bf16)ra[i].x; h[1] = (__bf16)ra[i].y; h[2] = (__bf16)ra[i].z; h[3] = (__bf16)ra[i].w;
-                *reinterpret_cast<bf16x4*>(&As[(buf * C5_AR + row) * C5_LD + (f & 15) * 4]) = h;
+                if constexpr (XB) {
+                    *reinterpret_cast<uint2*>(&As[(buf * C5_AR + row) * C5_LD + (tid & 15) * 4]) = rh[i];
+                } else {
+                    bf16x4 h;
+                    h[0] = (__bf16)ra[i].x; h[1] = (__bf16)ra[i].y; h[2] = (__bf16)ra[i].z; h[3] = (__bf16)ra[i].w;
+                    *reinterpret_cast<bf16x4*>(&As[(buf * C5_AR + row) * C5_LD + (tid & 15) * 4]) = h;
+                }
             }
         }
     };
@@ -434,7 +459,7 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
         }
     };
 
-    const int nslices = A.Cin / C5_BK, nsteps = nslices * 5;
+    const int nslices = (A.Cin + C5_BK - 1) / C5_BK, nsteps = nslices * 5;
     load_a(0, 0);
     store_a(0, 0);
     load_a(0, 1);
@@ -519,7 +544,8 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
 }
 
 static bool gt_conv5_bf16_applies(const ConvGemmArgs& a) {
-    return a.wt_bf16 && a.taps == 5 && a.Cin % C5_BK == 0 && !a.tokens && !a.pool2 && !a.conv2d && a.N >= 64 && a.T >= 64;
+    return a.wt_bf16 && a.taps == 5 && a.Cin % 4 == 0 && (a.Cin % C5_BK == 0 || a.ldk >= 4 * a.Cin + (a.Cin + C5_BK - 1) / C5_BK * C5_BK) && !a.tokens && !a.pool2 && !a.conv2d && a.N >= 64 && a.T >= 64 &&
+           ((size_t)a.B * a.T + a.pad_before) * a.Cin * 4 < 0x7FFFFFFFull;         // (the input as one buffer resource)
 }
 
 hipError_t gt_conv5_bf16_init() {

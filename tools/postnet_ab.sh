@@ -1,9 +1,12 @@
 #!/bin/bash
-# postnet alone (bench.py's roofline.postnet.ms) for two builds / environments, alternating.   bash tools/postnet_ab.sh <N> "<bench args>" "ENV_A" "ENV_B"
+# Same-box A/B of the postnet time (roofline.postnet.ms of bench.py) for two builds / environments, alternating, N rounds.
+#   bash tools/postnet_ab.sh <N> "<bench args>" "ENV_A=.." "ENV_B=.."
 N=$1; ARGS=$2; shift 2
-for i in $(seq 1 $N); do for cfg in "$@"; do
-  env $cfg python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-serving $ARGS 2>/dev/null | python -c "
+for i in $(seq 1 $N); do
+  for cfg in "$@"; do
+    env $cfg python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-serving $ARGS 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); p = d['roofline']['postnet']
-print('%-50s postnet %.3f ms  %.0f TF  (step %.3f ms)' % ('$cfg', p['ms'], p['TFLOP/s'], d['ms_per_step']))"
-done; done
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('%-50s %8.3f ms/step  postnet %.3f ms' % ('$cfg', d['ms_per_step'], d['roofline']['postnet']['ms']))"
+  done
+done
