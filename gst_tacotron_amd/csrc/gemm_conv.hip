@@ -243,7 +243,38 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
     float4 ra[A_F4];
     u32x4 rb[B_U4];       // (ext_vector_type, NOT HIP's uint4 struct: an array of those is not promoted to registers here -- it went through scratch)
     const __bf16* wt = reinterpret_cast<const __bf16*>(A.wt_bf16);
+    // The gather: every piece is ONE unconditional buffer load whose offset is out of range (-> zero) where the im2col element does not
+    // exist (SAME padding, masked rows, the M / K tails); with a token gather the (clamped) token is an unconditional load in front of it.
+    // (As loads under `if (valid)` each piece was waited for at the end of its branch -- the bf16 form converts right there.)  Only the
+    // pooled form (MaxPool1D fused into the gather: the vocoder's CBHG) keeps the conditional loads.
+    constexpr int AE = XB ? 2 : 4;
+    const bool buf_ok = !A.pool2 && (A.tokens != nullptr || (size_t)Mtot * A.Cin * AE < 0x7FFFFFFFull);      // (uniform)
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x), 0, A.tokens ? 0x7FFFFFFF : (int)((size_t)Mtot * A.Cin * AE), 0x00020000);
     auto load_slice = [&](int k0) {
+        if (buf_ok) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const int f = tid + i * 256;
+                const int kk = k0 + (f & 15) * 4;
+                const int tap = kk / A.Cin;
+                const int c = kk - tap * A.Cin;
+                const int ts = a_t[i] + tap - A.pad_before;
+                const bool ok = a_ok[i] && kk < K && ts >= 0 && ts < a_len[i];
+                const int64_t rowi = ok ? (int64_t)a_b[i] * A.T + ts : 0;
+                const int64_t ri = A.tokens ? (int64_t)A.tokens[rowi] : rowi;
+                const uint32_t vo = ok ? (uint32_t)((ri * A.Cin + c) * AE) : 0x80000000u;
+                if constexpr (XB) {
+                    const auto t = __builtin_amdgcn_raw_buffer_load_b64(rs_x, (int)vo, 0, 0);
+                    uint2 h;
+                    __builtin_memcpy(&h, &t, 8);
+                    ra[i] = make_float4(__builtin_bit_cast(float, h.x << 16), __builtin_bit_cast(float, h.x & 0xFFFF0000u),
+                                        __builtin_bit_cast(float, h.y << 16), __builtin_bit_cast(float, h.y & 0xFFFF0000u));
+                } else {
+                    const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo, 0, 0);
+                    __builtin_memcpy(&ra[i], &t, 16);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int f = tid + i * 256;
@@ -264,6 +295,7 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
                 }
             }
             ra[i] = v;
+        }
         }
 #pragma unroll
         for (int i = 0; i < B_U4; ++i) {
