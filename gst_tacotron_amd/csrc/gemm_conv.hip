@@ -62,23 +62,43 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_kernel(ConvGemmArgs A) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[A_F4], rb[B_F4];
+    // 2-D mode: per piece the output position's input origin and batch offset; per slice (load_slice) this thread's tap
+    int c2_h0[C2D ? A_F4 : 1], c2_w0[C2D ? A_F4 : 1];
+    int64_t c2_b[C2D ? A_F4 : 1];
+    int c2_ti = 0, c2_tj = 0, c2_c = 0;
+    const auto c2_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x), 0, C2D ? (int)min((int64_t)0x7FFFFFFF, (int64_t)A.B * A.xb * 4) : 0, 0x00020000);
+    if (C2D) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            const int ho = a_t[i] / A.Wo, wo = a_t[i] - ho * A.Wo;
+            c2_h0[i] = ho * A.stride - A.pad_h;
+            c2_w0[i] = wo * A.stride - A.pad_w;
+            c2_b[i] = (int64_t)a_b[i] * A.xb;
+        }
+    }
 
     auto load_slice = [&](int k0) {
+        if (C2D) {
+            const int kk = k0 + (tid & 7) * 4;
+            const int tap = kk / A.Cin;
+            c2_c = kk - tap * A.Cin;
+            c2_ti = tap / A.kw;
+            c2_tj = tap - c2_ti * A.kw;
+        }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             const int f = tid + i * 256;
             const int kk = k0 + (f & 7) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (C2D) {                                           // 2-D taps, stride, NHWC input (ConvGemmArgs::conv2d)
-                if (a_ok[i] && kk < K) {
-                    const int tap = kk / A.Cin;
-                    const int c = kk - tap * A.Cin;
-                    const int ti = tap / A.kw, tj = tap - ti * A.kw;
-                    const int ho = a_t[i] / A.Wo, wo = a_t[i] - ho * A.Wo;
-                    const int hi = ho * A.stride + ti - A.pad_h, wi = wo * A.stride + tj - A.pad_w;
-                    if (hi >= 0 && hi < A.H && wi >= 0 && wi < A.W)
-                        v = *reinterpret_cast<const float4*>(A.x + (int64_t)a_b[i] * A.xb + ((int64_t)hi * A.W + wi) * A.Cin + c);
-                }
+                // (this thread's k quad is the same for all of its pieces: the tap decomposition is done once per slice, the output
+                // position's once per kernel -- c2_h0 / c2_w0; the piece is ONE unconditional buffer load, out of range = zero.  These
+                // launches are a few workgroups with 18-36 dependent slices each: the divisions and branches WERE the slice time.)
+                const int hi = c2_h0[i] + c2_ti, wi = c2_w0[i] + c2_tj;
+                const bool ok = a_ok[i] && kk < K && hi >= 0 && hi < A.H && wi >= 0 && wi < A.W;
+                const uint32_t vo = ok ? (uint32_t)((c2_b[i] + ((int64_t)hi * A.W + wi) * A.Cin + c2_c) * 4) : 0x80000000u;
+                const auto t4 = __builtin_amdgcn_raw_buffer_load_b128(c2_rs, (int)vo, 0, 0);
+                __builtin_memcpy(&v, &t4, 16);
             } else if (a_ok[i] && kk < K) {
                 const int tap = kk / A.Cin;
                 const int c = kk - tap * A.Cin;
@@ -911,6 +931,7 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         }
     }
     if (a.conv2d) {
+        if ((size_t)a.B * a.xb * 4 >= 0x7FFFFFFFull) return hipErrorInvalidValue;      // (the 2-D gather addresses the input as one buffer resource)
         if (a.N > 64) hipLaunchKernelGGL((gt_conv_gemm_kernel<1, 4, 1, 1, true>), dim3((M + 31) / 32, (a.N + 127) / 128), dim3(256), 0, stream, a);
         else if (a.N > 32) hipLaunchKernelGGL((gt_conv_gemm_kernel<4, 1, 1, 2, true>), dim3((M + 127) / 128, 1), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((gt_conv_gemm_kernel<4, 1, 1, 1, true>), dim3((M + 127) / 128, 1), dim3(256), 0, stream, a);
