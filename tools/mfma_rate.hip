@@ -126,6 +126,53 @@ static void runfeed(const char* name, K kern, int nt, float* out, const float* x
     printf("%-44s %7.1f us  %6.1f TFLOP/s  %6.1f s_memtime ticks per MFMA and SIMD  (%.0f ticks/us)\n", name, ms * 1e3,
            256.0 * (nt / 64) * iters * 512 * 2048.0 / (ms * 1e-3) * 1e-12, (double)c / mfma_per_simd, (double)c / (ms * 1e3));
 }
+
+// ... and the bf16 pipe as gt_conv5_bf16_kernel uses it: 32x32x16 bf16 MFMAs, a wave's 2 x 4 accumulator tiles, operands read from LDS
+// (6 ds_read_b128 per 8 MFMAs), data = pseudo-random bf16 (RND) or a constant: what the pipe sustains under its own power draw.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int RND, int NT>
+__global__ __launch_bounds__(NT) void kbf16(float* out, int iters, unsigned long long* cyc) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[40960];            // 80 KB
+    for (int i = threadIdx.x; i < 40960; i += NT) {
+        unsigned int h = (unsigned int)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        lds[i] = RND ? (unsigned short)(0x3C00u + (h & 0x83FFu)) : (unsigned short)0x3F80u;     // +-[0.5, 2) or 1.0
+    }
+    __syncthreads();
+    f32x16 acc[2][4];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned short* Ab = lds + ((wave >> 1) * 64 + (lane & 31)) * 72 + (lane >> 5) * 8;
+    const unsigned short* Bb = lds + 20480 + ((wave & 1) * 128 + (lane & 31)) * 72 + (lane >> 5) * 8;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t av[2], bv[4];
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8_t*>(Ab + ((i * 32 + (it & 3)) * 72 + ks * 16) % 18000);
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const bf16x8_t*>(Bb + (j * 32 * 72 + ks * 16) % 18000);
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) for (int e = 0; e < 16; ++e) s += acc[i][j][e];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <typename K>
+static void runbf(const char* name, K kern, int nt, float* out, unsigned long long* cyc) {
+    const int iters = 4000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(nt), 0, 0, out, 10, cyc);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(nt), 0, 0, out, iters, cyc);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    printf("%-44s %7.1f us  %6.1f TFLOP/s  %6.1f ticks per MFMA and wave  (%.0f ticks/us)\n", name, ms * 1e3,
+           256.0 * (nt / 64) * iters * 32 * 32768.0 / (ms * 1e-3) * 1e-12, (double)c / (iters * 32.0), (double)c / (ms * 1e3));
+}
 template <typename K>
 static void run(const char* name, K kern, int nt, int chains, double flop_per_mfma, float* out, unsigned long long* cyc) {
     const int iters = 4000;
@@ -165,5 +212,8 @@ int main() {
     runfeed("16x16x4 B from LDS, 1 wave/SIMD", kfeed<0, 256>, 256, out, xg, cyc);
     runfeed("16x16x4 B from LDS, 2 waves/SIMD", kfeed<0, 512>, 512, out, xg, cyc);
     runfeed("16x16x4 B from LDS + A from memory, 2 waves/SIMD", kfeed<1, 512>, 512, out, xg, cyc);
+    runbf("bf16 32x32x16 from LDS, constant data, 8 waves", kbf16<0, 512>, 512, out, cyc);
+    runbf("bf16 32x32x16 from LDS, random data, 8 waves", kbf16<1, 512>, 512, out, cyc);
+    runbf("bf16 32x32x16 from LDS, random data, 4 waves", kbf16<1, 256>, 256, out, cyc);
     return 0;
 }
