@@ -612,8 +612,12 @@ def test_mixed_precision_matches_the_bf16_emulating_oracle(kind):
     mel, stop, spec, align, pre = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps,
                                                    with_vocoder=True, return_pre_mel=True)
     torch.cuda.synchronize()
+    # Which operands get rounded to bf16 depends on the algebraic form: DESIGN 3.1b folds prenet-0 into the projection for every BMA / SMA
+    # model (the projection and the first prenet Dense are both linear).  The oracle is told that form a priori -- not by the product --
+    # and the product is held to it.
+    assert m.decode_plan(Tv)[1] is True
     ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64, with_vocoder=True, mixed=True,
-                                   fused_prenet0=m.decode_plan(Tv)[1])
+                                   fused_prenet0=True)
     fp32 = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64, with_vocoder=True)
     errs = {"mel": np.abs(mel.cpu().numpy() - ref[0]).max(), "stop": np.abs(stop.cpu().numpy() - ref[1]).max(),
             "spec": np.abs(spec.cpu().numpy() - ref[2]).max(), "align": np.abs(align.cpu().numpy() - ref[3]).max()}
