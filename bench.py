@@ -252,6 +252,8 @@ def main():
                     "configs[4]); NOT the headline metric -- dtype is then reported as bf16")
     ap.add_argument("--batch-per-gpu", type=int, default=BATCH_PER_GPU, help="utterances per GPU (default 32 = the headline "
                     "configuration; BASELINE configs[4] uses 64 with --mixed).  Any other value is NOT the headline metric")
+    ap.add_argument("--inject-give-up", action="store_true", help="test hook: make the first timed run's in-kernel hand-off give up "
+                    "(gsttaco_debug_raise_handoff_error), to exercise the discard-and-repeat path; the line then carries fallback_taken")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="wall-time budget of the bounded CPU-baseline sample (both thread counts)")
     args = ap.parse_args()
 
@@ -303,40 +305,54 @@ def main():
     def set_prof(on):
         model.ctx.check(lib.gsttaco_set_profiling(handle, PROFILE_EVERY if on else 0))
 
-    set_prof(True)
-    one_step(-1).result()                          # capture + first replay of the bracketed graph (untimed, extra)
-    set_prof(False)
-    for i in range(args.warmup):
-        one_step(i).result()
-    if args.warmup == 0:
-        one_step(0).result()                       # the plain graph must exist before the clock starts
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out, pending = None, None
-    for i in range(args.steps):
-        if i == args.steps - 1:
-            set_prof(True)
-        nxt = one_step(args.warmup + i)
-        if pending is not None:
-            out = pending.result()
-        pending = nxt
-    out = pending.result()                         # every gather has completed before the clock stops
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    # an in-kernel hand-off that gave up (persistent BiLSTM / fused LSTM launch without co-residency) would have produced garbage at full
-    # speed: fail here rather than report a number for it (gsttaco_synchronize; the clock has stopped)
-    model.synchronize()
-    # ... and a give-up during warm-up would have left the timed loop on the fallback launches: never report that as the fused
-    # configuration (the library says so in a "warning:" text)
+    def timed_run():
+        """Warm-up + the timed region; returns the elapsed seconds (the clock stops after every gather has completed)."""
+        set_prof(True)
+        one_step(-1).result()                      # capture + first replay of the bracketed graph (untimed, extra)
+        set_prof(False)
+        for i in range(args.warmup):
+            one_step(i).result()
+        if args.warmup == 0:
+            one_step(0).result()                   # the plain graph must exist before the clock starts
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pending = None
+        for i in range(args.steps):
+            if i == args.steps - 1:
+                set_prof(True)
+            nxt = one_step(args.warmup + i)
+            if pending is not None:
+                pending.result()
+            pending = nxt
+        last = pending.result()                    # every gather has completed before the clock stops
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, last
+
+    # An in-kernel hand-off that gave up (persistent decode / BiLSTM / fused LSTM launch without co-residency: e.g. another process on
+    # the GPU) produced garbage at full speed: gsttaco_synchronize says so after the clock has stopped, and the context has switched to
+    # its launch-per-step forms (same results, slower).  That run is DISCARDED and the measurement is repeated once on those forms; the
+    # line then says so (`fallback_taken`, `library_message`) -- a slower honest number instead of none.  A give-up during warm-up
+    # leaves the same trace (a "warning:" text) and is flagged the same way.  A second failure is fatal.
+    fallback_note = None
+    if args.inject_give_up:
+        model.ctx.check(lib.gsttaco_debug_raise_handoff_error(handle, 1 << 16))
+    elapsed, out = timed_run()
+    try:
+        model.synchronize()
+    except Exception as e:                          # GstTacoError: a hand-off gave up inside the run just timed
+        if world > 1:
+            raise
+        fallback_note = "first timed run discarded: " + str(e)
+        elapsed, out = timed_run()
+        model.synchronize()
     lib_message = model.last_message()
-    if "warning" in lib_message:
-        raise SystemExit("bench.py: the library fell back from its default launch forms during this run: " + lib_message)
+    fallback_taken = fallback_note is not None or "warning" in lib_message
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -358,7 +374,8 @@ def main():
         model.ctx.check(lib.gsttaco_get_profile(handle, which, ctypes.byref(ms), ctypes.byref(cnt)))
         prof[which] = (ms.value, cnt.value, int(lib.gsttaco_lstm_launch_bytes(handle, which, B)))
     n_steps_dec = model.dims.steps
-    persistent = model.decode_counters()[0] > 0
+    _dc = model.decode_counters()
+    persistent = _dc[0] > 0 and _dc[1] != 0        # (after a give-up the persistent form is off: the timed run was launches)
     if persistent:
         # the whole decode loop ran as ONE persistent launch (csrc/persist_decode.hip): one bracket around it; a decode step is
         # 1 / steps of it.  Algorithmic bytes per step as SURVEY 8(d) defines them (every weight once PER STEP + the activations),
@@ -525,6 +542,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(hp, w, inputs, args.cpu_seconds)
         line["library_message"] = lib_message
+        line["fallback_taken"] = fallback_taken
+        if fallback_note:
+            line["fallback_note"] = fallback_note
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
