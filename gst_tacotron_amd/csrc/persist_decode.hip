@@ -44,7 +44,12 @@ constexpr uint32_t PD_SPIN_MAX = 1u << 20;
                        // requests per poll) 20.5-20.7 us per step, 16 (two per line) 20.4, 8: 20.9-21.2, 1 (all 32 in ONE line, a poll is one
                        // request): 24.2 -- 32 writers and 256 pollers on one line queue at its memory channel
 #endif
-constexpr int PD_F_P = 0, PD_F_C = 32 * 32, PD_CNT3 = 2 * 32 * 32, PD_CNT4 = PD_CNT3 + 256, PD_F_H = PD_CNT4 + 256, PD_CTL_WORDS = PD_F_H + 64 * 32;
+#ifndef PD_NSH
+#define PD_NSH 64      // shards of an arrival counter (a 128-byte line each): arrivals per line = 256 / PD_NSH, lines per poll = PD_NSH.  The 256
+                       // arrival atomics of an all-to-all are served one after the other per line: same-box A/B (profiles/r04_ab.txt) 8 shards
+                       // 20.7-21.1 us per step, 16: 20.4-20.9, 32: 20.0, 64: 19.9-20.3, 128: 19.6-19.9, 256: 19.9-20.1
+#endif
+constexpr int PD_F_P = 0, PD_F_C = 32 * 32, PD_CNT3 = 2 * 32 * 32, PD_CNT4 = PD_CNT3 + PD_NSH * 32, PD_F_H = PD_CNT4 + PD_NSH * 32, PD_CTL_WORDS = PD_F_H + 64 * 32;
 
 __device__ __forceinline__ uint32_t pd_ld_sc1(const uint32_t* p) {
     uint32_t v;
@@ -100,15 +105,26 @@ __device__ __forceinline__ void pd_wait_flags(const PersistDecodeArgs& A, const 
     }
     __syncthreads();
 }
-// sum of the 8 counter shards >= want
+// sum of the PD_NSH counter shards >= want
 __device__ __forceinline__ void pd_wait_count(const PersistDecodeArgs& A, const uint32_t* c, uint32_t want, PdShared* sh) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         uint32_t spins = 0;
         for (;;) {
-            uint32_t v = lane < 8 ? pd_ld_sc1(c + lane * 32) : 0u;
+            uint32_t v;
+            if constexpr (PD_NSH <= 64) {
+                v = lane < PD_NSH ? pd_ld_sc1(c + lane * 32) : 0u;
+            } else {                                    // several shards per lane: all requested, then one wait
+                uint32_t u[PD_NSH > 64 ? PD_NSH / 64 : 1];
 #pragma unroll
-            for (int d = 1; d < 8; d <<= 1) v += __shfl_xor(v, d, 64);
+                for (int k = 0; k < PD_NSH / 64; ++k) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(u[k]) : "v"(c + (lane + 64 * k) * 32) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                v = 0u;
+#pragma unroll
+                for (int k = 0; k < PD_NSH / 64; ++k) { asm volatile("" : "+v"(u[k])); v += u[k]; }
+            }
+#pragma unroll
+            for (int d = 1; d < (PD_NSH < 64 ? PD_NSH : 64); d <<= 1) v += __shfl_xor(v, d, 64);
             if (__builtin_amdgcn_readfirstlane(v) >= want) break;
             if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
             if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
@@ -121,7 +137,7 @@ __device__ __forceinline__ void pd_wait_count(const PersistDecodeArgs& A, const 
 __device__ __forceinline__ void pd_arrive(uint32_t* c) {
     pd_drain();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(c + (blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(c + (blockIdx.x & (PD_NSH - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- GEMM pieces (lean_body.h's arithmetic): wave w owns k-blocks w, w + 8, ... of a blocked A operand [kb][MT][64][4]
