@@ -44,6 +44,11 @@ constexpr uint32_t PD_SPIN_MAX = 1u << 20;
                        // requests per poll) 20.5-20.7 us per step, 16 (two per line) 20.4, 8: 20.9-21.2, 1 (all 32 in ONE line, a poll is one
                        // request): 24.2 -- 32 writers and 256 pollers on one line queue at its memory channel
 #endif
+#ifndef PD_SLEEP_N
+#define PD_SLEEP_N 0   // s_sleep between two polls of a flag / counter wait: 0 (none) 19.5-19.6 us per step, 1 (64 clocks): 20.3, 4: 20.3-20.4 (same-box
+                       // A/B, profiles/r04_ab.txt) -- a poll is one read in flight and a round trip long: the pause only delays the next one
+#endif
+#define PD_SLEEP() do { if (PD_SLEEP_N > 0) __builtin_amdgcn_s_sleep(PD_SLEEP_N); } while (0)
 #ifndef PD_NSH
 #define PD_NSH 64      // shards of an arrival counter (a 128-byte line each): arrivals per line = 256 / PD_NSH, lines per poll = PD_NSH.  The 256
                        // arrival atomics of an all-to-all are served one after the other per line: same-box A/B (profiles/r04_ab.txt) 8 shards
@@ -100,7 +105,7 @@ __device__ __forceinline__ void pd_wait_flags(const PersistDecodeArgs& A, const 
             if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(v >= want))) == 64) break;
             if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
             if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
-            __builtin_amdgcn_s_sleep(1);
+            PD_SLEEP();
         }
     }
     __syncthreads();
@@ -128,7 +133,7 @@ __device__ __forceinline__ void pd_wait_count(const PersistDecodeArgs& A, const 
             if (__builtin_amdgcn_readfirstlane(v) >= want) break;
             if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
             if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
-            __builtin_amdgcn_s_sleep(1);
+            PD_SLEEP();
         }
     }
     __syncthreads();
