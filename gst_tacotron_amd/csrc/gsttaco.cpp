@@ -865,7 +865,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     const bool fuse12_small = fuse_base && !c->lstm_x[0].bf16 && gt_lstm12_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->fuse12_slots[0]);
     const bool fuse12_mc = fuse_base && gt_lstm12_mc_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->fuse12_slots[c->lstm_x[0].bf16 ? 2 : 1]);
     const bool fuse12 = fuse12_small || fuse12_mc;
-    if (fuse12) HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_arrive), (size_t)steps * 256, s));
+    if (fuse12) HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_arrive), (size_t)steps * GT_L12_NSH * 32, s));
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
     // throughput mode: the whole decode's dropout masks and sigmoid noise are generated up front (same Philox streams the
@@ -1067,7 +1067,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                     (layer == 0 ? fa.l1 : fa.l2).hh = layer == 0 ? c->w_h1_h[p] : c->w_h2_h[p];
                 }
             }
-            fa.arrive = c->w_arrive + (size_t)t * 256;
+            fa.arrive = c->w_arrive + (size_t)t * GT_L12_NSH * 32;
             fa.err = c->w_err;
             fa.expect = (uint32_t)(fuse12_mc ? gt_lstm12_mc_grid(H1) : (H1 + 3) / 4) + (c->debug_drop_member >= 0 ? 1u : 0u);
             if (prof) { int rce = prof_begin(0); if (rce) return rce; }
@@ -1974,7 +1974,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     }
     if ((rc = fa(&c->w_part[0], Bp * 4 * c->H1))) return rc;
     if ((rc = fa(&c->w_part[1], Bp * 4 * c->H2))) return rc;
-    if ((rc = dev_alloc(c, (void**)&c->w_arrive, (size_t)S * 256 * sizeof(uint32_t)))) return rc;
+    if ((rc = dev_alloc(c, (void**)&c->w_arrive, (size_t)S * GT_L12_NSH * 32 * sizeof(uint32_t)))) return rc;
     // persistent decode launch (persist_decode.hip): second prenet | context buffer (ping-pong by step parity), prenet-0 granules,
     // the chain workgroups' recurrent halves, control words
     if ((rc = fa(&c->w_xa2, Bp * (c->P1 + c->att)))) return rc;

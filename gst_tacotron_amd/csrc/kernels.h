@@ -99,9 +99,12 @@ struct LstmXArgs {
 };
 bool gt_lstm_x_supported(int nkb);
 // Both cells in one launch with an in-kernel hand-off of h1 (skinny_gemm.hip gt_lstm12_kernel): fp32, batch <= 32.
+#ifndef GT_L12_NSH
+#define GT_L12_NSH 8        // shards (a 128-byte line each) of the fused LSTM launches' arrival counter; GT_L12_NSH * 32 words per decode step
+#endif
 struct Lstm12Args {
     LstmXArgs l1, l2;           // exactly the two launches' arguments (l2.x == l1.h)
-    uint32_t* arrive;           // 8 x 32 words, zero before the launch: per-shard arrival counters of THIS decode step
+    uint32_t* arrive;           // GT_L12_NSH x 32 words, zero before the launch: per-shard arrival counters of THIS decode step
     uint32_t* err;              // host-mapped give-up word
     uint32_t expect;            // arrivals to wait for = the grid size (fault injection: one more, so the wait runs into its bound)
 };

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512) void gt_lstm12_kernel(Lstm12Args P) {
     // arrive first: this workgroup's part of h1 is out once its stores are acknowledged (nothing else is in flight yet)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&P.arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&P.arrive[(blockIdx.x & (GT_L12_NSH - 1)) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ... then everything of layer 2 that does not depend on layer 1 is requested and arrives during the wait
     const float pin = (row < MT * 16) ? A.partial_in[((size_t)tile * MT * 16 + row) * 16 + col] : 0.f;
     const float c_prev = (col < 4 && row < A.M && unit < A.H) ? A.c[(size_t)row * A.H + unit] : 0.f;
@@ -238,9 +238,9 @@ __global__ __launch_bounds__(512) void gt_lstm12_kernel(Lstm12Args P) {
     if (threadIdx.x < 64) {
         uint32_t spins = 0;
         for (;;) {
-            uint32_t v = lane < 8 ? gt_ldu_sc1(P.arrive + lane * 32) : 0u;
+            uint32_t v = lane < GT_L12_NSH ? gt_ldu_sc1(P.arrive + lane * 32) : 0u;
 #pragma unroll
-            for (int d = 1; d < 8; d <<= 1) v += __shfl_xor(v, d, 64);
+            for (int d = 1; d < GT_L12_NSH; d <<= 1) v += __shfl_xor(v, d, 64);
             if (__builtin_amdgcn_readfirstlane(v) >= P.expect) break;
             ++spins;
             if (spins > (1u << 18)) { if (lane == 0) { atomicOr(P.err, 1u); s_abort = 1; } break; }
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512) void gt_lstm12_mc_kernel(Lstm12Args P) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&P.arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&P.arrive[(blockIdx.x & (GT_L12_NSH - 1)) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!job) return;
     LeanW<KPW2, 2, BF16> W2;
     gt_lean_mc_load_w<NW, KPW2, 2, BF16, false>(P.l2.wp, tile0, ntile, (P.l2.nkb + 1) >> 1, W2);
@@ -404,9 +404,9 @@ __global__ __launch_bounds__(512) void gt_lstm12_mc_kernel(Lstm12Args P) {
     if (threadIdx.x < 64) {
         uint32_t spins = 0;
         for (;;) {
-            uint32_t v = lane < 8 ? gt_ldu_sc1(P.arrive + lane * 32) : 0u;
+            uint32_t v = lane < GT_L12_NSH ? gt_ldu_sc1(P.arrive + lane * 32) : 0u;
 #pragma unroll
-            for (int d = 1; d < 8; d <<= 1) v += __shfl_xor(v, d, 64);
+            for (int d = 1; d < GT_L12_NSH; d <<= 1) v += __shfl_xor(v, d, 64);
             if (__builtin_amdgcn_readfirstlane(v) >= P.expect) break;
             ++spins;
             if (spins > (1u << 18)) { if (lane == 0) { atomicOr(P.err, 1u); s_abort = 1; } break; }
