@@ -33,9 +33,10 @@ from gst_tacotron_amd.model import GST_Tacotron  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}      # dense MFMA peaks (same guide; fp32-input MFMA = 1/16 of bf16)
-# What the matrix pipe SUSTAINS on real data (operands from LDS, every SIMD issuing back to back): the clock drops under its own power draw
-# (fp32: 1.76 GHz; tools/msplit_bench.hip -DGT_MSPLIT_NO_X, tools/mfma_rate.hip, profiles/r04_msplit.txt).  Reported beside `peak`, never in its place.
-MFMA_SUSTAINED_TFLOPS = {"f32": 100.0, "bf16": 1680.0}
+# What a LONG MFMA loop sustains on real data (operands from LDS, every SIMD issuing back to back, the clock as the chip holds it: fp32 2.0-2.36 GHz;
+# tools/msplit_bench.hip <rows> 100, tools/mfma_rate.hip, profiles/r04_msplit.txt).  Reported beside `peak`, never in its place.  (A ~20 us launch
+# reaches two thirds of it: start-up and a clock that has not ramped.)
+MFMA_SUSTAINED_TFLOPS = {"f32": 132.0, "bf16": 1680.0}
 BATCH_PER_GPU = 32
 PROFILE_EVERY = 20             # bracket every 20th decode step's LSTM launches with HIP events
 
@@ -525,7 +526,7 @@ def main():
                                            "launch times / 8 TB/s, or GEMM FLOP / the same time / the dense MFMA peak of the compute "
                                            "dtype, whichever is larger (fp32 MFMA overtakes the weight stream above 32 rows)",
                          "mfma_sustained": {"TFLOP/s": MFMA_SUSTAINED_TFLOPS["bf16" if args.mixed else "f32"],
-                                            "source": "profiles/r04_msplit.txt (tools/msplit_bench.hip, tools/mfma_rate.hip): the dense MFMA pipe of the compute dtype on "
+                                            "source": "profiles/r04_msplit.txt (tools/msplit_bench.hip, tools/mfma_rate.hip): a long MFMA loop of the compute dtype on "
                                                       "random operands, clock as the chip holds it; `peak` and every `frac` use the guide's figure"},
                          "postnet": post,
                          "decode_step": {"us": step_us, "algorithmic_bytes": step_bytes,

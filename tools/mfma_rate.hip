@@ -173,6 +173,60 @@ static void runbf(const char* name, K kern, int nt, float* out, unsigned long lo
     printf("%-44s %7.1f us  %6.1f TFLOP/s  %6.1f ticks per MFMA and wave  (%.0f ticks/us)\n", name, ms * 1e3,
            256.0 * (nt / 64) * iters * 32 * 32768.0 / (ms * 1e-3) * 1e-12, (double)c / (iters * 32.0), (double)c / (ms * 1e3));
 }
+
+// ... the fp32 pipe on RANDOM operands from LDS, both shapes: 16x16x4 reads one A and one B register per 2048 FLOP, 32x32x2 per 4096 FLOP.
+template <int BIG, int NT, int WIDE>
+__global__ __launch_bounds__(NT) void kf32(float* out, int iters, unsigned long long* cyc) {
+    __shared__ __attribute__((aligned(16))) float lds[16384];            // 64 KB
+    for (int i = threadIdx.x; i < 16384; i += NT) {
+        unsigned int h = (unsigned int)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        // WIDE = 0: +-[0.5, 1) (random sign and mantissa, one exponent); 1: the exponent random over 2^-8 .. 2^-1 as well
+        lds[i] = WIDE ? __builtin_bit_cast(float, (0x3B800000u + (((h >> 23) & 7u) << 23)) | (h & 0x807FFFFFu))
+                      : __builtin_bit_cast(float, 0x3F000000u | (h & 0x807FFFFFu));
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4* ap = reinterpret_cast<const float4*>(lds) + lane + wave * 64;
+    const float4* bp = reinterpret_cast<const float4*>(lds) + 2048 + lane;
+    f32x16 accB[4];
+    f32x4 accS[16];
+    for (int c = 0; c < 4; ++c) for (int e = 0; e < 16; ++e) accB[c][e] = 0.f;
+    for (int c = 0; c < 16; ++c) for (int e = 0; e < 4; ++e) accS[c][e] = 0.f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int kb = 0; kb < 16; ++kb) {
+            const float4 a = ap[((kb + it) & 15) * 64 % 1024], b = bp[(kb * 64 + (it & 3) * 16) % 1024];
+            if (BIG) {
+                accB[kb & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, accB[kb & 3], 0, 0, 0);
+                accB[kb & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, accB[kb & 3], 0, 0, 0);
+            } else {
+                accS[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, accS[kb], 0, 0, 0);
+                accS[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, accS[kb], 0, 0, 0);
+                accS[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, accS[kb], 0, 0, 0);
+                accS[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, accS[kb], 0, 0, 0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int c = 0; c < 4; ++c) for (int e = 0; e < 16; ++e) s += accB[c][e];
+    for (int c = 0; c < 16; ++c) for (int e = 0; e < 4; ++e) s += accS[c][e];
+    out[blockIdx.x * NT + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <typename K>
+static void runf32(const char* name, K kern, int nt, double flop_per_iter_wave, float* out, unsigned long long* cyc) {
+    const int iters = 20000;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(nt), 0, 0, out, 10, cyc);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(kern, dim3(256), dim3(nt), 0, 0, out, iters, cyc);
+    CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
+    printf("%-44s %7.1f us  %6.1f TFLOP/s  (%.0f shader clocks per us)\n", name, ms * 1e3, 256.0 * (nt / 64) * iters * flop_per_iter_wave / (ms * 1e-3) * 1e-12, (double)c / (ms * 1e3));
+}
 template <typename K>
 static void run(const char* name, K kern, int nt, int chains, double flop_per_mfma, float* out, unsigned long long* cyc) {
     const int iters = 4000;
@@ -215,5 +269,9 @@ int main() {
     runbf("bf16 32x32x16 from LDS, constant data, 8 waves", kbf16<0, 512>, 512, out, cyc);
     runbf("bf16 32x32x16 from LDS, random data, 8 waves", kbf16<1, 512>, 512, out, cyc);
     runbf("bf16 32x32x16 from LDS, random data, 4 waves", kbf16<1, 256>, 256, out, cyc);
+    runf32("fp32 16x16x4, random sign+mantissa, 8 waves", kf32<0, 512, 0>, 512, 64 * 2048.0, out, cyc);
+    runf32("fp32 32x32x2, random sign+mantissa, 8 waves", kf32<1, 512, 0>, 512, 32 * 4096.0, out, cyc);
+    runf32("fp32 16x16x4, + random exponent, 8 waves", kf32<0, 512, 1>, 512, 64 * 2048.0, out, cyc);
+    runf32("fp32 32x32x2, + random exponent, 8 waves", kf32<1, 512, 1>, 512, 32 * 4096.0, out, cyc);
     return 0;
 }

@@ -16,11 +16,15 @@ __global__ __launch_bounds__(NW * 64) void k_ksplit(LeanPartialArgs A, int mchun
     gt_lean_partial_mc<NW, KPW, 2>(A, 2 * blockIdx.x, 2, 0, mchunks, lds);
 }
 __device__ unsigned long long g_clk[4];
+__device__ int g_reps = 1;        // jobs per workgroup and launch (-> how long one launch keeps the matrix pipe busy)
 template <int NWAVES, int ORDER, int NKB, int TPW>
 __global__ __launch_bounds__(NWAVES * 64) void k_msplit(LeanPartialArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    gt_msplit_partial<NWAVES, ORDER, NKB, TPW>(A, 2 * blockIdx.x, 2, 0, A.MT, lds);
+    for (int rep = 0; rep < g_reps; ++rep) {
+        gt_msplit_partial<NWAVES, ORDER, NKB, TPW>(A, 2 * blockIdx.x, 2, 0, A.MT, lds);
+        __syncthreads();
+    }
     if (blockIdx.x == 7 && threadIdx.x == 0) { g_clk[0] = __builtin_amdgcn_s_memtime() - c0; g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
@@ -65,6 +69,9 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msplit<8, 8, 64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msplit<16, 16, 64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     constexpr size_t L8 = LeanLds<8, 2>::kFloats * 4, L16 = LeanLds<16, 2>::kFloats * 4, LM = MSplitLds<64>::kFloats * 4;
+    const int reps = argc > 2 ? atoi(argv[2]) : 1;
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_reps), &reps, sizeof(int)));
+    if (reps > 1) printf("(the M-split launches repeat their job %d times: their 'us per job' lines are per LAUNCH)\n", reps);
     printf("rows %d (%d M-tiles, %d chunks), K = 1024, fp32\n", M, MT, mchunks);
     timeit("K-split, 8 waves x 8 k-blocks (LSTM / projection launches)", [&] { hipLaunchKernelGGL((k_ksplit<8, 8>), dim3(NJOBS), dim3(512), L8, 0, A, mchunks); }, o1, r1);
     timeit("M-split, 8 waves, both tiles per wave, order of 8", [&] { hipLaunchKernelGGL((k_msplit<8, 8, 64, 2>), dim3(NJOBS), dim3(512), LM, 0, A); }, o2, r2);

@@ -1,7 +1,7 @@
 // Batches above 32 rows, M-split form of the decode-step GEMM bodies (gst_tacotron_amd/csrc/lean_body.h has the K-split forms the product
-// runs, and the history).  A TOOL (tools/msplit_bench.hip): bitwise the K-split bodies and not faster -- both sit at ~87 TFLOP/s because the
-// fp32 matrix pipe itself is power-limited there (with the activation loads taken out the pipe is saturated at 1.76 GHz: 100 TFLOP/s;
-// EXPERIMENTS round 4, profiles/r04_msplit.txt).
+// runs, and the history).  A TOOL (tools/msplit_bench.hip): bitwise the K-split bodies and not faster per launch (87 TFLOP/s either way);
+// repeated inside one launch it holds 132 TFLOP/s -- what a ~20 us launch loses is its start-up, not its body (EXPERIMENTS round 4,
+// profiles/r04_msplit.txt).
 //
 // The K-split multi-chunk bodies (gt_lean_mc) split a tile's K over the workgroup's waves and walk the batch in 32-row chunks:
 // per chunk every wave multiplies, spills its partial sums to LDS, waits at a barrier, and the workgroup reduces -- all waves
