@@ -36,7 +36,7 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}      # dense MFMA peaks (same 
 # What a LONG MFMA loop sustains on real data (operands from LDS, every SIMD issuing back to back, the clock as the chip holds it: fp32 2.0-2.36 GHz;
 # tools/msplit_bench.hip <rows> 100, tools/mfma_rate.hip, profiles/r04_msplit.txt).  Reported beside `peak`, never in its place.  (A ~20 us launch
 # reaches two thirds of it: start-up and a clock that has not ramped.)
-MFMA_SUSTAINED_TFLOPS = {"f32": 132.0, "bf16": 1680.0}
+MFMA_SUSTAINED_TFLOPS = {"f32": 132.0, "bf16": 1650.0}
 BATCH_PER_GPU = 32
 PROFILE_EVERY = 20             # bracket every 20th decode step's LSTM launches with HIP events
 
