@@ -700,6 +700,12 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
     __syncthreads();
     for (int t = 0; t < A.steps; ++t) {
         PD_STAMP(0, 0);
+        // (diagnostic: when this workgroup's steps 0, 1, 2, 8, 64, half, 3/4 and last begin -- slots 24..31 of the chain role)
+        if (A.dbg && threadIdx.x == 0 && blockIdx.x == 0) {
+            const int ts[8] = {0, 1, 2, 8, 64, A.steps >> 1, (3 * A.steps) >> 2, A.steps - 1};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (t == ts[k]) A.dbg[24 + k] = __builtin_amdgcn_s_memrealtime();
+        }
         if (live) {
             pd_chain(A, L, R, t, b, sh, p1v);
             if (sh->abort) return;

@@ -25,7 +25,13 @@ legend = {0: "step start", 1: "prenet flags seen", 2: "prenet part multiplied", 
 chain_legend = dict(legend); chain_legend.update({13: "weights requested", 14: "z0 arrived, y0 in LDS"})
 for r in range(3):
     t0 = buf[r * 32]
-    st = sorted((buf[r * 32 + i], i) for i in range(1, 32) if buf[r * 32 + i])
+    st = sorted((buf[r * 32 + i], i) for i in range(1, 24 if r == 0 else 32) if buf[r * 32 + i])
     lg = chain_legend if r == 0 else legend
     print(names[r], "(us since its step start):", ", ".join("[%d %s] %.2f" % (i, lg.get(i, ""), (v - t0) / 100.0) for v, i in st))
 print("step starts relative to chain WG 0's (us): proj %.2f plain %.2f" % ((buf[32] - buf[0]) / 100.0, (buf[64] - buf[0]) / 100.0))
+steps = 500
+ts = [0, 1, 2, 8, 64, steps >> 1, (3 * steps) >> 2, steps - 1]
+tv = [buf[24 + k] for k in range(8)]
+print("chain WG 0, average step period between the stamped steps (us):",
+      ", ".join("steps %d..%d: %.2f" % (ts[k], ts[k + 1], (tv[k + 1] - tv[k]) / 100.0 / (ts[k + 1] - ts[k])) for k in range(7)),
+      "| first stamped step start -> last: %.1f us" % ((tv[7] - tv[0]) / 100.0))
