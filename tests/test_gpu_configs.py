@@ -454,3 +454,89 @@ def test_several_contexts_on_several_streams_all_keep_the_persistent_bilstm():
             res.append(many[i % 4].Inference_Step(tokens2, None, None, mels2, ml2, seed=7, steps=12)[0])
     torch.cuda.synchronize()
     assert all(np.array_equal(r.cpu().numpy(), ref_mel) for r in res)
+
+
+def test_persistent_decode_launch_under_a_foreign_gemm_stream():
+    """Co-residency under load (tools/foreign_load.py as a test): a second stream keeps the GPU busy with large GEMMs of another
+    library while three headline-shaped Inference_Steps run on the persistent decode launch, whose 256 workgroups must all be
+    resident.  Every call either completes or gives up within its bound, is reported by ``synchronize`` and repeated on the launch
+    forms: never a hang, never a silently wrong result."""
+    import gc
+    import threading
+    import time
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    from gst_tacotron_amd.capi import GstTacoError
+    gc.collect()
+    hp, inputs = synthetic.config_inputs("cfg2", batch=32)
+    w = weights.synthetic_weights(hp, seed=0)
+    m = _model(hp, w, 32, 128, 257)
+    args = (inputs["tokens"], None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"])
+    ref = [t.cpu().numpy() for t in m.Inference_Step(*args, seed=7) if t is not None]
+    m.synchronize()
+    assert m.decode_counters() == (1, 1)
+    stop = threading.Event()
+    side = torch.cuda.Stream()
+
+    def foreign():
+        a = torch.randn(8192, 8192, device="cuda")
+        b = torch.randn(8192, 8192, device="cuda")
+        with torch.cuda.stream(side):
+            while not stop.is_set():
+                for _ in range(4):
+                    a @ b
+                side.synchronize()
+
+    th = threading.Thread(target=foreign)
+    th.start()
+    try:
+        time.sleep(0.5)
+        gave_up = 0
+        t0 = time.perf_counter()
+        for i in range(3):
+            try:
+                out = m.Inference_Step(*args, seed=7)
+                m.synchronize()
+            except GstTacoError as e:
+                assert "gave up" in str(e)
+                gave_up += 1
+                out = m.Inference_Step(*args, seed=7)
+                m.synchronize()
+            for a, b in zip([t for t in out if t is not None], ref):
+                assert np.array_equal(a.cpu().numpy(), b), "wrong result under foreign load"
+        dt = time.perf_counter() - t0
+    finally:
+        stop.set()
+        th.join()
+    print("3 calls under a foreign GEMM stream: give-ups", gave_up, "persistent launches", m.decode_counters(), "seconds %.2f" % dt)
+    assert gave_up <= 1 and dt < 60.0        # (after a give-up the context stays on the launch forms)
+    assert m.handoff_error() == 0
+
+
+def test_persistent_decode_launch_2000_steps_bitwise_the_launches(monkeypatch):
+    """A slice of tools/fused_stress.py --persist as a test: four headline-shaped Inference_Steps (4 x 500 decode steps = 2 000
+    steps, ~10 000 all-to-all hand-offs among 256 workgroups, throughput-mode randomness, a new seed per call) on the persistent
+    decode launch against the launch path, bitwise.  A stale word in any hand-off would show up as a difference."""
+    import gc
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    hp, inputs = synthetic.config_inputs("cfg2", batch=32)
+    w = weights.synthetic_weights(hp, seed=0)
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GSTTACO_PERSIST_DECODE", flag)
+        gc.collect()
+        m = _model(hp, w, 32, 128, 257)
+        res = []
+        for i in range(4):
+            mel, stop, _, align = m.Inference_Step(inputs["tokens"], None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"], seed=100 + i)
+            res.append((mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy()))
+        m.synchronize()
+        assert m.handoff_error() == 0
+        assert m.decode_counters() == ((1, 1) if flag == "1" else (0, 0))      # (enqueued once, then the captured graph is replayed)
+        outs[flag] = res
+        del m
+    for a, b in zip(outs["0"], outs["1"]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert not np.array_equal(outs["1"][0][0], outs["1"][1][0])                 # (the seeds did change the trajectories)

@@ -20,12 +20,26 @@ def _model(hp, w, B, Tv, Tref1):
     return m
 
 
+def _sole_context():
+    """The persistent decode launch is taken only while the process has ONE live context: drop what earlier tests left behind."""
+    import gc
+    gc.collect()
+
+
+def _assert_persistent_decode(m, calls=1):
+    """The test means the persistent decode launch (csrc/persist_decode.hip): fail, do not fall back silently to the launch path."""
+    n, on = m.decode_counters()
+    assert on == 1 and n >= calls, ("the persistent decode launch was not taken", n, on, m.last_message())
+    assert m.handoff_error() == 0
+
+
 def _run_case(name, **kw):
     import torch
     hp, w, g = load_golden(name)
     B, Tv = g["tokens"].shape
     gst = bool(hp["GST"]["Use"])
     Tref1 = g["mels_for_gst"].shape[1] if gst else 0
+    _sole_context()
     m = _model(hp, w, B, Tv, Tref1)
     out = m.Inference_Step(
         g["tokens"], g["token_lengths"], None,
@@ -34,6 +48,8 @@ def _run_case(name, **kw):
     torch.cuda.synchronize()
     mel, stop, spec, align, pre = out
     assert (spec is None) == (not kw.get("with_vocoder"))
+    if name.startswith("full_"):        # the reference's decoder sizes, <= 32 utterances, <= 256 tokens: the persistent decode launch
+        _assert_persistent_decode(m)
     if spec is not None:
         g = dict(g); g["_spec"] = spec.cpu().numpy()
     return g, mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy(), pre.cpu().numpy(), m
@@ -173,12 +189,19 @@ def test_front_end_variants_match_oracle(monkeypatch, env, att):
     from oracle import oracle_np
     for k, v in env.items():
         monkeypatch.setenv(k, v)
+    persistent = env == {"GSTTACO_FUSED_FRONT": "2"}
     for B in (5, 32):
         steps, Tv, Tref = 40, 48, 80
         hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=71 + B, att=att)
+        m = None
+        _sole_context()
         m = _model(hp, w, B, Tv, Tref + 1)
         mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps)
         torch.cuda.synchronize()
+        if persistent:
+            _assert_persistent_decode(m)
+        else:
+            assert m.decode_counters()[0] == 0
         ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
         assert np.abs(mel.cpu().numpy() - ref[0]).max() <= TOL
         assert np.abs(stop.cpu().numpy() - ref[1]).max() <= TOL
@@ -192,6 +215,8 @@ def test_front_end_variants_match_oracle(monkeypatch, env, att):
                                         steps=steps, dt=np.float64)
         assert np.abs(mel2.cpu().numpy() - ref2[0]).max() <= TOL
         assert np.abs(align2.cpu().numpy() - ref2[3]).max() <= TOL
+        if persistent:
+            _assert_persistent_decode(m, 2)
 
 
 @pytest.mark.parametrize("mixed,B", [(False, 5), (True, 5), (False, 37), (True, 37), (False, 65), (True, 65), (False, 128), (True, 128)])
@@ -414,9 +439,11 @@ def test_long_trajectory_matches_oracle():
     from oracle import oracle_np
     B, Tv, Tref, steps = 2, 48, 100, 500
     hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=51)
+    _sole_context()
     m = _model(hp, w, B, Tv, Tref + 1)
     mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise)
-    torch.cuda.synchronize()
+    m.synchronize()
+    _assert_persistent_decode(m)        # (ONE launch runs all 500 steps: the form the headline number is measured on)
     t0 = time.time()
     ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, dt=np.float64)
     print("oracle: %.1f s" % (time.time() - t0))
@@ -439,10 +466,12 @@ def test_full_size_batch_independence_and_invariants():
     w = weights.synthetic_weights(hp, seed=0)
     rng = np.random.default_rng(77)
     masks, noise = synthetic.make_randomness(rng, 500, 32, 128, [256, 256])
+    _sole_context()
     m = _model(hp, w, 32, 128, 257)
     mel, stop, _, align = m.Inference_Step(inputs["tokens"], None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"],
                                            prenet_masks=masks, attn_noise=noise)
-    torch.cuda.synchronize()
+    m.synchronize()
+    _assert_persistent_decode(m)
     mel, align = mel.cpu().numpy(), align.cpu().numpy()
     assert mel.shape == (32, 1000, 80) and stop.shape == (32, 500) and align.shape == (32, 500, 128)
     assert np.isfinite(mel).all()
@@ -456,6 +485,31 @@ def test_full_size_batch_independence_and_invariants():
         torch.cuda.synchronize()
         assert np.abs(one[0].cpu().numpy()[0] - mel[b]).max() <= TOL
         assert np.abs(one[3].cpu().numpy()[0] - align[b]).max() <= TOL
+    m.synchronize()
+    _assert_persistent_decode(m, 2)      # (batch 32 and batch 1: two shapes, one persistent launch each)
+
+
+@pytest.mark.parametrize("att", ["SMA", "BMA"])
+def test_headline_tile_shape_on_the_persistent_launch_matches_oracle(att):
+    """The persistent decode launch at the tile shape the headline number is measured on -- 32 utterances (two M-tiles), 128 tokens
+    (the whole processed-memory tile in LDS) -- against the float64 oracle over 64 steps with injected keep masks and noise, the
+    persistent path asserted (the bitwise test against the launch path covers the same shape; this is the oracle's word on it)."""
+    import time
+    import torch
+    from oracle import oracle_np
+    B, Tv, Tref, steps = 32, 128, 90, 64
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=88, att=att)
+    _sole_context()
+    m = _model(hp, w, B, Tv, Tref + 1)
+    mel, stop, _, align = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps)
+    m.synchronize()
+    _assert_persistent_decode(m)
+    t0 = time.time()
+    ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
+    print("oracle: %.1f s" % (time.time() - t0))
+    errs = (np.abs(mel.cpu().numpy() - ref[0]).max(), np.abs(stop.cpu().numpy() - ref[1]).max(), np.abs(align.cpu().numpy() - ref[3]).max())
+    print("B 32 x T_v 128 x 64 steps on the persistent launch vs oracle: mel %.3g stop %.3g alignment %.3g" % errs)
+    assert max(errs) <= TOL
 
 
 def test_error_behaviour_on_gpu():
