@@ -124,15 +124,18 @@ struct gsttaco_ctx {
     PackedLinear prenet0, prenet1, query, val_gst, lstm0, lstm1, proj;
     PackedLinear lstm_x[2], lstm_h[2];   // split packs: input half (critical path) / recurrent half + bias (front-kernel workers)
     float* w_part[2] = {nullptr, nullptr};
-    uint32_t* w_err = nullptr;   // device alias of h_err: [0] fused decode-LSTM launch, [1] persistent BiLSTM give-up word
+    uint32_t* w_err = nullptr;   // device alias of h_err: give-up words of [0] the fused decode-LSTM launch, [1] the persistent BiLSTM, [2] the persistent decode launch
     uint32_t* h_err = nullptr;
-    uint32_t gave_up = 0;        // sticky: give-ups seen by a later enqueue and not yet reported by gsttaco_synchronize (bit 0 / 1 as h_err)
+    uint32_t gave_up = 0;        // sticky: give-ups seen by a later enqueue and not yet reported by gsttaco_synchronize (bit i = word i of h_err)
     bool announce_warn = false;  // the next compute call leaves `warn` in gsttaco_last_error
     bool persist_decode = true;  // the whole decode loop as ONE persistent launch where it applies (GSTTACO_PERSIST_DECODE=0: launches)
     bool persist_now = false;    // ... for the call being enqueued (one live context, as fuse12_now)
+    int persist_rows = 128;      // ... for batches up to this many rows (GSTTACO_PERSIST_ROWS; 32: the one-group kernel only)
+    int persist_split16 = 0;     // GSTTACO_PERSIST_SPLIT16=1: 17..32 rows as two groups of 16 through the group kernel (experiment)
     int persist_slots = 0;       // workgroups of gt_persist_decode_kernel the device holds at once
     uint64_t n_persist_decodes = 0;      // persistent decode launches enqueued (eagerly or into a captured graph)
     float* w_xa2 = nullptr; uint2* w_z0g = nullptr; float* w_hpart = nullptr; uint32_t* w_pctl = nullptr;    // its workspace
+    float* w_stash = nullptr;
     int fuse12_slots[3] = {0, 0, 0};    // workgroups of gt_lstm12_kernel / gt_lstm12_mc_kernel fp32 / bf16 the device holds at once (occupancy x CUs)
     bool counted = false;        // this context is included in g_live_contexts
     uint64_t n_persist_enqueued = 0;     // persistent BiLSTM launches enqueued (eagerly or into a captured graph)
@@ -906,7 +909,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
                           c->worker_tiles == 2 && c->co_worker_tiles == 1 && g.att_type != GSTTACO_ATT_LSA &&
                           gt_dec_front_supported(mel, P0, P1, att, Tv) && c->lstm_x[0].nkb == 24 && c->lstm_x[1].nkb == 64 && c->lstm_h[0].nkb == 64 &&
                           c->lstm_h[1].nkb == 64 &&
-                          gt_persist_decode_supported(mel, r, P0, P1, att, H1, H2, B, Tv, c->proj_z.ntiles, c->proj_z.nkb, c->persist_slots);
+                          B <= c->persist_rows &&
+                          gt_persist_decode_supported(mel, r, P0, P1, att, H1, H2, B, Tv, c->proj_z.ntiles, c->proj_z.nkb, c->persist_slots, c->persist_split16);
         const bool hashed = !injected_mask && g.prenet_rate == 0.5f && c->keep_hash;
         if (base && (g.prenet_rate == 0.f || hashed || has_mask) && (g.sigmoid_noise == 0.f || has_noise)) {
             PersistDecodeArgs a{};
@@ -923,14 +927,15 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             a.keep_hash = hashed ? 1 : 0; a.att_type = g.att_type;
             a.xa[0] = c->w_xa; a.xa[1] = c->w_xa2;
             a.h1[0] = c->w_h1[0]; a.h1[1] = c->w_h1[1]; a.h2[0] = c->w_h2[0]; a.h2[1] = c->w_h2[1];
-            a.z0g = c->w_z0g; a.hpart = c->w_hpart; a.ctl = c->w_pctl; a.err = c->w_err;
+            a.stash = c->w_stash;
+            a.z0g = c->w_z0g; a.hpart = c->w_hpart; a.ctl = c->w_pctl; a.err = c->w_err + 2;        // (its own give-up word)
             a.pre = c->w_pre; a.ld_pre = ld_pre; a.stop = c->w_stop; a.align = c->w_align; a.ld_align = (int64_t)steps * Tv;
             a.B = B; a.MT = MT; a.Tv = Tv; a.steps = steps; a.co_tiles = co_tiles;
             a.expect_extra = c->debug_drop_member >= 0 ? 1 : 0;
             a.dbg = c->stamps ? c->w_dbg : nullptr;
             const bool prof = c->prof_every > 0;
             if (prof) { int rce = prof_begin(2); if (rce) return rce; }
-            HIPCHECK(c, gt_launch_persist_decode(a, c->pb0, s));
+            HIPCHECK(c, gt_launch_persist_decode(a, c->pb0, c->persist_split16, s));
             if (prof) { int rce = prof_end(2); if (rce) return rce; }
             ++c->n_persist_decodes;
             if (c->prof_every > 0)
@@ -1412,9 +1417,11 @@ int run_cached_inner(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in,
 //     gsttaco_synchronize clears it behind the stream synchronisation.
 void note_give_up(gsttaco_ctx* c) {
     if (!c->h_err) return;
-    if (c->h_err[0]) {          // word 0: bit 0 the fused decode-LSTM launch's hand-off, bit 1 the persistent decode launch's
-        c->gave_up |= 1u;
-        if ((c->h_err[0] & 2u) && c->persist_decode) {
+    // (one word per launch form: a kernel polls its own word to leave early once a sibling has given up, so a give-up of the persistent
+    // decode launch must not make the fused LSTM launches enqueued behind it abort)
+    if (c->h_err[2]) {
+        c->gave_up |= 4u;
+        if (c->persist_decode) {
             c->persist_decode = false;
             c->debug_drop_member = -1;
             c->warn = "warning: a hand-off wait of the persistent decode launch gave up in an earlier call (its workgroups were not co-resident: "
@@ -1422,7 +1429,10 @@ void note_give_up(gsttaco_ctx* c) {
                       "loop as launches per step (bitwise the same results, ~25 % slower)";
             c->announce_warn = true;
         }
-        if ((c->h_err[0] & 1u) && c->fuse12) {
+    }
+    if (c->h_err[0]) {
+        c->gave_up |= 1u;
+        if (c->fuse12) {
             c->fuse12 = false;
             c->debug_drop_member = -1;
             c->warn = "warning: the in-kernel hand-off of the fused decode-LSTM launch gave up in an earlier call (its workgroups were not "
@@ -1624,6 +1634,8 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->bilstm_persist = env_int("GSTTACO_BILSTM_PERSIST", 1) != 0;
     c->fuse12 = env_int("GSTTACO_FUSED_LSTM", 1) != 0;
     c->persist_decode = env_int("GSTTACO_PERSIST_DECODE", 1) != 0;
+    c->persist_rows = env_int("GSTTACO_PERSIST_ROWS", 128);
+    c->persist_split16 = env_int("GSTTACO_PERSIST_SPLIT16", 0) != 0 ? 1 : 0;
     c->wino = env_int("GSTTACO_WINO", 4);
     if (c->wino != 0 && c->wino != 2) c->wino = 4;      // {0, 2, 4}; any other non-zero value (the old boolean's 1 included) means the default
     c->stamps = env_int("GSTTACO_STAMPS", 0) == 1;
@@ -1979,8 +1991,9 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     // the chain workgroups' recurrent halves, control words
     if ((rc = fa(&c->w_xa2, Bp * (c->P1 + c->att)))) return rc;
     HIPCHECK(c, hipMemset(c->w_xa2, 0, Bp * (c->P1 + c->att) * sizeof(float)));
-    if ((rc = dev_alloc(c, (void**)&c->w_z0g, (size_t)32 * 256 * sizeof(uint2)))) return rc;
+    if ((rc = dev_alloc(c, (void**)&c->w_z0g, std::max<size_t>(32, B) * 256 * sizeof(uint2)))) return rc;
     if ((rc = fa(&c->w_hpart, (size_t)2 * 32 * 512))) return rc;
+    if (B > 16 && (rc = fa(&c->w_stash, (size_t)256 * 16 * 512))) return rc;      // (the group kernels: batches above 32 rows, or 17..32 as two groups of 16)
     if ((rc = dev_alloc(c, (void**)&c->w_pctl, gt_persist_decode_ctl_words() * sizeof(uint32_t)))) return rc;
     // the give-up words of the in-kernel hand-offs live in host-mapped memory: the device raises them with a system-scope
     // atomic (failure path only), the host reads them without a synchronisation at the start of the next call
@@ -2262,10 +2275,11 @@ int gsttaco_synchronize(gsttaco_ctx* c, void* stream) {
     if (c->gave_up) {
         // the ONLY place the give-up words are cleared: behind the synchronisation, nothing of this context polls them any more
         c->gave_up = 0;
-        c->h_err[0] = 0; c->h_err[1] = 0;
-        return fail(c, GSTTACO_E_HIP, "a hand-off wait of the persistent BiLSTM launch / the fused decode-LSTM launch gave up (its members were not co-resident: is another process or "
-                                      "a CU mask sharing this GPU?): the outputs of the calls since the last gsttaco_synchronize are invalid.  Repeat "
-                                      "them: the context now uses one launch per time step / two launches per decode step");
+        c->h_err[0] = 0; c->h_err[1] = 0; c->h_err[2] = 0;
+        return fail(c, GSTTACO_E_HIP, "a hand-off wait of the persistent decode launch / the persistent BiLSTM launch / the fused decode-LSTM launch gave up (its workgroups "
+                                      "were not co-resident: is another process or a CU mask sharing this GPU?): the outputs of the calls since the last "
+                                      "gsttaco_synchronize are invalid.  Repeat them: the context now uses the next launch form down (launches per decode step / "
+                                      "one launch per BiLSTM time step / two launches for the two LSTM cells)");
     }
     return 0;
 }
@@ -2356,7 +2370,7 @@ int gsttaco_debug_handoff_error(gsttaco_ctx* c, uint32_t* host_out) {
     if (!c || !host_out || !c->w_err) return GSTTACO_E_INVALID;
     HIPCHECK(c, hipDeviceSynchronize());
     // pending = raised by a kernel or noted by a later enqueue, and not yet reported by gsttaco_synchronize
-    *host_out = (c->h_err[0] | (c->gave_up & 1u)) | ((c->h_err[1] | ((c->gave_up >> 1) & 1u)) << 8);
+    *host_out = (c->h_err[0] | (c->gave_up & 1u)) | ((c->h_err[1] | ((c->gave_up >> 1) & 1u)) << 8) | ((c->h_err[2] | ((c->gave_up >> 2) & 1u)) << 16);
     return 0;
 }
 
@@ -2371,7 +2385,8 @@ int gsttaco_debug_counters(const gsttaco_ctx* c, uint64_t out[4]) {
 
 int gsttaco_debug_raise_handoff_error(gsttaco_ctx* c, uint32_t bits) {
     if (!c || !c->h_err) return GSTTACO_E_INVALID;
-    c->h_err[0] |= bits & 0xFFu;
+    c->h_err[0] |= bits & 0x7Fu;
+    c->h_err[2] |= (bits >> 7) & 1u;          // (bit 7: the persistent decode launch's word)
     c->h_err[1] |= (bits >> 8) & 0xFFu;
     if (bits >> 16) {               // fault injection for real: member (bits >> 16) - 1 of every group of the NEXT persistent launches exits
         c->debug_drop_member = (int)(bits >> 16) - 1;                // at once, so the launch's waits run into their bound

@@ -295,7 +295,7 @@ hipError_t gt_dec_front_init();
 hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t stream);
 
 // ---------------------------------------------------------------- persist_decode.hip
-// The whole decoder loop as ONE persistent launch (batch <= 32, T_v <= 128, fp32, the reference's decoder sizes): see the file.
+// The whole decoder loop as ONE persistent launch (batch <= 128, T_v <= 256, fp32, the reference's decoder sizes): see the file.
 struct PersistDecodeArgs {
     // weights: the launch path's packs (MFMA-fragment order [tile][k-block][lane][4])
     const float *w1x, *w1h, *b1h, *w2x, *w2h, *b2h;   // lstm_x[l].wp / lstm_h[l].wp / lstm_h[l].bias
@@ -312,23 +312,26 @@ struct PersistDecodeArgs {
     // state / workspace
     float* xa[2];                                      // blocked [24][MT][256], ping-pong by step parity
     float* h1[2]; float* h2[2];                        // blocked [64][MT][256]
-    uint2* z0g;                                        // [32][256] {value bits, step tag}
+    uint2* z0g;                                        // [B][256] {value bits, step tag}
     float* hpart;                                      // [2][32][512] recurrent halves of the chain workgroups' tiles
+    float* stash;                                      // [256][16][512] the group kernels' chain workgroups park their tile state here during the chain
     uint32_t* ctl;                                     // gt_persist_decode_ctl_words() words, zeroed by the launcher
-    uint32_t* err;                                     // host-mapped give-up word (shared with the fused LSTM launch)
+    uint32_t* err;                                     // host-mapped give-up word of this launch
     // outputs
     float* pre; int64_t ld_pre;                        // [B][steps*r*mel]
     float* stop;                                       // [B][steps]
     float* align; int64_t ld_align;                    // [B][steps][Tv]
     int B, MT, Tv, steps, co_tiles;                    // co_tiles: layer-2 tiles whose recurrent half the launch path sums in 8-wave order
+    int G, n_chain, tvp;                               // filled in by the launcher: groups of rows, chain workgroups, T_v rounded up to 64
     int expect_extra;                                  // fault injection (tests): the all-to-all waits expect this many arrivals too many
     unsigned long long* dbg;                           // diagnostic stamps [3 roles][32] or NULL (GSTTACO_STAMPS=1)
 };
 size_t gt_persist_decode_ctl_words();
-bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots);
+bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots, int split16);
+int gt_persist_decode_max_batch();
 hipError_t gt_persist_decode_init();                   // opt in to > 64 KiB dynamic LDS; once, outside stream capture
 int gt_persist_decode_blocks_per_cu();
-hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a, const float* b0, hipStream_t stream);
+hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a, const float* b0, int split16, hipStream_t stream);
 
 // ---------------------------------------------------------------- gst.hip
 struct Conv2dArgs {

@@ -34,7 +34,8 @@
 namespace {
 
 constexpr int PD_NT = 512, PD_NW = 8, PD_NWG = 256, PD_UTT = 32, PD_HELP = 64;
-constexpr int PD_P = 256, PD_A = 128, PD_H = 1024, PD_TV = 128, PD_LDV = PD_A + 4;
+constexpr int PD_P = 256, PD_A = 128, PD_H = 1024, PD_TVMAX = 256, PD_LDV = PD_A + 4;
+constexpr int PD_GMAX = 4, PD_BMAX = 32 * PD_GMAX;     // groups of up to 32 rows through one set of resident weights (the _g kernels below)
 constexpr int PD_KBP = PD_P / 16, PD_KBC = PD_A / 16, PD_KBH = PD_H / 16, PD_KBPJ = PD_KBH + PD_KBC;
 constexpr uint32_t PD_SPIN_MAX = 1u << 20;
 
@@ -54,7 +55,9 @@ constexpr uint32_t PD_SPIN_MAX = 1u << 20;
                        // arrival atomics of an all-to-all are served one after the other per line: same-box A/B (profiles/r04_ab.txt) 8 shards
                        // 20.7-21.1 us per step, 16: 20.4-20.9, 32: 20.0, 64: 19.9-20.3, 128: 19.6-19.9, 256: 19.9-20.1
 #endif
-constexpr int PD_F_P = 0, PD_F_C = 32 * 32, PD_CNT3 = 2 * 32 * 32, PD_CNT4 = PD_CNT3 + PD_NSH * 32, PD_F_H = PD_CNT4 + PD_NSH * 32, PD_CTL_WORDS = PD_F_H + 64 * 32;
+// (per utterance: a prenet flag and a context flag; per group of rows: the two arrival counters; per chain tile: two helper flags)
+constexpr int PD_F_P = 0, PD_F_C = PD_BMAX * 32, PD_CNT3 = 2 * PD_BMAX * 32, PD_CNT4 = PD_CNT3 + PD_GMAX * PD_NSH * 32,
+              PD_F_H = PD_CNT4 + PD_GMAX * PD_NSH * 32, PD_CTL_WORDS = PD_F_H + 64 * 32;
 
 __device__ __forceinline__ uint32_t pd_ld_sc1(const uint32_t* p) {
     uint32_t v;
@@ -85,13 +88,13 @@ struct PdShared { int abort; };
 // the middle step, slot = role * 32 + index (100 MHz ticks)
 #define PD_STAMP(role, slot)                                                                                              \
     do {                                                                                                                  \
-        if (A.dbg && t == (A.steps >> 1) && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == PD_UTT || blockIdx.x == PD_NWG - 1)) \
+        if (A.dbg && t == (A.steps >> 1) && threadIdx.x == 0 && (blockIdx.x == 0 || (int)blockIdx.x == A.n_chain || blockIdx.x == PD_NWG - 1)) \
             A.dbg[(role) * 32 + (slot)] = __builtin_amdgcn_s_memrealtime();                                                 \
     } while (0)
 
 // ---- bounded waits: one wave polls (ONE read in flight), the workgroup joins behind a barrier
 __device__ __forceinline__ void pd_give_up(const PersistDecodeArgs& A, PdShared* sh, bool raise) {
-    if (raise) atomicOr(A.err, 2u);         // (word 0 of the context's give-up words: bit 0 the fused LSTM launch, bit 1 this kernel)
+    if (raise) atomicOr(A.err, 1u);         // (this launch's OWN give-up word: the fused LSTM launches poll theirs on any bit)
     sh->abort = 1;
 }
 // flags [n] (a line each) all >= want
@@ -160,6 +163,20 @@ __device__ __forceinline__ void pd_xload(const float* base, int MT, float4 (&x0)
         x1[i] = gt_bload4_sc1(rs, (uint32_t)lane * 16u, so + m1);
     }
 }
+// the same for group g of MTG M-tiles (M-tiles MTG g, MTG g + 1; MTG == 1: only x0)
+template <int MTG, int I0, int I1, int NB>
+__device__ __forceinline__ void pd_g_xload(const float* base, int MT, int g, float4 (&x0)[NB], float4 (&x1)[NB]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto rs = gt_rsrc(base, 0x7FFFF000u);
+    const uint32_t m0 = (uint32_t)(MTG * g) * 1024u, m1 = (uint32_t)min(MTG * g + 1, MT - 1) * 1024u;
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        const uint32_t so = (uint32_t)((wave + i * PD_NW) * MT) * 1024u;
+        x0[i] = gt_bload4_sc1(rs, (uint32_t)lane * 16u, so + m0);
+        if (MTG == 2) x1[i] = gt_bload4_sc1(rs, (uint32_t)lane * 16u, so + m1);
+    }
+}
 // b[OFF + i * STRIDE], i < KPW (compile-time indices only: the weight fragments must stay registers)
 template <int KPW, int OFF, int STRIDE, int NB>
 __device__ __forceinline__ void pd_mma(const float4 (&x0)[NB], const float4 (&x1)[NB], const float4 (&b)[NB], f32x4& a0, f32x4& a1) {
@@ -170,6 +187,21 @@ __device__ __forceinline__ void pd_mma(const float4 (&x0)[NB], const float4 (&x1
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].y, b[k].y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[k].y, b[k].y, a1, 0, 0, 0);
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].z, b[k].z, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[k].z, b[k].z, a1, 0, 0, 0);
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].w, b[k].w, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[k].w, b[k].w, a1, 0, 0, 0);
+    }
+}
+template <int MTG, int KPW, int OFF, int STRIDE, int NB>
+__device__ __forceinline__ void pd_g_mma(const float4 (&x0)[NB], const float4 (&x1)[NB], const float4 (&b)[NB], f32x4& a0, f32x4& a1) {
+    if constexpr (MTG == 2) {
+        pd_mma<KPW, OFF, STRIDE, NB>(x0, x1, b, a0, a1);
+    } else {
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int k = OFF + i * STRIDE;
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].x, b[k].x, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].y, b[k].y, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].z, b[k].z, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[k].w, b[k].w, a0, 0, 0, 0);
+        }
     }
 }
 __device__ __forceinline__ void pd_spill(float* lds, int slab, const f32x4& a0, const f32x4& a1) {
@@ -211,12 +243,38 @@ __device__ __forceinline__ float pd_rec_tile(const float4 (&x0)[8], const float4
         return pd_reduce<8>(lds, bias);
     }
 }
+// The same for a group of MTG M-tiles.  TWOPASS: the 16-slab sum through EIGHT slabs -- virtual waves 0..7, then 8..15 onto the running
+// sum: the same sequence of additions (chain workgroups, whose LDS holds the utterance's processed memory).
+template <bool ORDER16, int MTG, bool TWOPASS>
+__device__ __forceinline__ float pd_g_rec_tile(const float4 (&x0)[8], const float4 (&x1)[8], const float4 (&wh)[8], float bias, float* lds) {
+    const int wave = threadIdx.x >> 6;
+    if (ORDER16) {
+        f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+        pd_g_mma<MTG, 4, 0, 2, 8>(x0, x1, wh, a0, a1);
+        pd_g_mma<MTG, 4, 1, 2, 8>(x0, x1, wh, b0, b1);
+        if (TWOPASS) {
+            pd_spill(lds, wave, a0, a1);
+            const float z = pd_reduce<8>(lds, bias);
+            pd_spill(lds, wave, b0, b1);
+            return pd_reduce<8>(lds, z);
+        }
+        pd_spill(lds, wave, a0, a1);
+        pd_spill(lds, wave + 8, b0, b1);
+        return pd_reduce<16>(lds, bias);
+    } else {
+        f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+        pd_g_mma<MTG, 8, 0, 1, 8>(x0, x1, wh, a0, a1);
+        pd_spill(lds, wave, a0, a1);
+        return pd_reduce<8>(lds, bias);
+    }
+}
 // gates of tile-local column g*4+u (i, f, c~, o of unit tile*4+u; Appendix A.6, reference Taco2.py:79-85): lanes col < 4 own a unit;
 // h of the tile's 4 units leaves as ONE 16-byte write-through store per row (rows >= M are never stored)
-__device__ __forceinline__ void pd_gates_store(float z, float& c, float* hdst, int tile, int M, int MT) {
-    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+__device__ __forceinline__ void pd_gates_store(float z, float& c, float* hdst, int tile, int M, int MT, int row0 = 0, int rows = 32) {
+    const int lrow = threadIdx.x >> 4, row = row0 + lrow, col = threadIdx.x & 15;       // (a group: rows row0 .. row0 + rows - 1)
     const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
     float hv = 0.f;
+    if (lrow >= rows) return;               // (16-row groups: the slab's upper half is unused; whole 16-lane segments leave together)
     if (col < 4 && row < M) {
         const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
         c = __builtin_fmaf(gf, c, gi * gg);
@@ -341,9 +399,9 @@ __device__ __forceinline__ float pd_rec1_mem(const PersistDecodeArgs& A, const f
 
 // Projection tile `ptile`, M-tile `pmt` (Taco2.py:112-118: r mel frames | stop logit) + the next step's prenet-0 pre-activations
 // (both layers are linear: gsttaco.cpp proj_z), gt_proj_lean_kernel's arithmetic
-__device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4 (&wp)[9], int t, int ptile, int pmt, float* lds, PdShared* sh) {
+__device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4 (&wp)[9], int t, int ptile, int pmt, float* lds, PdShared* sh, int g = 0) {
     const int par = t & 1, MT = A.MT;
-    pd_wait_count(A, A.ctl + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+    pd_wait_count(A, A.ctl + PD_CNT4 + g * (PD_NSH * 32), (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
     if (sh->abort) return;
     PD_STAMP(1, 9);
     const int lane = threadIdx.x & 63;
@@ -391,19 +449,33 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
 struct PdChainLds {
     float *y0, *y1, *qs, *vs, *sc, *nz, *pv, *al, *ks1, *partial, *red, *tile;
 };
-constexpr int PD_CHAIN_FLOATS = 2 * PD_P + 2 * PD_A + 4 * PD_TV + PD_P + 4096 + 8 * PD_A + PD_TV * PD_LDV;
-constexpr int PD_LDS_FLOATS = 16 * 32 * 17 + PD_CHAIN_FLOATS;
-__device__ __forceinline__ PdChainLds pd_carve(float* base) {
+// LDS of a chain workgroup (floats): [8 reduction slabs of its LSTM tile | small vectors | the utterance's processed memory, tvp rows].
+// The chain's GEMV partials (16 x 256) and the context's row-group sums (8 x 128) ALIAS the slabs: the chain is over (a barrier
+// behind its last LDS read) before the cells spill, and the cells' last reduction ends in a barrier before the next step's chain
+// writes.  tvp = T_v rounded up to the 64 rows of a score pass: 157 KB at 256 tokens -- the CU's 160 KB hold one utterance.
+// The other roles use 16 slabs (the 16-wave summation order of the recurrent halves) and nothing else.
+constexpr int PD_SLAB = 32 * 17;
+constexpr int PD_OTHER_FLOATS = 16 * PD_SLAB + 4 * PD_GMAX * PD_NT;      // (+ the group kernels' projection role: its per-group state)
+__host__ __device__ constexpr int pd_lds_floats(int tvp) {
+    return 8 * PD_SLAB + 3 * PD_P + 2 * PD_A + 4 * tvp + tvp * PD_LDV > PD_OTHER_FLOATS ? 8 * PD_SLAB + 3 * PD_P + 2 * PD_A + 4 * tvp + tvp * PD_LDV : PD_OTHER_FLOATS;
+}
+static_assert(16 * PD_P <= 8 * PD_SLAB && 8 * PD_A <= 8 * PD_SLAB, "the chain's partial sums alias the reduction slabs");
+static_assert(pd_lds_floats(PD_TVMAX) * 4 + 64 <= 160 * 1024, "one utterance's chain state must fit a CU's LDS");
+__device__ __forceinline__ PdChainLds pd_carve(float* smem, int tvp) {
     PdChainLds L;
-    L.y0 = base; L.y1 = L.y0 + PD_P; L.qs = L.y1 + PD_P; L.vs = L.qs + PD_A; L.sc = L.vs + PD_A; L.nz = L.sc + PD_TV; L.pv = L.nz + PD_TV;
-    L.al = L.pv + PD_TV; L.ks1 = L.al + PD_TV; L.partial = L.ks1 + PD_P; L.red = L.partial + 4096; L.tile = L.red + 8 * PD_A;
+    L.partial = smem; L.red = smem;
+    L.y0 = smem + 8 * PD_SLAB; L.y1 = L.y0 + PD_P; L.qs = L.y1 + PD_P; L.vs = L.qs + PD_A; L.sc = L.vs + PD_A; L.nz = L.sc + tvp; L.pv = L.nz + tvp;
+    L.al = L.pv + tvp; L.ks1 = L.al + tvp; L.tile = L.ks1 + PD_P;
     return L;
 }
 
 struct PdChainRegs { float bias1, biasq, sbias; int Tv; uint64_t seed; bool hashed, drop, noisy; };
 
-__device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v) {
-    const int tid = threadIdx.x, lane = tid & 63;
+// HELPED: the workgroup's layer-1 recurrent half comes from a helper workgroup (the one-group kernel) and is fetched here
+// zt: 0, or a per-step opaque zero (the group kernels: nothing of the chain's address arithmetic may be hoisted out of the step loop)
+template <bool HELPED>
+__device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v, int zt = 0) {
+    const int tid = threadIdx.x + zt, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int par = t & 1, Tv = R.Tv, TvFull = A.Tv, MT = A.MT;
     // ---- ALL of prenet-1's weights for this step, requested before the projection's hand-off is even looked at.  Launch-path wave
@@ -526,7 +598,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
         pd_drain();
         if (tid == 0) pd_st1_sc1(A.ctl + PD_F_P + b * PD_FS, (uint32_t)t + 1u);
     }
-    if (t > 0 && tid >= PD_NT - 64) {        // the last wave, meanwhile: this tile's layer-1 recurrent half from its helper must show step t
+    if (HELPED && t > 0 && tid >= PD_NT - 64) {        // the last wave, meanwhile: this tile's layer-1 recurrent half from its helper must show step t
         const int l2 = tid & 63;
         uint32_t spins = 0;
         for (;;) {
@@ -559,7 +631,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
     }
     __syncthreads();
     if (sh->abort) return;
-    if (t > 0) {                                    // (behind the barrier the flag poll joined: the helper's sums, consumed by cell 1)
+    if (HELPED && t > 0) {                          // (behind the barrier the flag poll joined: the helper's sums, consumed by cell 1)
         const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
         const float4 d1 = gt_bload4_sc1(rh, (uint32_t)((b * 512 + (tid & ~3)) * 4), 0u);
         const int e = tid & 3;
@@ -568,9 +640,10 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
     if (tid < PD_A) L.qs[tid] = reduce_partial(L.partial, 32, PD_A, tid) + R.biasq;
     __syncthreads();
     PD_STAMP(0, 17);
-    // ---- scores (Steps.py:126-152): 8 lanes per memory row, 4 x 16-byte pieces each; rows tid / 8 and 64 + tid / 8
+    // ---- scores (Steps.py:126-152): 8 lanes per memory row, 4 x 16-byte pieces each; rows tid / 8, 64 + tid / 8, ... (tvp / 64 passes)
+    const int npass = A.tvp >> 6;
 #pragma unroll 1
-    for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < npass; ++hh) {
         const int row = hh * 64 + (tid >> 3), li = tid & 7;
         f32x2 s2 = {0.f, 0.f};
 #pragma unroll 2
@@ -629,19 +702,27 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
     if (tid < TvFull) A.align[(size_t)b * A.ld_align + (size_t)t * TvFull + tid] = tid < Tv ? L.al[tid] : 0.f;
     // ---- context (Steps.py:160-166): lane = channel, 8 row groups (this thread plays groups tid / 128 and 4 + tid / 128)
     {
+        // (beyond 128 tokens the launch path streams the memory through its 128-row tile and sums the row chunks last to first,
+        // each chunk into its own pair of partial sums: the same order here, where every row is resident)
         const int ca = tid & (PD_A - 1);
+        const int nchunks = (Tv + 127) >> 7;
 #pragma unroll 1
         for (int hh = 0; hh < 2; ++hh) {
             const int cp = hh * 4 + (tid >> 7);
-            float p0 = 0.f, p1 = 0.f;
-            int tt = cp;
-            for (; tt + 8 < Tv; tt += 16) {
-                p0 = __builtin_fmaf(L.al[tt], L.tile[tt * PD_LDV + ca], p0);
-                p1 = __builtin_fmaf(L.al[tt + 8], L.tile[(tt + 8) * PD_LDV + ca], p1);
-            }
-            if (tt < Tv) p0 = __builtin_fmaf(L.al[tt], L.tile[tt * PD_LDV + ca], p0);
             float cacc = 0.f;
-            cacc += p0 + p1;
+            for (int c = nchunks - 1; c >= 0; --c) {
+                const int nr = min(128, Tv - 128 * c);
+                const float* alc = L.al + 128 * c;
+                const float* tl = L.tile + 128 * c * PD_LDV;
+                float p0 = 0.f, p1 = 0.f;
+                int tt = cp;
+                for (; tt + 8 < nr; tt += 16) {
+                    p0 = __builtin_fmaf(alc[tt], tl[tt * PD_LDV + ca], p0);
+                    p1 = __builtin_fmaf(alc[tt + 8], tl[(tt + 8) * PD_LDV + ca], p1);
+                }
+                if (tt < nr) p0 = __builtin_fmaf(alc[tt], tl[tt * PD_LDV + ca], p0);
+                cacc += p0 + p1;
+            }
             L.red[cp * PD_A + ca] = cacc;
         }
     }
@@ -670,7 +751,7 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
 // the roles, not their sum.
 __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* smem, PdShared* sh) {
     float* lds = smem;
-    const PdChainLds L = pd_carve(smem + 16 * 32 * 17);
+    const PdChainLds L = pd_carve(smem, A.tvp);
     const int tile = blockIdx.x, b = blockIdx.x, tid = threadIdx.x, col = tid & 15;
     const bool live = b < A.B;                                  // (batches below 32: the spare chain workgroups only run their LSTM tile)
     // nothing of this tile's LSTM weights stays resident here: the chain's own operands (all of prenet 1's weights, prefetched)
@@ -690,12 +771,12 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
         R.sbias = A.score_bias[0];
         // processed memory of utterance b -> LDS, once (rows >= T_v: zeros, as the launch path's bounded descriptor reads them)
         const float4* src = reinterpret_cast<const float4*>(A.pm + (size_t)b * A.Tv * PD_A);
-        for (int e = tid; e < PD_TV * PD_A / 4; e += PD_NT) {
+        for (int e = tid; e < A.tvp * PD_A / 4; e += PD_NT) {
             const int row = e / (PD_A / 4), c4 = e % (PD_A / 4);
             *reinterpret_cast<float4*>(L.tile + row * PD_LDV + 4 * c4) = row < R.Tv ? src[(size_t)row * (PD_A / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (tid < PD_A) L.vs[tid] = A.av[tid];
-        if (tid < PD_TV) L.pv[tid] = tid == 0 ? 1.f : 0.f;     // one-hot(0) initial alignment (Steps.py:201-206)
+        if (tid < A.tvp) L.pv[tid] = tid == 0 ? 1.f : 0.f;     // one-hot(0) initial alignment (Steps.py:201-206)
     }
     __syncthreads();
     for (int t = 0; t < A.steps; ++t) {
@@ -707,7 +788,7 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
             for (int k = 0; k < 8; ++k) if (t == ts[k]) A.dbg[24 + k] = __builtin_amdgcn_s_memrealtime();
         }
         if (live) {
-            pd_chain(A, L, R, t, b, sh, p1v);
+            pd_chain<true>(A, L, R, t, b, sh, p1v);
             if (sh->abort) return;
         } else if (t > 0) {                                     // no chain to hide it behind: fetch the layer-1 half directly
             pd_wait_flags(A, A.ctl + PD_F_H + tile * 32, 1, (uint32_t)t, sh);
@@ -811,6 +892,246 @@ __global__ __launch_bounds__(PD_NT) void gt_persist_decode_kernel(PersistDecodeA
     }
 }
 
+
+// ====================================================================================================================== groups
+// Batches above 32 rows (and, as an experiment, 32 rows as two groups of 16): G groups of 16 MTG rows go through ONE set of resident
+// weights.  Every workgroup still owns gate tile `blockIdx.x` of both cells and runs each GEMM phase group by group -- the hand-off
+// of group g travels while group g + 1 is multiplied, which is what hides the all-to-all latencies the one-group kernel waits out.
+// Per group the arithmetic is the one-group kernel's (= the launch path's single-chunk bodies', which its multi-chunk bodies
+// reproduce per 32-row chunk): bitwise the launches at any batch.  Roles: workgroup b < B runs utterance b's chain, then its tile for
+// every group with the tile's weights STREAMED (the chain's operands own the registers meanwhile; nobody helps: with one chain per
+// CU on half of the chip there is no idle half to help from); the next pj_tiles x MTG own a projection (tile, M-tile of the group);
+// the rest are plain.  Control: per-group arrival counters, per-utterance flags as before.
+template <int GM> struct PdG { float c1[GM], c2[GM], p1[GM], p2[GM]; };
+
+// `zt`: a per-step opaque zero added into every per-thread global address of these bodies.  Without it the step loop's invariant
+// addresses -- flags, counter shards and state rows of every group and parity: dozens of 64-bit pairs at four groups -- are hoisted
+// out of the loop and live across the chain, which needs the whole register file: they spill, and a scratch reload waits for vmcnt(0).
+#define PD_ZT(zt) int zt = 0; asm volatile("" : "+v"(zt))
+template <int MTG>
+__device__ __forceinline__ void pd_g_cell1_one(const PersistDecodeArgs& A, const float4 (&wx1)[3], int t, int tile, float* lds, float& c1v, float p1v, int g,
+                                               PdShared* sh, int role, int zt) {
+    constexpr int RG = 16 * MTG;
+    const int par = t & 1, MT = A.MT;
+    pd_wait_flags<PD_FS>(A, A.ctl + zt + PD_F_C + RG * g * PD_FS, min(RG, A.B - RG * g), (uint32_t)t + 1u, sh);   // (a chain's context flag follows its prenet flag)
+    if (sh->abort) return;
+    if (g == 0) PD_STAMP(role, 3);
+    float4 x0[3], x1[3];
+    pd_g_xload<MTG, 0, 3, 3>(A.xa[par], MT, g, x0, x1);
+    PD_PIN();
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    pd_g_mma<MTG, 3, 0, 1, 3>(x0, x1, wx1, a0, a1);
+    pd_spill(lds, threadIdx.x >> 6, a0, a1);
+    const float z = pd_reduce<8>(lds, p1v);
+    pd_gates_store(z, c1v, A.h1[par] + zt, tile, A.B, MT, RG * g, RG);
+    if (g == 0) PD_STAMP(role, 4);
+    pd_arrive(A.ctl + zt + PD_CNT3 + g * (PD_NSH * 32));
+}
+
+// REC1: the layer-1 recurrent half for the next step from the same fragments
+template <int MTG, bool REC1, bool TWOPASS>
+__device__ __forceinline__ void pd_g_cell2_one(const PersistDecodeArgs& A, const float4 (&wx2)[8], const float4 (&wh1)[8], int t, int tile, float* lds, float& c2v,
+                                               float p2v, float& p1_next, int g, PdShared* sh, int role, int zt) {
+    constexpr int RG = 16 * MTG;
+    const int par = t & 1, MT = A.MT;
+    pd_wait_count(A, A.ctl + zt + PD_CNT3 + g * (PD_NSH * 32), (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+    if (sh->abort) return;
+    if (g == 0) PD_STAMP(role, 5);
+    float4 x0[8], x1[8];
+    pd_g_xload<MTG, 0, 8, 8>(A.h1[par], MT, g, x0, x1);
+    PD_PIN();
+    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    pd_g_mma<MTG, 8, 0, 1, 8>(x0, x1, wx2, a0, a1);
+    if (g == 0) PD_STAMP(role, 6);
+    pd_spill(lds, threadIdx.x >> 6, a0, a1);
+    const float z = pd_reduce<8>(lds, p2v);
+    pd_gates_store(z, c2v, A.h2[par] + zt, tile, A.B, MT, RG * g, RG);
+    if (g == 0) PD_STAMP(role, 7);
+    pd_arrive(A.ctl + zt + PD_CNT4 + g * (PD_NSH * 32));
+    if (g == 0) PD_STAMP(role, 8);
+    if (REC1) p1_next = pd_g_rec_tile<true, MTG, TWOPASS>(x0, x1, wh1, A.b1h[tile * 16 + (threadIdx.x & 15)], lds);
+}
+
+template <int MTG, bool TWOPASS>
+__device__ __forceinline__ float pd_g_rec1_mem_one(const PersistDecodeArgs& A, const float4 (&wh1)[8], int t, int tile, float* lds, int g) {
+    float4 x0[8], x1[8];
+    pd_g_xload<MTG, 0, 8, 8>(A.h1[t & 1], A.MT, g, x0, x1);
+    PD_PIN();
+    return pd_g_rec_tile<true, MTG, TWOPASS>(x0, x1, wh1, A.b1h[tile * 16 + (threadIdx.x & 15)], lds);
+}
+
+// layer-2 recurrent half for the next step (tiles below co_tiles sum in the projection launch's co-workers' 8-wave order)
+template <int MTG, bool TWOPASS, bool WAIT>
+__device__ __forceinline__ float pd_g_rec2_one(const PersistDecodeArgs& A, const float4 (&wh2)[8], int t, int tile, float* lds, int g, PdShared* sh, int zt) {
+    if (WAIT) {
+        pd_wait_count(A, A.ctl + zt + PD_CNT4 + g * (PD_NSH * 32), (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        if (sh->abort) return 0.f;
+    }
+    float4 x0[8], x1[8];
+    pd_g_xload<MTG, 0, 8, 8>(A.h2[t & 1], A.MT, g, x0, x1);
+    PD_PIN();
+    const float bias = A.b2h[tile * 16 + (threadIdx.x & 15)];
+    return tile < A.co_tiles ? pd_g_rec_tile<false, MTG, TWOPASS>(x0, x1, wh2, bias, lds) : pd_g_rec_tile<true, MTG, TWOPASS>(x0, x1, wh2, bias, lds);
+}
+
+// a tile's four GEMM halves for every group; CHAIN: utterance blockIdx.x's chain first, the tile's weights streamed phase by phase
+template <int GM, int MTG, bool CHAIN>
+__device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float* smem, PdShared* sh) {
+    float* lds = smem;
+    const int tile = blockIdx.x, b = blockIdx.x, tid = threadIdx.x, col = tid & 15;
+    constexpr int role = CHAIN ? 0 : 2;
+    PdW W;
+    PdG<GM> S;
+#pragma unroll
+    for (int g = 0; g < GM; ++g) { S.c1[g] = 0.f; S.c2[g] = 0.f; S.p1[g] = A.b1h[tile * 16 + col]; S.p2[g] = A.b2h[tile * 16 + col]; }
+    PdChainLds L{};
+    PdChainRegs R{};
+    if (CHAIN) {
+        L = pd_carve(smem, A.tvp);
+        R.Tv = A.tok_len ? max(1, min(A.Tv, (int)A.tok_len[b])) : A.Tv;
+        R.drop = A.drop_rate > 0.f;
+        R.hashed = R.drop && A.keep_hash != 0;
+        R.noisy = A.sigmoid_noise > 0.f;
+        R.seed = R.hashed ? *A.seed_ptr : 0ull;
+        R.bias1 = tid < PD_P ? A.b1[tid] : 0.f;
+        R.biasq = tid < PD_A ? A.bq[tid] : 0.f;
+        R.sbias = A.score_bias[0];
+        const float4* src = reinterpret_cast<const float4*>(A.pm + (size_t)b * A.Tv * PD_A);
+        for (int e = tid; e < A.tvp * PD_A / 4; e += PD_NT) {
+            const int row = e / (PD_A / 4), c4 = e % (PD_A / 4);
+            *reinterpret_cast<float4*>(L.tile + row * PD_LDV + 4 * c4) = row < R.Tv ? src[(size_t)row * (PD_A / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < PD_A) L.vs[tid] = A.av[tid];
+        if (tid < A.tvp) L.pv[tid] = tid == 0 ? 1.f : 0.f;
+    } else {
+        pd_load_tile<3>(A.w1x, tile, W.x1); pd_load_tile<8>(A.w2x, tile, W.x2);
+        pd_load_tile<8>(A.w1h, tile, W.h1); pd_load_tile<8>(A.w2h, tile, W.h2);
+    }
+    __syncthreads();
+    // The chain needs the whole register file (all of prenet 1's weights in flight): the tile's per-group state -- cell states,
+    // recurrent halves -- waits in memory meanwhile (its own rows of `stash`, written and re-read by the same thread: L2 hits,
+    // requested back before the first flag wait).  Left in registers it spills to scratch, whose reloads wait for vmcnt(0).
+    for (int t = 0; t < A.steps; ++t) {
+        PD_STAMP(role, 0);
+        PD_ZT(zt);
+        float* st = A.stash + (size_t)blockIdx.x * (4 * GM * PD_NT) + tid + zt;
+        if (CHAIN) {
+#pragma unroll
+            for (int g = 0; g < GM; ++g) {
+                st[(4 * g + 0) * PD_NT] = S.c1[g]; st[(4 * g + 1) * PD_NT] = S.c2[g];
+                st[(4 * g + 2) * PD_NT] = S.p1[g]; st[(4 * g + 3) * PD_NT] = S.p2[g];
+            }
+            PD_PIN();
+            float unused = 0.f;
+            int bs = b;
+            asm volatile("" : "+s"(bs));
+            pd_chain<false>(A, L, R, t, bs, sh, unused, zt);
+            if (sh->abort) return;
+            PD_PIN();
+            pd_load_tile<3>(A.w1x, tile, W.x1);
+#pragma unroll
+            for (int g = 0; g < GM; ++g) {
+                S.c1[g] = st[(4 * g + 0) * PD_NT]; S.c2[g] = st[(4 * g + 1) * PD_NT];
+                S.p1[g] = st[(4 * g + 2) * PD_NT]; S.p2[g] = st[(4 * g + 3) * PD_NT];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GM; ++g)
+            if (g < A.G) {
+                pd_g_cell1_one<MTG>(A, W.x1, t, tile, lds, S.c1[g], S.p1[g], g, sh, role, zt);
+                if (sh->abort) return;
+            }
+        if (CHAIN) { pd_load_tile<8>(A.w2x, tile, W.x2); pd_load_tile<8>(A.w1h, tile, W.h1); }
+#pragma unroll
+        for (int g = 0; g < GM; ++g)
+            if (g < A.G) {
+                pd_g_cell2_one<MTG, true, CHAIN>(A, W.x2, W.h1, t, tile, lds, S.c2[g], S.p2[g], S.p1[g], g, sh, role, zt);
+                if (sh->abort) return;
+            }
+        PD_STAMP(role, 12);
+        if (t + 1 == A.steps) break;
+        if (CHAIN) pd_load_tile<8>(A.w2h, tile, W.h2);
+#pragma unroll
+        for (int g = 0; g < GM; ++g)
+            if (g < A.G) {
+                S.p2[g] = pd_g_rec2_one<MTG, CHAIN, true>(A, W.h2, t, tile, lds, g, sh, zt);
+                if (sh->abort) return;
+            }
+        PD_STAMP(role, 14);
+    }
+}
+
+// a projection (tile, M-tile of the group) + the LSTM tile; the projection of group g - 1 follows cell 2 of group g, so that the
+// chains of the early groups start while the later groups are still in their cells.  Resident: the layer-2 input half and the
+// projection tile; W1x (24 KB) is streamed at the start of every step (it arrives while the workgroup waits for the chains), the
+// recurrent halves' tiles behind the projection as in the one-group kernel; the per-group state (cell states, recurrent halves)
+// lives in LDS behind the slabs -- this role has no chain and the LDS to spare, and not the registers.
+template <int GM, int MTG>
+__device__ __forceinline__ void pd_g_run_proj(const PersistDecodeArgs& A, float* lds, PdShared* sh) {
+    const int tile = blockIdx.x, col = threadIdx.x & 15;
+    const int pi = tile - A.n_chain, ptile = pi % A.pj_tiles, pm = pi / A.pj_tiles;
+    PdW W;
+    pd_load_tile<8>(A.w2x, tile, W.x2);
+    float4 wpj[9];
+    pd_load_tile<9>(A.wp, ptile, wpj);
+    float* sl = lds + 16 * PD_SLAB + threadIdx.x;           // [4 GM][512]: c1, c2, p1, p2 of group g at rows 4 g ..
+#pragma unroll
+    for (int g = 0; g < GM; ++g) { sl[(4 * g + 0) * PD_NT] = 0.f; sl[(4 * g + 1) * PD_NT] = 0.f; sl[(4 * g + 2) * PD_NT] = A.b1h[tile * 16 + col]; sl[(4 * g + 3) * PD_NT] = A.b2h[tile * 16 + col]; }
+    for (int t = 0; t < A.steps; ++t) {
+        PD_STAMP(1, 0);
+        PD_ZT(zt);
+        pd_load_tile<3>(A.w1x, tile, W.x1);
+#pragma unroll
+        for (int g = 0; g < GM; ++g)
+            if (g < A.G) {
+                float c1v = sl[(4 * g + 0) * PD_NT];
+                pd_g_cell1_one<MTG>(A, W.x1, t, tile, lds, c1v, sl[(4 * g + 2) * PD_NT], g, sh, 1, zt);
+                if (sh->abort) return;
+                sl[(4 * g + 0) * PD_NT] = c1v;
+            }
+#pragma unroll
+        for (int g = 0; g < GM; ++g)
+            if (g < A.G) {
+                float unused = 0.f, c2v = sl[(4 * g + 1) * PD_NT];
+                pd_g_cell2_one<MTG, false, false>(A, W.x2, W.h1, t, tile, lds, c2v, sl[(4 * g + 3) * PD_NT], unused, g, sh, 1, zt);
+                if (sh->abort) return;
+                sl[(4 * g + 1) * PD_NT] = c2v;
+                if (g >= 1) {
+                    pd_proj(A, wpj, t, ptile, MTG * (g - 1) + pm, lds, sh, g - 1);
+                    if (sh->abort) return;
+                }
+            }
+        pd_proj(A, wpj, t, ptile, MTG * (A.G - 1) + pm, lds, sh, A.G - 1);
+        if (sh->abort) return;
+        if (t + 1 == A.steps) break;
+        pd_load_tile<8>(A.w1h, tile, W.h1);
+        PD_PIN();
+#pragma unroll
+        for (int g = 0; g < GM; ++g)
+            if (g < A.G) sl[(4 * g + 2) * PD_NT] = pd_g_rec1_mem_one<MTG, false>(A, W.h1, t, tile, lds, g);
+        pd_load_tile<8>(A.w2h, tile, W.h2);
+        PD_PIN();
+#pragma unroll
+        for (int g = 0; g < GM; ++g)
+            if (g < A.G) sl[(4 * g + 3) * PD_NT] = pd_g_rec2_one<MTG, false, false>(A, W.h2, t, tile, lds, g, sh, zt);     // (its counter was seen by the projection)
+    }
+}
+
+template <int GM, int MTG>
+__global__ __launch_bounds__(PD_NT) void gt_persist_decode_g_kernel(PersistDecodeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ PdShared sh;
+    if (threadIdx.x == 0) sh.abort = 0;
+    __syncthreads();
+    const int tile = blockIdx.x;
+#ifndef PD_GONLY
+#define PD_GONLY -1         // (register-budget diagnosis: compile one role alone)
+#endif
+    if (tile < A.n_chain) { if (PD_GONLY < 0 || PD_GONLY == 0) pd_g_run_tile<GM, MTG, true>(A, smem, &sh); }
+    else if (tile < A.n_chain + A.pj_tiles * MTG) { if (PD_GONLY < 0 || PD_GONLY == 1) pd_g_run_proj<GM, MTG>(A, smem, &sh); }
+    else if (PD_GONLY < 0 || PD_GONLY == 2) pd_g_run_tile<GM, MTG, false>(A, smem, &sh);
+}
+
 // z0 granules of step 0: the first frame is zero (Taco2.py:162-165), so prenet 0's pre-activations are its bias; + the control words
 __global__ void gt_persist_decode_init_kernel(uint2* z0g, const float* b0, uint32_t* ctl, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -826,25 +1147,57 @@ __global__ void gt_persist_decode_init_kernel(uint2* z0g, const float* b0, uint3
 
 size_t gt_persist_decode_ctl_words() { return PD_CTL_WORDS; }
 
-bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots) {
+int gt_persist_decode_max_batch() { return PD_BMAX; }
+
+// `split16`: a batch of 17..32 rows as two groups of 16 (experiment; the default is the one-group kernel with its helper workgroups)
+bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots, int split16) {
     (void)mel; (void)r;
-    return P0 == PD_P && P1 == PD_P && A == PD_A && H1 == PD_H && H2 == PD_H && B >= 1 && B <= 32 && Tv >= 1 && Tv <= PD_TV && pj_nkb == PD_KBPJ &&
-           pj_tiles >= 1 && PD_UTT + pj_tiles * ((B + 15) / 16) + PD_HELP <= PD_NWG && slots >= PD_NWG;
+    if (!(P0 == PD_P && P1 == PD_P && A == PD_A && H1 == PD_H && H2 == PD_H && B >= 1 && Tv >= 1 && Tv <= PD_TVMAX && pj_nkb == PD_KBPJ && pj_tiles >= 1 &&
+          slots >= PD_NWG))
+        return false;
+    if (B <= 32 && !(split16 && B > 16)) return PD_UTT + pj_tiles * ((B + 15) / 16) + PD_HELP <= PD_NWG;
+    return B <= PD_BMAX && B + pj_tiles * (B <= 32 ? 1 : 2) <= PD_NWG;
 }
+
+namespace {
+typedef void (*PdKernel)(PersistDecodeArgs);
+// which kernel a batch runs on: the one-group kernel up to 32 rows, groups of 32 rows above (2 up to 64 rows, else 4)
+PdKernel pd_kernel_for(int B, int split16, int* G, int* mtg) {
+    if (B <= 32 && !(split16 && B > 16)) { *G = 1; *mtg = 2; return gt_persist_decode_kernel; }
+    if (B <= 32) { *G = 2; *mtg = 1; return gt_persist_decode_g_kernel<2, 1>; }
+    *mtg = 2; *G = (B + 31) / 32;
+    return B <= 64 ? gt_persist_decode_g_kernel<2, 2> : gt_persist_decode_g_kernel<4, 2>;
+}
+const PdKernel kPdKernels[] = {gt_persist_decode_kernel, gt_persist_decode_g_kernel<2, 1>, gt_persist_decode_g_kernel<2, 2>, gt_persist_decode_g_kernel<4, 2>};
+}  // namespace
 
 hipError_t gt_persist_decode_init() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(gt_persist_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PD_LDS_FLOATS * 4);
+    for (PdKernel k : kPdKernels) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, pd_lds_floats(PD_TVMAX) * 4);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
+// the smallest occupancy over the kernels at the largest LDS size: every one of them needs its 256 workgroups resident
 int gt_persist_decode_blocks_per_cu() {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(gt_persist_decode_kernel), PD_NT, (size_t)PD_LDS_FLOATS * 4) != hipSuccess) return 0;
-    return n;
+    int worst = 1 << 30;
+    for (PdKernel k : kPdKernels) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), PD_NT, (size_t)pd_lds_floats(PD_TVMAX) * 4) != hipSuccess) return 0;
+        worst = n < worst ? n : worst;
+    }
+    return worst;
 }
 
-hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a, const float* b0, hipStream_t stream) {
+hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a_in, const float* b0, int split16, hipStream_t stream) {
+    PersistDecodeArgs a = a_in;
+    int mtg = 2;
+    const PdKernel k = pd_kernel_for(a.B, split16, &a.G, &mtg);
+    a.tvp = (a.Tv + 63) / 64 * 64;
+    a.n_chain = a.G == 1 && mtg == 2 && k == gt_persist_decode_kernel ? PD_UTT : a.B;
     const int n = PD_CTL_WORDS > a.B * PD_P ? PD_CTL_WORDS : a.B * PD_P;
     hipLaunchKernelGGL(gt_persist_decode_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.z0g, b0, a.ctl, a.B);
-    hipLaunchKernelGGL(gt_persist_decode_kernel, dim3(PD_NWG), dim3(PD_NT), (size_t)PD_LDS_FLOATS * 4, stream, a);
+    hipLaunchKernelGGL(k, dim3(PD_NWG), dim3(PD_NT), (size_t)pd_lds_floats(a.tvp) * 4, stream, a);
     return hipGetLastError();
 }

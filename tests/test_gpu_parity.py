@@ -282,8 +282,8 @@ def test_fused_lstm_launch_is_bitwise_the_two_launches(monkeypatch, B, mixed):
         assert np.abs(outs["1"][0] - ref[0]).max() <= TOL and np.abs(outs["1"][2] - ref[3]).max() <= TOL
 
 
-@pytest.mark.parametrize("persist", ["0", "1"])
-def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers(monkeypatch, persist):
+@pytest.mark.parametrize("persist,B", [("0", 4), ("1", 4), ("1", 40)])
+def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers(monkeypatch, persist, B):
     """The fused LSTM launch's wait (persist = 0) and the persistent decode launch's waits (1) are bounded: with one arrival too
     many expected (fault injection) every workgroup runs into the bound, the call's outputs are invalid and ``synchronize``
     says so; the next call uses the next launch form down (persistent -> fused -> two launches) and is correct."""
@@ -293,8 +293,8 @@ def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers(monkeypatch, 
     from gst_tacotron_amd.capi import GstTacoError
     gc.collect()                                    # (both launch forms are taken only while the process has ONE live context)
     monkeypatch.setenv("GSTTACO_PERSIST_DECODE", persist)
-    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(4, 24, 40, 3, seed=8)
-    m = _model(hp, w, 4, 24, 41)
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, 24, 40, 3, seed=8)        # (B = 40: the group kernel, two groups of rows)
+    m = _model(hp, w, B, 24, 41)
     assert m.decode_counters()[1] == int(persist)
     ref = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=3)[0].cpu().numpy()
     m.synchronize()
@@ -311,22 +311,36 @@ def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers(monkeypatch, 
     assert m.decode_counters()[1] == 0
 
 
-@pytest.mark.parametrize("B,Tv,att,mode", [(32, 128, "SMA", "hashed"), (32, 128, "BMA", "hashed"), (5, 40, "SMA", "injected"),
-                                           (17, 100, "BMA", "injected"), (9, 77, "SMA", "masked"), (16, 128, "SMA", "rate25"),
-                                           (3, 20, "SMA", "nodrop")])
-def test_persistent_decode_launch_is_bitwise_the_launches(monkeypatch, B, Tv, att, mode):
+PERSIST_CASES = [
+    # the one-group kernel (<= 32 rows): 256 workgroups, helpers for the chain workgroups' recurrent halves
+    (32, 128, "SMA", "hashed", 150, {}), (32, 128, "BMA", "hashed", 150, {}), (5, 40, "SMA", "injected", 150, {}),
+    (17, 100, "BMA", "injected", 150, {}), (9, 77, "SMA", "masked", 150, {}), (16, 128, "SMA", "rate25", 150, {}), (3, 20, "SMA", "nodrop", 150, {}),
+    # more than 128 tokens (round 5): the utterance's whole processed memory in LDS up to 256 rows, the context summed in the launch
+    # path's chunk order; 187 = the reference's own 8-sentence inference batch (Inference_Sentence_for_Training.txt, Feeder.py:161-180)
+    (32, 129, "BMA", "injected", 100, {}), (8, 187, "SMA", "hashed", 150, {}), (20, 256, "BMA", "hashed", 100, {}), (7, 256, "SMA", "masked", 100, {}),
+    # groups of 32 rows through one set of resident weights (round 5): 2 groups up to 64 rows, 4 up to 128; partial last groups and M-tiles
+    (37, 60, "SMA", "hashed", 100, {}), (64, 128, "BMA", "injected", 60, {}), (65, 50, "SMA", "masked", 100, {}), (128, 128, "SMA", "hashed", 100, {}),
+    (128, 256, "BMA", "masked", 60, {}), (100, 187, "SMA", "rate25", 60, {}),
+    # 17..32 rows as two groups of 16 (GSTTACO_PERSIST_SPLIT16=1: the measured alternative to the helpers of the one-group kernel)
+    (32, 128, "SMA", "hashed", 100, {"GSTTACO_PERSIST_SPLIT16": "1"}), (23, 70, "BMA", "injected", 100, {"GSTTACO_PERSIST_SPLIT16": "1"}),
+]
+
+
+@pytest.mark.parametrize("B,Tv,att,mode,steps,env", PERSIST_CASES)
+def test_persistent_decode_launch_is_bitwise_the_launches(monkeypatch, B, Tv, att, mode, steps, env):
     """The whole decoder loop as ONE persistent launch (csrc/persist_decode.hip: every GEMM weight resident in registers, the
     utterances' processed memory in LDS, in-kernel hand-offs with bounded waits) against the launch path
     (GSTTACO_PERSIST_DECODE=0: fused front launch + fused LSTM launch + projection launch per step): the SAME arithmetic in
-    the same order -- mel, stop and alignment outputs bitwise equal over 150 steps at full dimensions, which is also the test
+    the same order -- mel, stop and alignment outputs bitwise equal over 60-150 steps at full dimensions, which is also the test
     that no in-kernel hand-off ever delivers a stale word.  Hashed (throughput-mode) and injected dropout, a rate the hash
     does not cover (masks from the buffer), no dropout, SMA and BMA, batches of one and two M-tiles, ragged batches in masked
-    mode, repeated calls; and the persistent form against the float64 oracle."""
+    mode, repeated calls, up to 256 tokens, up to 128 utterances (the group kernels); and the persistent form against the float64
+    oracle (injected cases of up to 32 utterances)."""
     import gc
     import torch
     from oracle import oracle_np
     gc.collect()                                    # (the persistent launch is taken only while the process has ONE live context)
-    steps, Tref = 150, 60
+    Tref = 60
     rate = {"rate25": 0.25, "nodrop": 0.0}.get(mode, 0.5)
     hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=40 + B, att=att, rate=rate)
     kw = dict(steps=steps)
@@ -338,6 +352,8 @@ def test_persistent_decode_launch_is_bitwise_the_launches(monkeypatch, B, Tv, at
         tl = np.random.default_rng(3).integers(Tv // 3, Tv + 1, B).astype(np.int32)
         tl[0] = Tv
         kw.update(masked=True)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     outs = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("GSTTACO_PERSIST_DECODE", flag)
@@ -349,7 +365,7 @@ def test_persistent_decode_launch_is_bitwise_the_launches(monkeypatch, B, Tv, at
         n_persist, on = m.decode_counters()            # (enqueued once: the second call replays the captured graph)
         assert (n_persist >= 1 and on == 1) if flag == "1" else (n_persist == 0 and on == 0)
         outs[flag] = (mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy())
-        if flag == "1" and mode == "injected":
+        if flag == "1" and mode == "injected" and B <= 32:
             ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
             assert np.abs(outs[flag][0] - ref[0]).max() <= TOL and np.abs(outs[flag][2] - ref[3]).max() <= TOL
         del m, mel, stop, align
@@ -358,6 +374,27 @@ def test_persistent_decode_launch_is_bitwise_the_launches(monkeypatch, B, Tv, at
     assert np.isfinite(outs["1"][0]).all()
     for a, b in zip(outs["1"], outs["0"]):
         assert np.array_equal(a, b)
+
+
+def test_the_reference_inference_sentences_take_the_persistent_launch():
+    """The reference's own inference example: its 8 sentences (Inference_Sentence_for_Training.txt, the longest 185 characters ->
+    a batch padded to 187 tokens by Feeder.py:161-180) through ``Inference`` -- tokens from the committed fixture the reference's
+    Feeder produced -- run on the persistent decode launch (T_v <= 256 since round 5), not silently on the launch path."""
+    import os
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "feeder_tokens.npz"), allow_pickle=False)
+    sentences = [str(x) for x in fx["sentences"]]
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, seed=0)
+    rng = np.random.default_rng(5)
+    ref_mels = [np.clip(rng.normal(0, 1.5, (n, 80)), -4, 4).astype(np.float32) for n in rng.integers(100, 240, len(sentences))]
+    _sole_context()
+    m = _model(hp, w, len(sentences), 256, 260)
+    out = m.Inference(sentences, ref_mels, steps=40)
+    assert out is not None and out[3].shape[2] == int(fx["nogst.tokens"].shape[1]) == 187
+    _assert_persistent_decode(m)
+    assert np.isfinite(out[0].cpu().numpy()).all()
 
 
 def test_on_device_randomness_is_seeded():
