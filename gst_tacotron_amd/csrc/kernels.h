@@ -322,7 +322,8 @@ struct PersistDecodeArgs {
     float* stop;                                       // [B][steps]
     float* align; int64_t ld_align;                    // [B][steps][Tv]
     int B, MT, Tv, steps, co_tiles;                    // co_tiles: layer-2 tiles whose recurrent half the launch path sums in 8-wave order
-    int G, n_chain, tvp;                               // filled in by the launcher: groups of rows, chain workgroups, T_v rounded up to 64
+    int G, n_chain, tvp, twopass;                      // filled in by the launcher: groups of rows, chain workgroups, T_v rounded up to 64, and
+                                                       // whether the group kernels' chain workgroups sum their recurrent halves through 8 slabs
     int expect_extra;                                  // fault injection (tests): the all-to-all waits expect this many arrivals too many
     unsigned long long* dbg;                           // diagnostic stamps [3 roles][32] or NULL (GSTTACO_STAMPS=1)
 };

@@ -223,6 +223,20 @@ __device__ __forceinline__ float pd_reduce(float* lds, float base) {
     __syncthreads();            // the slabs are re-used by the next reduction
     return z;
 }
+// the same, and one lane signals an arrival counter behind the first barrier (`cnt` != NULL): the DEFERRED arrival of an earlier
+// store -- every wave has drained its stores before it got here (pd_drain in front of the spill)
+template <int NSLAB>
+__device__ __forceinline__ float pd_reduce_arrive(float* lds, float base, uint32_t* cnt) {
+    __syncthreads();
+    if (cnt && threadIdx.x == 0) __hip_atomic_fetch_add(cnt + (blockIdx.x & (PD_NSH - 1)) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    float z = base;
+#pragma unroll
+    for (int w = 0; w < NSLAB; ++w) z += part[w][row][col];
+    __syncthreads();
+    return z;
+}
 // h . W_h (+ bias) of one tile from the fragments x0 / x1 of the whole state (8 k-blocks per wave).  ORDER16: the summation order
 // of the launch path's 16-wave workers (gt_lean_partial<16, 4, 2>: virtual wave v owns k-blocks v, v + 16, v + 32, v + 48; this
 // wave plays v = wave and v = wave + 8), else the 8-wave order of the projection launch's co-workers (gt_lean_partial<8, 8, 1>).
@@ -399,11 +413,14 @@ __device__ __forceinline__ float pd_rec1_mem(const PersistDecodeArgs& A, const f
 
 // Projection tile `ptile`, M-tile `pmt` (Taco2.py:112-118: r mel frames | stop logit) + the next step's prenet-0 pre-activations
 // (both layers are linear: gsttaco.cpp proj_z), gt_proj_lean_kernel's arithmetic
+template <bool GK = false>     // GK: called by a group kernel (its stamp slots)
 __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4 (&wp)[9], int t, int ptile, int pmt, float* lds, PdShared* sh, int g = 0) {
     const int par = t & 1, MT = A.MT;
-    pd_wait_count(A, A.ctl + PD_CNT4 + g * (PD_NSH * 32), (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
-    if (sh->abort) return;
-    PD_STAMP(1, 9);
+    if (!GK) {          // (a group kernel has waited for every group's arrivals at once)
+        pd_wait_count(A, A.ctl + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        if (sh->abort) return;
+    }
+    if (!GK) PD_STAMP(1, 9);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const auto rh = gt_rsrc(A.h2[par], 0x7FFFF000u);
@@ -424,7 +441,7 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].z, wp[i].z, a0, 0, 0, 0);
         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].w, wp[i].w, a0, 0, 0, 0);
     }
-    PD_STAMP(1, 10);
+    if (!GK) PD_STAMP(1, 10);
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
     const float v = pd_reduce<8>(lds, A.bp[ptile * 16 + (threadIdx.x & 15)]);
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
@@ -442,7 +459,8 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
             A.stop[(size_t)grow * A.steps + t] = v;
         }
     }
-    PD_STAMP(1, 11);
+    if (!GK) PD_STAMP(1, 11);
+    else PD_STAMP(1, 6 + 7 * g);
 }
 
 // ---- the per-utterance chain (front_lean.h's arithmetic; every thread plays launch-path threads tid and tid + 512)
@@ -456,15 +474,19 @@ struct PdChainLds {
 // The other roles use 16 slabs (the 16-wave summation order of the recurrent halves) and nothing else.
 constexpr int PD_SLAB = 32 * 17;
 constexpr int PD_OTHER_FLOATS = 16 * PD_SLAB + 4 * PD_GMAX * PD_NT;      // (+ the group kernels' projection role: its per-group state)
-__host__ __device__ constexpr int pd_lds_floats(int tvp) {
-    return 8 * PD_SLAB + 3 * PD_P + 2 * PD_A + 4 * tvp + tvp * PD_LDV > PD_OTHER_FLOATS ? 8 * PD_SLAB + 3 * PD_P + 2 * PD_A + 4 * tvp + tvp * PD_LDV : PD_OTHER_FLOATS;
+__host__ __device__ constexpr int pd_chain_floats(int tvp, int nslab) { return nslab * PD_SLAB + 3 * PD_P + 2 * PD_A + 4 * tvp + tvp * PD_LDV; }
+// the group kernels' chain workgroups also sum their own recurrent halves (16 slabs in the launch path's 16-wave order): with 16
+// slabs while they fit beside the processed memory (T_v <= 192), else in two passes over 8
+__host__ __device__ constexpr int pd_chain_slabs(int tvp, bool group_kernel) { return group_kernel && pd_chain_floats(tvp, 16) * 4 + 64 <= 160 * 1024 ? 16 : 8; }
+__host__ __device__ constexpr int pd_lds_floats(int tvp, bool group_kernel = false) {
+    return pd_chain_floats(tvp, pd_chain_slabs(tvp, group_kernel)) > PD_OTHER_FLOATS ? pd_chain_floats(tvp, pd_chain_slabs(tvp, group_kernel)) : PD_OTHER_FLOATS;
 }
 static_assert(16 * PD_P <= 8 * PD_SLAB && 8 * PD_A <= 8 * PD_SLAB, "the chain's partial sums alias the reduction slabs");
-static_assert(pd_lds_floats(PD_TVMAX) * 4 + 64 <= 160 * 1024, "one utterance's chain state must fit a CU's LDS");
-__device__ __forceinline__ PdChainLds pd_carve(float* smem, int tvp) {
+static_assert(pd_lds_floats(PD_TVMAX, true) * 4 + 64 <= 160 * 1024 && pd_lds_floats(PD_TVMAX, false) * 4 + 64 <= 160 * 1024, "one utterance's chain state must fit a CU's LDS");
+__device__ __forceinline__ PdChainLds pd_carve(float* smem, int tvp, int nslab = 8) {
     PdChainLds L;
     L.partial = smem; L.red = smem;
-    L.y0 = smem + 8 * PD_SLAB; L.y1 = L.y0 + PD_P; L.qs = L.y1 + PD_P; L.vs = L.qs + PD_A; L.sc = L.vs + PD_A; L.nz = L.sc + tvp; L.pv = L.nz + tvp;
+    L.y0 = smem + nslab * PD_SLAB; L.y1 = L.y0 + PD_P; L.qs = L.y1 + PD_P; L.vs = L.qs + PD_A; L.sc = L.vs + PD_A; L.nz = L.sc + tvp; L.pv = L.nz + tvp;
     L.al = L.pv + tvp; L.ks1 = L.al + tvp; L.tile = L.ks1 + PD_P;
     return L;
 }
@@ -894,9 +916,14 @@ __global__ __launch_bounds__(PD_NT) void gt_persist_decode_kernel(PersistDecodeA
 
 
 // ====================================================================================================================== groups
-// Batches above 32 rows (and, as an experiment, 32 rows as two groups of 16): G groups of 16 MTG rows go through ONE set of resident
-// weights.  Every workgroup still owns gate tile `blockIdx.x` of both cells and runs each GEMM phase group by group -- the hand-off
-// of group g travels while group g + 1 is multiplied, which is what hides the all-to-all latencies the one-group kernel waits out.
+// Batches above 32 rows (and, as an experiment, 17..32 rows as two groups of 16): G groups of 16 MTG rows go through ONE set of
+// resident weights.  Every workgroup still owns gate tile `blockIdx.x` of both cells and runs each GEMM phase group by group:
+//   * ONE wait per phase for all groups (context flags, h1 arrivals, h2 arrivals) instead of one per group -- a satisfied wait still
+//     costs a poll's round trip;
+//   * the NEXT group's activation fragments are requested while the current group is multiplied (cell 1: a second fragment buffer;
+//     the K = 1024 phases: each fragment re-requested right behind the MFMAs that consumed it, lean_body.h's multi-chunk order), so a
+//     group's hand-off and fragment latencies hide behind its neighbours' arithmetic -- v1 of this kernel ran them back to back and
+//     spent 30 of 59 us per step at 128 rows waiting for fragments (profiles/r05_group_stamps.txt).
 // Per group the arithmetic is the one-group kernel's (= the launch path's single-chunk bodies', which its multi-chunk bodies
 // reproduce per 32-row chunk): bitwise the launches at any batch.  Roles: workgroup b < B runs utterance b's chain, then its tile for
 // every group with the tile's weights STREAMED (the chain's operands own the registers meanwhile; nobody helps: with one chain per
@@ -908,73 +935,236 @@ template <int GM> struct PdG { float c1[GM], c2[GM], p1[GM], p2[GM]; };
 // addresses -- flags, counter shards and state rows of every group and parity: dozens of 64-bit pairs at four groups -- are hoisted
 // out of the loop and live across the chain, which needs the whole register file: they spill, and a scratch reload waits for vmcnt(0).
 #define PD_ZT(zt) int zt = 0; asm volatile("" : "+v"(zt))
-template <int MTG>
-__device__ __forceinline__ void pd_g_cell1_one(const PersistDecodeArgs& A, const float4 (&wx1)[3], int t, int tile, float* lds, float& c1v, float p1v, int g,
-                                               PdShared* sh, int role, int zt) {
-    constexpr int RG = 16 * MTG;
-    const int par = t & 1, MT = A.MT;
-    pd_wait_flags<PD_FS>(A, A.ctl + zt + PD_F_C + RG * g * PD_FS, min(RG, A.B - RG * g), (uint32_t)t + 1u, sh);   // (a chain's context flag follows its prenet flag)
-    if (sh->abort) return;
-    if (g == 0) PD_STAMP(role, 3);
-    float4 x0[3], x1[3];
-    pd_g_xload<MTG, 0, 3, 3>(A.xa[par], MT, g, x0, x1);
-    PD_PIN();
-    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-    pd_g_mma<MTG, 3, 0, 1, 3>(x0, x1, wx1, a0, a1);
-    pd_spill(lds, threadIdx.x >> 6, a0, a1);
-    const float z = pd_reduce<8>(lds, p1v);
-    pd_gates_store(z, c1v, A.h1[par] + zt, tile, A.B, MT, RG * g, RG);
-    if (g == 0) PD_STAMP(role, 4);
-    pd_arrive(A.ctl + zt + PD_CNT3 + g * (PD_NSH * 32));
-}
 
-// REC1: the layer-1 recurrent half for the next step from the same fragments
-template <int MTG, bool REC1, bool TWOPASS>
-__device__ __forceinline__ void pd_g_cell2_one(const PersistDecodeArgs& A, const float4 (&wx2)[8], const float4 (&wh1)[8], int t, int tile, float* lds, float& c2v,
-                                               float p2v, float& p1_next, int g, PdShared* sh, int role, int zt) {
-    constexpr int RG = 16 * MTG;
-    const int par = t & 1, MT = A.MT;
-    pd_wait_count(A, A.ctl + zt + PD_CNT3 + g * (PD_NSH * 32), (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
-    if (sh->abort) return;
-    if (g == 0) PD_STAMP(role, 5);
-    float4 x0[8], x1[8];
-    pd_g_xload<MTG, 0, 8, 8>(A.h1[par], MT, g, x0, x1);
-    PD_PIN();
-    f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-    pd_g_mma<MTG, 8, 0, 1, 8>(x0, x1, wx2, a0, a1);
-    if (g == 0) PD_STAMP(role, 6);
-    pd_spill(lds, threadIdx.x >> 6, a0, a1);
-    const float z = pd_reduce<8>(lds, p2v);
-    pd_gates_store(z, c2v, A.h2[par] + zt, tile, A.B, MT, RG * g, RG);
-    if (g == 0) PD_STAMP(role, 7);
-    pd_arrive(A.ctl + zt + PD_CNT4 + g * (PD_NSH * 32));
-    if (g == 0) PD_STAMP(role, 8);
-    if (REC1) p1_next = pd_g_rec_tile<true, MTG, TWOPASS>(x0, x1, wh1, A.b1h[tile * 16 + (threadIdx.x & 15)], lds);
-}
-
-template <int MTG, bool TWOPASS>
-__device__ __forceinline__ float pd_g_rec1_mem_one(const PersistDecodeArgs& A, const float4 (&wh1)[8], int t, int tile, float* lds, int g) {
-    float4 x0[8], x1[8];
-    pd_g_xload<MTG, 0, 8, 8>(A.h1[t & 1], A.MT, g, x0, x1);
-    PD_PIN();
-    return pd_g_rec_tile<true, MTG, TWOPASS>(x0, x1, wh1, A.b1h[tile * 16 + (threadIdx.x & 15)], lds);
-}
-
-// layer-2 recurrent half for the next step (tiles below co_tiles sum in the projection launch's co-workers' 8-wave order)
-template <int MTG, bool TWOPASS, bool WAIT>
-__device__ __forceinline__ float pd_g_rec2_one(const PersistDecodeArgs& A, const float4 (&wh2)[8], int t, int tile, float* lds, int g, PdShared* sh, int zt) {
-    if (WAIT) {
-        pd_wait_count(A, A.ctl + zt + PD_CNT4 + g * (PD_NSH * 32), (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
-        if (sh->abort) return 0.f;
+// ---- one wait for ALL groups: the context flags of every utterance (two per lane: B <= 128) ...
+__device__ __forceinline__ void pd_wait_flags_all(const PersistDecodeArgs& A, const uint32_t* f, uint32_t want, PdShared* sh) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const bool h0 = lane < A.B, h1 = lane + 64 < A.B;
+        const uint32_t* p0 = f + (h0 ? lane : 0) * PD_FS;
+        const uint32_t* p1 = f + (h1 ? lane + 64 : 0) * PD_FS;
+        uint32_t spins = 0;
+        for (;;) {
+            uint32_t v0, v1;
+            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+            const bool ok = (!h0 || v0 >= want) && (!h1 || v1 >= want);
+            if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(ok))) == 64) break;
+            if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
+            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
+        }
     }
-    float4 x0[8], x1[8];
-    pd_g_xload<MTG, 0, 8, 8>(A.h2[t & 1], A.MT, g, x0, x1);
-    PD_PIN();
-    const float bias = A.b2h[tile * 16 + (threadIdx.x & 15)];
-    return tile < A.co_tiles ? pd_g_rec_tile<false, MTG, TWOPASS>(x0, x1, wh2, bias, lds) : pd_g_rec_tile<true, MTG, TWOPASS>(x0, x1, wh2, bias, lds);
+    __syncthreads();
+}
+// ... and the arrival counters of groups [0, G) (PD_NSH shards each, one per lane; all requested, then one wait)
+template <int GM>
+__device__ __forceinline__ void pd_wait_count_all(const PersistDecodeArgs& A, const uint32_t* c, uint32_t want, PdShared* sh) {
+    static_assert(PD_NSH == 64, "one counter shard per lane");
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t spins = 0;
+        for (;;) {
+            uint32_t u[GM];
+#pragma unroll
+            for (int g = 0; g < GM; ++g) {
+                u[g] = want;
+                if (g < A.G) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(u[g]) : "v"(c + g * (PD_NSH * 32) + lane * 32) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bool ok = true;
+#pragma unroll
+            for (int g = 0; g < GM; ++g) {
+                if (g < A.G) {
+                    asm volatile("" : "+v"(u[g]));
+                    uint32_t v = u[g];
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+                    ok = ok && __builtin_amdgcn_readfirstlane(v) >= want;
+                }
+            }
+            if (ok) break;
+            if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
+            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
+        }
+    }
+    __syncthreads();
 }
 
-// a tile's four GEMM halves for every group; CHAIN: utterance blockIdx.x's chain first, the tile's weights streamed phase by phase
+// the wave's eight K = 1024 fragments times one weight tile.  ORDER16: two accumulator pairs, fragments 0, 2, 4, 6 -> a, 1, 3, 5, 7 -> b
+// (the launch path's 16-wave order, pd_rec_tile); else all eight -> a in ascending order.  RELOAD: fragment i of group `gn` is requested
+// right behind the MFMAs that consumed fragment i (gn = the group itself when there is no next one: re-read, never multiplied).
+template <int MTG, bool ORDER16, bool RELOAD>
+__device__ __forceinline__ void pd_g_mma8(float4 (&x0)[8], float4 (&x1)[8], const float4 (&w)[8], f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1,
+                                          const float* base, int MT, int gn) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto rs = gt_rsrc(base, 0x7FFFF000u);
+    const uint32_t m0 = (uint32_t)(MTG * gn) * 1024u, m1 = (uint32_t)min(MTG * gn + 1, MT - 1) * 1024u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        f32x4& c0 = (ORDER16 && (i & 1)) ? b0 : a0;
+        f32x4& c1 = (ORDER16 && (i & 1)) ? b1 : a1;
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, w[i].x, c0, 0, 0, 0); if (MTG == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, w[i].x, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, w[i].y, c0, 0, 0, 0); if (MTG == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, w[i].y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, w[i].z, c0, 0, 0, 0); if (MTG == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, w[i].z, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, w[i].w, c0, 0, 0, 0); if (MTG == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, w[i].w, c1, 0, 0, 0);
+        if (RELOAD) {
+            PD_PIN();
+            const uint32_t so = (uint32_t)((wave + i * PD_NW) * MT) * 1024u;
+            x0[i] = gt_bload4_sc1(rs, (uint32_t)lane * 16u, so + m0);
+            if (MTG == 2) x1[i] = gt_bload4_sc1(rs, (uint32_t)lane * 16u, so + m1);
+            PD_PIN();
+        }
+    }
+}
+// sums of a recurrent-half tile from its accumulators (pd_rec_tile's orders).  TWOPASS: the 16-slab sum through EIGHT slabs -- virtual
+// waves 0..7, then 8..15 onto the running sum: the same sequence of additions (chain workgroups: their LDS holds the processed memory).
+// `cnt`: a deferred arrival (pd_reduce_arrive) or NULL
+template <bool ORDER16, bool TWOPASS>
+__device__ __forceinline__ float pd_g_rec_sum(float* lds, float bias, const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, uint32_t* cnt = nullptr,
+                                              bool two = true) {
+    const int wave = threadIdx.x >> 6;
+    if (ORDER16) {
+        if (TWOPASS && two) {
+            pd_spill(lds, wave, a0, a1);
+            const float z = pd_reduce_arrive<8>(lds, bias, cnt);
+            pd_spill(lds, wave, b0, b1);
+            return pd_reduce<8>(lds, z);
+        }
+        pd_spill(lds, wave, a0, a1);
+        pd_spill(lds, wave + 8, b0, b1);
+        return pd_reduce_arrive<16>(lds, bias, cnt);
+    }
+    pd_spill(lds, wave, a0, a1);
+    return pd_reduce_arrive<8>(lds, bias, cnt);
+}
+
+// ---- the phases, for all groups.  State access: `c(g)` / `p(g)` return references (registers, or LDS in the projection role).
+// LSTM cell 1 of every group: z = [p | ctx] . W1x + p1[g]; the next group's fragments in a second buffer
+template <int GM, int MTG, class C1, class P1>
+__device__ __forceinline__ void pd_g_cell1_all(const PersistDecodeArgs& A, const float4 (&wx1)[3], int t, int tile, float* lds, C1 c1, P1 p1, PdShared* sh, int role, int zt) {
+    constexpr int RG = 16 * MTG;
+    const int par = t & 1, MT = A.MT;
+    pd_wait_flags_all(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, sh);       // (a chain's context flag follows its prenet flag)
+    if (sh->abort) return;
+    PD_STAMP(role, 2);
+    float4 xa0[3], xa1[3], xb0[3], xb1[3];
+    pd_g_xload<MTG, 0, 3, 3>(A.xa[par], MT, 0, xa0, xa1);
+#pragma unroll
+    for (int g = 0; g < GM; ++g) {
+        if (g < A.G) {
+            float4 (&x0)[3] = (g & 1) ? xb0 : xa0;
+            float4 (&x1)[3] = (g & 1) ? xb1 : xa1;
+            PD_PIN();
+            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+            pd_g_mma<MTG, 3, 0, 1, 3>(x0, x1, wx1, a0, a1);
+            // (group g - 1's h1 stores were left in flight: their acknowledgement arrived under this group's MFMAs; drained here, its
+            // arrival is signalled behind the reduction's first barrier -- the last group's at once, everybody waits for it.  The next
+            // group's fragments are requested BEHIND the drain -- in front of it the drain waited for them -- and land under the epilogue)
+            if (g > 0) pd_drain();
+            PD_PIN();
+            if (g + 1 < GM && g + 1 < A.G) {
+                if (g & 1) pd_g_xload<MTG, 0, 3, 3>(A.xa[par], MT, g + 1, xa0, xa1);
+                else pd_g_xload<MTG, 0, 3, 3>(A.xa[par], MT, g + 1, xb0, xb1);
+            }
+            PD_PIN();
+            pd_spill(lds, threadIdx.x >> 6, a0, a1);
+            const float z = pd_reduce_arrive<8>(lds, p1(g), g > 0 ? A.ctl + zt + PD_CNT3 + (g - 1) * (PD_NSH * 32) : nullptr);
+            pd_gates_store(z, c1(g), A.h1[par], tile + zt, A.B, MT, RG * g, RG);
+            if (g == A.G - 1) pd_arrive(A.ctl + zt + PD_CNT3 + g * (PD_NSH * 32));
+            PD_STAMP(role, 3 + 7 * g);
+        }
+    }
+}
+
+// LSTM cell 2 of every group: z = h1_t . W2x + p2[g]; REC1: then, from the same fragments, the layer-1 recurrent half for the next step,
+// the next group's fragments requested behind its MFMAs (else behind cell 2's own)
+// STREAM_H2 (chain workgroups): the layer-2 recurrent tile for the next phase is requested once the last group's cell-2 MFMAs have
+// released W2x's registers
+template <int GM, int MTG, bool REC1, bool TWOPASS, bool STREAM_H2, class C2, class P2, class P1>
+__device__ __forceinline__ void pd_g_cell2_all(const PersistDecodeArgs& A, const float4 (&wx2)[8], const float4 (&wh1)[8], float4 (&wh2)[8], int t, int tile, float* lds,
+                                               C2 c2, P2 p2, P1 p1, PdShared* sh, int role, int zt) {
+    constexpr int RG = 16 * MTG;
+    const int par = t & 1, MT = A.MT;
+    pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+    if (sh->abort) return;
+    PD_STAMP(role, 4);
+    float4 x0[8], x1[8];
+    pd_g_xload<MTG, 0, 8, 8>(A.h1[par], MT, 0, x0, x1);
+    PD_PIN();
+    const float bias1 = A.b1h[tile * 16 + (threadIdx.x & 15)];
+#pragma unroll
+    for (int g = 0; g < GM; ++g) {
+        if (g < A.G) {
+            const int gn = min(g + 1, A.G - 1);
+            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+            pd_g_mma8<MTG, false, !REC1>(x0, x1, wx2, a0, a1, b0, b1, A.h1[par], MT, gn);
+            // REC1: group g - 1's h2 stores stayed in flight under its recurrent half and this group's MFMAs -- which waited for every
+            // fragment re-requested in between, so nothing is left to wait for here -- and its arrival is signalled behind this
+            // reduction's first barrier; the last group's at once (everybody waits for it)
+            const bool deferred = REC1 && g > 0;
+            if (deferred) pd_drain();
+            pd_spill(lds, threadIdx.x >> 6, a0, a1);
+            const float z = pd_reduce_arrive<8>(lds, p2(g), deferred ? A.ctl + zt + PD_CNT4 + (g - 1) * (PD_NSH * 32) : nullptr);
+            pd_gates_store(z, c2(g), A.h2[par], tile + zt, A.B, MT, RG * g, RG);
+            if (!REC1 || g == A.G - 1) pd_arrive(A.ctl + zt + PD_CNT4 + g * (PD_NSH * 32));
+            PD_STAMP(role, 5 + 7 * g);
+            if (STREAM_H2 && g == A.G - 1 && t + 1 < A.steps) pd_load_tile<8>(A.w2h, tile, wh2);
+            if (REC1) {
+                a0 = f32x4{0, 0, 0, 0}; a1 = f32x4{0, 0, 0, 0};
+                pd_g_mma8<MTG, true, true>(x0, x1, wh1, a0, a1, b0, b1, A.h1[par], MT, gn);
+                p1(g) = pd_g_rec_sum<true, TWOPASS>(lds, bias1, a0, a1, b0, b1, nullptr, A.twopass != 0);
+                PD_STAMP(role, 6 + 7 * g);
+            }
+        }
+    }
+}
+
+// a recurrent half of every group from the state in memory: LAYER 1 -> p(g) = h1_t . W1h + b1 (projection role), 2 -> h2_t . W2h + b2
+// (tiles below co_tiles sum in the projection launch's co-workers' 8-wave order)
+template <int GM, int MTG, int LAYER, bool TWOPASS, bool WAIT, class P>
+__device__ __forceinline__ void pd_g_rec_all(const PersistDecodeArgs& A, const float4 (&wh)[8], int t, int tile, float* lds, P p, PdShared* sh, int role, int zt) {
+    const int MT = A.MT;
+    if (WAIT) {
+        pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        if (sh->abort) return;
+    }
+    PD_STAMP(role, 7);
+    const float* hb = LAYER == 1 ? A.h1[t & 1] : A.h2[t & 1];
+    const float bias = (LAYER == 1 ? A.b1h : A.b2h)[tile * 16 + (threadIdx.x & 15)];
+    // (the summation order is a property of the tile: the branch encloses the whole phase -- first fragment loads included -- so that
+    // the fragments carried from group to group belong to ONE arm: shared between the arms, the allocator gave every re-requested
+    // fragment a register of its own and spilled)
+    if (LAYER == 1 || tile >= A.co_tiles) {
+        float4 x0[8], x1[8];
+        pd_g_xload<MTG, 0, 8, 8>(hb, MT, 0, x0, x1);
+        PD_PIN();
+#pragma unroll
+        for (int g = 0; g < GM; ++g) {
+            if (g < A.G) {
+                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+                pd_g_mma8<MTG, true, true>(x0, x1, wh, a0, a1, b0, b1, hb, MT, min(g + 1, A.G - 1));
+                p(g) = pd_g_rec_sum<true, TWOPASS>(lds, bias, a0, a1, b0, b1, nullptr, A.twopass != 0);
+                PD_STAMP(role, 8 + 7 * g);
+            }
+        }
+    } else {
+        float4 x0[8], x1[8];
+        pd_g_xload<MTG, 0, 8, 8>(hb, MT, 0, x0, x1);
+        PD_PIN();
+#pragma unroll
+        for (int g = 0; g < GM; ++g) {
+            if (g < A.G) {
+                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
+                pd_g_mma8<MTG, false, true>(x0, x1, wh, a0, a1, b0, b1, hb, MT, min(g + 1, A.G - 1));
+                p(g) = pd_g_rec_sum<false, TWOPASS>(lds, bias, a0, a1, b0, b1);
+                PD_STAMP(role, 8 + 7 * g);
+            }
+        }
+    }
+}
+
+// a tile's four GEMM halves for every group; CHAIN: utterance blockIdx.x's chain first, the tile's weights streamed -- each requested a
+// phase ahead of its use
 template <int GM, int MTG, bool CHAIN>
 __device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float* smem, PdShared* sh) {
     float* lds = smem;
@@ -984,10 +1174,14 @@ __device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float*
     PdG<GM> S;
 #pragma unroll
     for (int g = 0; g < GM; ++g) { S.c1[g] = 0.f; S.c2[g] = 0.f; S.p1[g] = A.b1h[tile * 16 + col]; S.p2[g] = A.b2h[tile * 16 + col]; }
+    auto c1 = [&](int g) -> float& { return S.c1[g]; };
+    auto c2 = [&](int g) -> float& { return S.c2[g]; };
+    auto p1 = [&](int g) -> float& { return S.p1[g]; };
+    auto p2 = [&](int g) -> float& { return S.p2[g]; };
     PdChainLds L{};
     PdChainRegs R{};
     if (CHAIN) {
-        L = pd_carve(smem, A.tvp);
+        L = pd_carve(smem, A.tvp, A.twopass ? 8 : 16);
         R.Tv = A.tok_len ? max(1, min(A.Tv, (int)A.tok_len[b])) : A.Tv;
         R.drop = A.drop_rate > 0.f;
         R.hashed = R.drop && A.keep_hash != 0;
@@ -1010,7 +1204,7 @@ __device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float*
     __syncthreads();
     // The chain needs the whole register file (all of prenet 1's weights in flight): the tile's per-group state -- cell states,
     // recurrent halves -- waits in memory meanwhile (its own rows of `stash`, written and re-read by the same thread: L2 hits,
-    // requested back before the first flag wait).  Left in registers it spills to scratch, whose reloads wait for vmcnt(0).
+    // requested back before the first flag wait).
     for (int t = 0; t < A.steps; ++t) {
         PD_STAMP(role, 0);
         PD_ZT(zt);
@@ -1027,6 +1221,7 @@ __device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float*
             asm volatile("" : "+s"(bs));
             pd_chain<false>(A, L, R, t, bs, sh, unused, zt);
             if (sh->abort) return;
+            PD_STAMP(role, 1);
             PD_PIN();
             pd_load_tile<3>(A.w1x, tile, W.x1);
 #pragma unroll
@@ -1034,86 +1229,58 @@ __device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float*
                 S.c1[g] = st[(4 * g + 0) * PD_NT]; S.c2[g] = st[(4 * g + 1) * PD_NT];
                 S.p1[g] = st[(4 * g + 2) * PD_NT]; S.p2[g] = st[(4 * g + 3) * PD_NT];
             }
+            pd_load_tile<8>(A.w2x, tile, W.x2); pd_load_tile<8>(A.w1h, tile, W.h1);        // (for the NEXT phase: they arrive during cell 1)
         }
-#pragma unroll
-        for (int g = 0; g < GM; ++g)
-            if (g < A.G) {
-                pd_g_cell1_one<MTG>(A, W.x1, t, tile, lds, S.c1[g], S.p1[g], g, sh, role, zt);
-                if (sh->abort) return;
-            }
-        if (CHAIN) { pd_load_tile<8>(A.w2x, tile, W.x2); pd_load_tile<8>(A.w1h, tile, W.h1); }
-#pragma unroll
-        for (int g = 0; g < GM; ++g)
-            if (g < A.G) {
-                pd_g_cell2_one<MTG, true, CHAIN>(A, W.x2, W.h1, t, tile, lds, S.c2[g], S.p2[g], S.p1[g], g, sh, role, zt);
-                if (sh->abort) return;
-            }
-        PD_STAMP(role, 12);
+        pd_g_cell1_all<GM, MTG>(A, W.x1, t, tile, lds, c1, p1, sh, role, zt);
+        if (sh->abort) return;
+        pd_g_cell2_all<GM, MTG, true, CHAIN, CHAIN>(A, W.x2, W.h1, W.h2, t, tile, lds, c2, p2, p1, sh, role, zt);
+        if (sh->abort) return;
         if (t + 1 == A.steps) break;
-        if (CHAIN) pd_load_tile<8>(A.w2h, tile, W.h2);
-#pragma unroll
-        for (int g = 0; g < GM; ++g)
-            if (g < A.G) {
-                S.p2[g] = pd_g_rec2_one<MTG, CHAIN, true>(A, W.h2, t, tile, lds, g, sh, zt);
-                if (sh->abort) return;
-            }
-        PD_STAMP(role, 14);
+        pd_g_rec_all<GM, MTG, 2, CHAIN, true>(A, W.h2, t, tile, lds, p2, sh, role, zt);
+        if (sh->abort) return;
     }
 }
 
-// a projection (tile, M-tile of the group) + the LSTM tile; the projection of group g - 1 follows cell 2 of group g, so that the
-// chains of the early groups start while the later groups are still in their cells.  Resident: the layer-2 input half and the
-// projection tile; W1x (24 KB) is streamed at the start of every step (it arrives while the workgroup waits for the chains), the
-// recurrent halves' tiles behind the projection as in the one-group kernel; the per-group state (cell states, recurrent halves)
-// lives in LDS behind the slabs -- this role has no chain and the LDS to spare, and not the registers.
+// a projection (tile, M-tile of the group) + the LSTM tile.  Resident: the layer-2 input half, the layer-1 recurrent half (fused into
+// cell 2 as in the tile roles: as a pass of its own over h1 behind the projections it made this role the last to finish every step,
+// and every other workgroup waited for its cell-1 arrivals: v1 of this kernel, 60 us per step at 128 rows) ;
+// W1x (24 KB) is streamed at the start of every step (it arrives while the workgroup waits for the chains), the projection tile in
+// front of the wait for the h2 arrivals, the layer-2 recurrent tile behind the projections; the per-group state (cell states, recurrent halves) lives in LDS behind the slabs -- this
+// role has no chain and the LDS to spare, and not the registers.
 template <int GM, int MTG>
 __device__ __forceinline__ void pd_g_run_proj(const PersistDecodeArgs& A, float* lds, PdShared* sh) {
     const int tile = blockIdx.x, col = threadIdx.x & 15;
     const int pi = tile - A.n_chain, ptile = pi % A.pj_tiles, pm = pi / A.pj_tiles;
     PdW W;
-    pd_load_tile<8>(A.w2x, tile, W.x2);
-    float4 wpj[9];
-    pd_load_tile<9>(A.wp, ptile, wpj);
+    pd_load_tile<8>(A.w2x, tile, W.x2); pd_load_tile<8>(A.w1h, tile, W.h1);
     float* sl = lds + 16 * PD_SLAB + threadIdx.x;           // [4 GM][512]: c1, c2, p1, p2 of group g at rows 4 g ..
 #pragma unroll
     for (int g = 0; g < GM; ++g) { sl[(4 * g + 0) * PD_NT] = 0.f; sl[(4 * g + 1) * PD_NT] = 0.f; sl[(4 * g + 2) * PD_NT] = A.b1h[tile * 16 + col]; sl[(4 * g + 3) * PD_NT] = A.b2h[tile * 16 + col]; }
+    auto c1 = [&](int g) -> float& { return sl[(4 * g + 0) * PD_NT]; };
+    auto c2 = [&](int g) -> float& { return sl[(4 * g + 1) * PD_NT]; };
+    auto p1 = [&](int g) -> float& { return sl[(4 * g + 2) * PD_NT]; };
+    auto p2 = [&](int g) -> float& { return sl[(4 * g + 3) * PD_NT]; };
     for (int t = 0; t < A.steps; ++t) {
         PD_STAMP(1, 0);
         PD_ZT(zt);
         pd_load_tile<3>(A.w1x, tile, W.x1);
-#pragma unroll
-        for (int g = 0; g < GM; ++g)
-            if (g < A.G) {
-                float c1v = sl[(4 * g + 0) * PD_NT];
-                pd_g_cell1_one<MTG>(A, W.x1, t, tile, lds, c1v, sl[(4 * g + 2) * PD_NT], g, sh, 1, zt);
-                if (sh->abort) return;
-                sl[(4 * g + 0) * PD_NT] = c1v;
-            }
-#pragma unroll
-        for (int g = 0; g < GM; ++g)
-            if (g < A.G) {
-                float unused = 0.f, c2v = sl[(4 * g + 1) * PD_NT];
-                pd_g_cell2_one<MTG, false, false>(A, W.x2, W.h1, t, tile, lds, c2v, sl[(4 * g + 3) * PD_NT], unused, g, sh, 1, zt);
-                if (sh->abort) return;
-                sl[(4 * g + 1) * PD_NT] = c2v;
-                if (g >= 1) {
-                    pd_proj(A, wpj, t, ptile, MTG * (g - 1) + pm, lds, sh, g - 1);
-                    if (sh->abort) return;
-                }
-            }
-        pd_proj(A, wpj, t, ptile, MTG * (A.G - 1) + pm, lds, sh, A.G - 1);
+        pd_g_cell1_all<GM, MTG>(A, W.x1, t, tile, lds, c1, p1, sh, 1, zt);
         if (sh->abort) return;
-        if (t + 1 == A.steps) break;
-        pd_load_tile<8>(A.w1h, tile, W.h1);
-        PD_PIN();
+        pd_g_cell2_all<GM, MTG, true, false, false>(A, W.x2, W.h1, W.h2, t, tile, lds, c2, p2, p1, sh, 1, zt);
+        if (sh->abort) return;
+        // every group's projection behind ONE wait for the h2 arrivals (the chains that need them start ~10 us later: their
+        // workgroups still have this step's recurrent halves to multiply); the projection tile (72 KB) arrives during that wait
+        float4 wpj[9];
+        pd_load_tile<9>(A.wp, ptile, wpj);
+        pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        if (sh->abort) return;
 #pragma unroll
         for (int g = 0; g < GM; ++g)
-            if (g < A.G) sl[(4 * g + 2) * PD_NT] = pd_g_rec1_mem_one<MTG, false>(A, W.h1, t, tile, lds, g);
+            if (g < A.G) pd_proj<true>(A, wpj, t, ptile, MTG * g + pm, lds, sh, g);
+        if (t + 1 == A.steps) break;
         pd_load_tile<8>(A.w2h, tile, W.h2);
         PD_PIN();
-#pragma unroll
-        for (int g = 0; g < GM; ++g)
-            if (g < A.G) sl[(4 * g + 3) * PD_NT] = pd_g_rec2_one<MTG, false, false>(A, W.h2, t, tile, lds, g, sh, zt);     // (its counter was seen by the projection)
+        pd_g_rec_all<GM, MTG, 2, false, false>(A, W.h2, t, tile, lds, p2, sh, 1, zt);
     }
 }
 
@@ -1173,7 +1340,7 @@ const PdKernel kPdKernels[] = {gt_persist_decode_kernel, gt_persist_decode_g_ker
 
 hipError_t gt_persist_decode_init() {
     for (PdKernel k : kPdKernels) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, pd_lds_floats(PD_TVMAX) * 4);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, pd_lds_floats(PD_TVMAX, true) * 4);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1184,7 +1351,7 @@ int gt_persist_decode_blocks_per_cu() {
     int worst = 1 << 30;
     for (PdKernel k : kPdKernels) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), PD_NT, (size_t)pd_lds_floats(PD_TVMAX) * 4) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(k), PD_NT, (size_t)pd_lds_floats(PD_TVMAX, true) * 4) != hipSuccess) return 0;
         worst = n < worst ? n : worst;
     }
     return worst;
@@ -1195,9 +1362,11 @@ hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a_in, const float* 
     int mtg = 2;
     const PdKernel k = pd_kernel_for(a.B, split16, &a.G, &mtg);
     a.tvp = (a.Tv + 63) / 64 * 64;
-    a.n_chain = a.G == 1 && mtg == 2 && k == gt_persist_decode_kernel ? PD_UTT : a.B;
+    const bool gk = k != gt_persist_decode_kernel;
+    a.n_chain = gk ? a.B : PD_UTT;
+    a.twopass = pd_chain_slabs(a.tvp, gk) == 8 ? 1 : 0;
     const int n = PD_CTL_WORDS > a.B * PD_P ? PD_CTL_WORDS : a.B * PD_P;
     hipLaunchKernelGGL(gt_persist_decode_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.z0g, b0, a.ctl, a.B);
-    hipLaunchKernelGGL(k, dim3(PD_NWG), dim3(PD_NT), (size_t)pd_lds_floats(a.tvp) * 4, stream, a);
+    hipLaunchKernelGGL(k, dim3(PD_NWG), dim3(PD_NT), (size_t)pd_lds_floats(a.tvp, gk) * 4, stream, a);
     return hipGetLastError();
 }
