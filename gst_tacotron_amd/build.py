@@ -47,6 +47,9 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LAST_BUILD = {"compiled": [], "linked": False, "mode": "not run"}     # what the last build() call actually did (reported by __graft_entry__.build)
+
+
 def build(force=False, verbose=False, debug=False):
     """debug=True adds -DGSTTACO_DEBUG: the experiment knobs are compiled in.  Never the default."""
     global FLAGS
@@ -76,8 +79,13 @@ def build(force=False, verbose=False, debug=False):
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
                 print(warn)
-    if force or jobs or _stale(LIB, objs):
+    linked = bool(force or jobs or _stale(LIB, objs))
+    if linked:
         run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    LAST_BUILD["compiled"] = [os.path.basename(j[-3]) for j in jobs]
+    LAST_BUILD["linked"] = linked
+    LAST_BUILD["mode"] = ("compiled all sources" if len(jobs) == len(SOURCES) else "compiled %d of %d sources" % (len(jobs), len(SOURCES)) if jobs
+                          else "relinked" if linked else "reused the up-to-date in-tree library")
     with open(FLAGS_STAMP, "w") as f:
         f.write(" ".join([_hipcc()] + FLAGS))
     return LIB

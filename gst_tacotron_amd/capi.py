@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgsttaco.so")
 
 MAX_LAYERS = 8
-ABI_VERSION = 11
+ABI_VERSION = 12
 ATT_CODES = {"BMA": 0, "SMA": 1, "LSA": 2}
 
 # every symbol include/gsttaco.h declares

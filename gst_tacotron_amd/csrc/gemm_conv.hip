@@ -931,7 +931,23 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         }
     }
     if (a.conv2d) {
-        if ((size_t)a.B * a.xb * 4 >= 0x7FFFFFFFull) return hipErrorInvalidValue;      // (the 2-D gather addresses the input as one buffer resource)
+        if ((size_t)a.B * a.xb * 4 >= 0x7FFFFFFFull) {
+            // the 2-D gather addresses the input as ONE buffer resource (< 2 GiB): a larger input goes slice by slice over the batch
+            if ((size_t)a.xb * 4 >= 0x7FFFFFFFull) return hipErrorInvalidValue;        // (one utterance alone is too large)
+            const int per = (int)(0x7FFFFFFEull / ((size_t)a.xb * 4));
+            for (int b0 = 0; b0 < a.B; b0 += per) {
+                ConvGemmArgs s2 = a;
+                s2.B = a.B - b0 < per ? a.B - b0 : per;
+                s2.x = a.x + (size_t)b0 * a.xb;
+                s2.out = a.out + (size_t)b0 * a.T * a.ldo;
+                if (a.res) s2.res = a.res + (size_t)b0 * a.T * a.ldo;
+                if (a.rowbias) s2.rowbias = a.rowbias + (size_t)b0 * a.N;
+                if (a.row_len) s2.row_len = a.row_len + b0;
+                const hipError_t e = gt_launch_conv_gemm(s2, stream);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
         if (a.N > 64) hipLaunchKernelGGL((gt_conv_gemm_kernel<1, 4, 1, 1, true>), dim3((M + 31) / 32, (a.N + 127) / 128), dim3(256), 0, stream, a);
         else if (a.N > 32) hipLaunchKernelGGL((gt_conv_gemm_kernel<4, 1, 1, 2, true>), dim3((M + 127) / 128, 1), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((gt_conv_gemm_kernel<4, 1, 1, 1, true>), dim3((M + 127) / 128, 1), dim3(256), 0, stream, a);

@@ -103,6 +103,12 @@ struct gsttaco_ctx {
     // device memory
     std::vector<void*> allocs;
     hipStream_t cap_stream = nullptr;
+    // GSTTACO_GST_FORK=1: the GST branch (six small convolutions + the tail, ~0.25 ms of mostly idle GPU) runs on a side stream beside
+    // the text encoder's CONVOLUTIONS and joins in front of its persistent BiLSTM launch (beside THAT launch it cost a millisecond:
+    // EXPERIMENTS round 3, item 2b)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool gst_fork = false;
 
     // weights on device
     float* d_emb = nullptr;
@@ -206,7 +212,7 @@ struct gsttaco_ctx {
     float *w_p1 = nullptr, *w_xa = nullptr, *w_q = nullptr, *w_h1[2] = {nullptr, nullptr},
           *w_h2[2] = {nullptr, nullptr}, *w_c1 = nullptr, *w_c2 = nullptr;
     // bf16 mirrors of the blocked decoder activations (kernels.h gt_blk_off_h): mixed precision, batches above 32 rows
-    uint16_t *w_xa_h = nullptr, *w_h1_h[2] = {nullptr, nullptr}, *w_h2_h[2] = {nullptr, nullptr};
+    uint16_t *w_xa_h = nullptr, *w_xa2_h = nullptr, *w_h1_h[2] = {nullptr, nullptr}, *w_h2_h[2] = {nullptr, nullptr};
     float *w_pre = nullptr, *w_stop = nullptr, *w_align = nullptr, *w_post[2] = {nullptr, nullptr},
           *w_mel = nullptr;
     size_t zero_floats = 0;
@@ -697,12 +703,22 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
 }
 
 // ------------------------------------------------------------------------------------------------ enqueue
-int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked) {
+int enqueue_gst(gsttaco_ctx* c, hipStream_t s, int B, int Tref1);
+
+// gst_Tref1 > 0: the GST branch is forked onto the side stream here and joined in front of the BiLSTM (gsttaco_ctx::gst_fork)
+int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, int gst_Tref1 = 0) {
     const int32_t* tlen = masked ? c->w_tok_len : nullptr;      // masked-mode extension
     const gsttaco_config& g = c->cfg;
     const float* x = c->d_emb;
     const int32_t* tok = c->w_tokens;
     int cur = 0;
+    if (gst_Tref1 > 0) {
+        HIPCHECK(c, hipEventRecord(c->ev_fork, s));
+        HIPCHECK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        const int rg = enqueue_gst(c, c->side_stream, B, gst_Tref1);
+        if (rg) return rg;
+        HIPCHECK(c, hipEventRecord(c->ev_join, c->side_stream));
+    }
     for (int i = 0; i < g.n_enc_conv; ++i) {
         const ConvLayer& L = c->enc_conv[i];
         ConvGemmArgs a{};
@@ -717,6 +733,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked) {
     }
     // BiLSTM: one launch per time step, both directions in grid.z; h is written straight into enc_out.
     const int H = g.enc_rnn, C = c->conv_c, EO = c->enc_out;
+    if (gst_Tref1 > 0) HIPCHECK(c, hipStreamWaitEvent(s, c->ev_join, 0));
     HIPCHECK(c, gt_launch_zero(c->w_cenc, (size_t)2 * B * H, s));
     if (lean_bilstm_usable(c, c->enc_lean, B)) return enqueue_lean_bilstm(c, s, c->enc_lean, x, B, Tv, c->w_cenc, c->w_enc, tlen);
     for (int t = 0; t < Tv; ++t) {
@@ -845,8 +862,27 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     const int MT = (B + 15) / 16;
     const size_t BLK = (size_t)MT * 256;        // floats per k-block of a blocked activation buffer
     const int64_t ld_pre = (int64_t)steps * r * mel;
-    HIPCHECK(c, gt_launch_zero(c->w_h1[1], (size_t)MT * 16 * H1, s));
-    HIPCHECK(c, gt_launch_zero(c->w_h2[1], (size_t)MT * 16 * H2, s));
+    // ---- the whole loop as ONE persistent launch (persist_decode.hip): fp32, batch <= 128 (above 32 rows: groups of 32 through one set of
+    // resident weights), T_v <= 256, the reference's decoder sizes, SMA / BMA -- while this is the process's only live context (its
+    // hand-offs need every workgroup resident).  Bitwise the launches below (GPU test), which stay the path for every other shape, for
+    // several contexts, and after a give-up.  It keeps its state in registers and initialises it itself: none of the launch path's
+    // zero-fill launches (and their boundaries) is enqueued for it.
+    // (mixed precision: the bf16 kernel -- every GEMM pack bf16, the activation mirrors allocated, one group of up to 64 rows)
+    const int n_bf16 = c->lstm_x[0].bf16 + c->lstm_x[1].bf16 + c->lstm_h[0].bf16 + c->lstm_h[1].bf16 + c->proj_z.bf16;
+    const bool persist_bf16 = n_bf16 == 5 && c->w_xa_h && c->w_xa2_h && c->w_h1_h[0] && c->w_h2_h[0];
+    const bool persist_base = c->persist_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->front_mode >= 2 &&
+                              (n_bf16 == 0 || persist_bf16) && c->proj_z.wp != nullptr && c->proj.nkb >= 32 &&
+                              c->worker_tiles == 2 && c->co_worker_tiles == 1 && g.att_type != GSTTACO_ATT_LSA &&
+                              gt_dec_front_supported(mel, P0, P1, att, Tv) && c->lstm_x[0].nkb == 24 && c->lstm_x[1].nkb == 64 && c->lstm_h[0].nkb == 64 &&
+                              c->lstm_h[1].nkb == 64 && B <= c->persist_rows && (B <= 16 || !c->persist_split16 || c->w_stash) && (B <= 32 || c->w_stash) &&
+                              gt_persist_decode_supported(mel, r, P0, P1, att, H1, H2, B, Tv, c->proj_z.ntiles, c->proj_z.nkb, c->persist_slots, c->persist_split16,
+                                                          persist_bf16 ? 1 : 0);
+    if (!persist_base) {
+        HIPCHECK(c, gt_launch_zero(c->w_h1[1], (size_t)MT * 16 * H1, s));
+        HIPCHECK(c, gt_launch_zero(c->w_h2[1], (size_t)MT * 16 * H2, s));
+        HIPCHECK(c, gt_launch_zero(c->w_c1, (size_t)B * H1, s));
+        HIPCHECK(c, gt_launch_zero(c->w_c2, (size_t)B * H2, s));
+    }
     // Mixed precision above 32 rows: the producers of the blocked activations (front launch: prenet output + context; LSTM launches:
     // h1, h2) also write bf16 MIRRORS, which the bf16 multi-chunk GEMM bodies read instead -- half the activation bytes through
     // each CU's load pipe, which is what bounds those launches (EXPERIMENTS round 4), and no conversion per consumer.  Only when
@@ -854,12 +890,10 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     const bool mirror = B > 32 && c->w_xa_h != nullptr && c->fused_front && c->split_rec && c->lean && c->keep_x_weights &&
                         g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv) &&
                         gt_lstm_x_supported(c->lstm_x[0].nkb) && gt_lstm_x_supported(c->lstm_x[1].nkb) && c->lstm_h[0].nkb == 64 && c->lstm_h[1].nkb == 64;
-    if (mirror) {
+    if (mirror && !persist_base) {
         HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_h1_h[1]), (size_t)MT * 16 * H1 / 2, s));
         HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_h2_h[1]), (size_t)MT * 16 * H2 / 2, s));
     }
-    HIPCHECK(c, gt_launch_zero(c->w_c1, (size_t)B * H1, s));
-    HIPCHECK(c, gt_launch_zero(c->w_c2, (size_t)B * H2, s));
     if (g.att_type == GSTTACO_ATT_LSA) HIPCHECK(c, gt_launch_zero(c->w_lsa_state, (size_t)B * Tv, s));   // Layers.py:356
     // both LSTM cells in one launch (skinny_gemm.hip gt_lstm12_kernel): fp32 lean shapes, batch <= 32, one live context
     // (batch <= 32: fp32; above: the multi-chunk form, fp32 or bf16)
@@ -868,7 +902,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     const bool fuse12_small = fuse_base && !c->lstm_x[0].bf16 && gt_lstm12_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->fuse12_slots[0]);
     const bool fuse12_mc = fuse_base && gt_lstm12_mc_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->fuse12_slots[c->lstm_x[0].bf16 ? 2 : 1]);
     const bool fuse12 = fuse12_small || fuse12_mc;
-    if (fuse12) HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_arrive), (size_t)steps * GT_L12_NSH * 32, s));
+    if (fuse12 && !persist_base) HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_arrive), (size_t)steps * GT_L12_NSH * 32, s));
     const float drop_scale = g.prenet_rate > 0.f ? 1.0f / (1.0f - g.prenet_rate) : 1.f;
     const size_t mask_step = (size_t)B * (P0 + P1);
     // throughput mode: the whole decode's dropout masks and sigmoid noise are generated up front (same Philox streams the
@@ -900,19 +934,12 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     // (batches above 32 rows: every launch is throughput-bound, the front launch most of all, and the projection launch has
     // ~150 CUs to spare: it takes half of layer 2's recurrent tiles instead of a quarter)
     const int co_tiles = std::max(0, std::min(c->lstm_h[1].ntiles, c->co_tiles >= 0 ? c->co_tiles : (B > 32 ? 128 : 64)));
-    // ---- the whole loop as ONE persistent launch (persist_decode.hip): the headline shape class -- fp32, batch <= 32, T_v <= 128, the
-    // reference's decoder sizes, SMA / BMA -- while this is the process's only live context (its hand-offs need every workgroup resident).
-    // Bitwise the launches below (GPU test), which stay the path for every other shape, for several contexts, and after a give-up.
     {
-        const bool base = c->persist_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->front_mode >= 2 &&
-                          !c->lstm_x[0].bf16 && !c->lstm_x[1].bf16 && !c->proj_z.bf16 && c->proj_z.wp != nullptr && c->proj.nkb >= 32 &&
-                          c->worker_tiles == 2 && c->co_worker_tiles == 1 && g.att_type != GSTTACO_ATT_LSA &&
-                          gt_dec_front_supported(mel, P0, P1, att, Tv) && c->lstm_x[0].nkb == 24 && c->lstm_x[1].nkb == 64 && c->lstm_h[0].nkb == 64 &&
-                          c->lstm_h[1].nkb == 64 &&
-                          B <= c->persist_rows &&
-                          gt_persist_decode_supported(mel, r, P0, P1, att, H1, H2, B, Tv, c->proj_z.ntiles, c->proj_z.nkb, c->persist_slots, c->persist_split16);
+        // (randomness: hashed keep decisions, or the masks / noise in the buffers -- injected, or generated above -- always one of them)
         const bool hashed = !injected_mask && g.prenet_rate == 0.5f && c->keep_hash;
-        if (base && (g.prenet_rate == 0.f || hashed || has_mask) && (g.sigmoid_noise == 0.f || has_noise)) {
+        if (persist_base) {
+            if (!((g.prenet_rate == 0.f || hashed || has_mask) && (g.sigmoid_noise == 0.f || has_noise)))
+                return fail(c, GSTTACO_E_INVALID, "internal: the persistent decode launch was chosen without its randomness");
             PersistDecodeArgs a{};
             a.w1x = c->lstm_x[0].wp; a.w1h = c->lstm_h[0].wp; a.b1h = c->lstm_h[0].bias;
             a.w2x = c->lstm_x[1].wp; a.w2h = c->lstm_h[1].wp; a.b2h = c->lstm_h[1].bias;
@@ -928,6 +955,9 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             a.xa[0] = c->w_xa; a.xa[1] = c->w_xa2;
             a.h1[0] = c->w_h1[0]; a.h1[1] = c->w_h1[1]; a.h2[0] = c->w_h2[0]; a.h2[1] = c->w_h2[1];
             a.stash = c->w_stash;
+            a.bf16 = persist_bf16 ? 1 : 0;
+            a.xah[0] = c->w_xa_h; a.xah[1] = c->w_xa2_h;
+            a.h1h[0] = c->w_h1_h[0]; a.h1h[1] = c->w_h1_h[1]; a.h2h[0] = c->w_h2_h[0]; a.h2h[1] = c->w_h2_h[1];
             a.z0g = c->w_z0g; a.hpart = c->w_hpart; a.ctl = c->w_pctl; a.err = c->w_err + 2;        // (its own give-up word)
             a.pre = c->w_pre; a.ld_pre = ld_pre; a.stop = c->w_stop; a.align = c->w_align; a.ld_align = (int64_t)steps * Tv;
             a.B = B; a.MT = MT; a.Tv = Tv; a.steps = steps; a.co_tiles = co_tiles;
@@ -1187,7 +1217,8 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
         // LDS anyway, so no result changes and half the bytes move; the residual input and the last layer's output stay fp32
         if (c->cfg.mixed_precision && c->bf16_w.count(L.w)) {
             a.x_bf16 = i > 0 && c->bf16_w.count(c->post_conv[i - 1].w) ? 1 : 0;
-            a.out_bf16 = !last && c->bf16_w.count(c->post_conv[i + 1].w) ? 1 : 0;
+            // (a bf16 output row is stored as PAIRS of columns: an even channel count only)
+            a.out_bf16 = !last && L.cout % 2 == 0 && c->bf16_w.count(c->post_conv[i + 1].w) ? 1 : 0;
         }
         HIPCHECK(c, launch_conv(c, a, s));
         x = a.out; cur ^= 1;
@@ -1463,8 +1494,11 @@ void recover_from_give_up(gsttaco_ctx* c) {
 template <typename F>
 int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F body, bool persist_segment = false) {
     recover_from_give_up(c);
-    std::lock_guard<std::mutex> lock(g_persist_mu);
+    // The process-wide mutex guards the two event tables and -- for segments with a persistent BiLSTM launch only -- the order in which
+    // such segments are chained on the GPU.  Every other segment is captured / instantiated / launched OUTSIDE it: several contexts on
+    // several threads do not serialise their host-side enqueue on one lock.
     {   // another context's fused launches may still be in flight: this segment starts behind them (see g_fused_event)
+        std::lock_guard<std::mutex> lock(g_persist_mu);
         auto it = g_fused_event.find(c->cfg.device);
         if (it != g_fused_event.end() && it->second.ev && it->second.owner != c) HIPCHECK(c, hipStreamWaitEvent(stream, it->second.ev, 0));
     }
@@ -1472,6 +1506,7 @@ int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F bod
     if (!(persist_segment && c->bilstm_persist)) {
         rc = run_cached_inner(c, stream, key_in, body);
     } else {
+        std::lock_guard<std::mutex> lock(g_persist_mu);        // (wait -> enqueue -> record must not interleave with another context's)
         hipEvent_t& ev = g_persist_event[c->cfg.device];
         if (!ev) HIPCHECK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else HIPCHECK(c, hipStreamWaitEvent(stream, ev, 0));
@@ -1479,6 +1514,7 @@ int run_cached(gsttaco_ctx* c, hipStream_t stream, const GraphKey& key_in, F bod
         HIPCHECK(c, hipEventRecord(ev, stream));
     }
     if (!rc && (c->fuse12_now || c->persist_now) && (key_in.kind == 0 || key_in.kind == 3)) {      // the segment held fused / persistent decode launches
+        std::lock_guard<std::mutex> lock(g_persist_mu);
         FusedInFlight& f = g_fused_event[c->cfg.device];
         if (!f.ev) HIPCHECK(c, hipEventCreateWithFlags(&f.ev, hipEventDisableTiming));
         HIPCHECK(c, hipEventRecord(f.ev, stream));
@@ -1636,6 +1672,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->persist_decode = env_int("GSTTACO_PERSIST_DECODE", 1) != 0;
     c->persist_rows = env_int("GSTTACO_PERSIST_ROWS", 128);
     c->persist_split16 = env_int("GSTTACO_PERSIST_SPLIT16", 0) != 0 ? 1 : 0;
+    c->gst_fork = env_int("GSTTACO_GST_FORK", 0) != 0;
     c->wino = env_int("GSTTACO_WINO", 4);
     if (c->wino != 0 && c->wino != 2) c->wino = 4;      // {0, 2, 4}; any other non-zero value (the old boolean's 1 included) means the default
     c->stamps = env_int("GSTTACO_STAMPS", 0) == 1;
@@ -1667,6 +1704,9 @@ void gsttaco_destroy(gsttaco_ctx* c) {
     for (int l = 0; l < 5; ++l)
         for (auto e : c->prof_ev[l]) (void)hipEventDestroy(e);
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
 
 
     for (void* p : c->allocs) (void)hipFree(p);
@@ -1721,6 +1761,9 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     if (!strstr(prop.gcnArchName, "gfx950"))
         return fail(c, GSTTACO_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     HIPCHECK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    HIPCHECK(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+    HIPCHECK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHECK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     if (prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
 
     int rc = 0;
@@ -1966,11 +2009,14 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     const size_t Bp = (B + 15) / 16 * 16;       // blocked activation buffers hold whole 16-row tiles
     if ((rc = fa(&c->w_xa, Bp * (c->P1 + c->att)))) return rc;
     HIPCHECK(c, hipMemset(c->w_xa, 0, Bp * (c->P1 + c->att) * sizeof(float)));
-    if (c->lstm_x[0].bf16 && c->lstm_x[1].bf16 && c->lstm_h[0].bf16 && c->lstm_h[1].bf16 && c->proj.bf16 && Bp > 32 &&
+    if (c->lstm_x[0].bf16 && c->lstm_x[1].bf16 && c->lstm_h[0].bf16 && c->lstm_h[1].bf16 && c->proj.bf16 &&
         (c->P1 + c->att) % 32 == 0 && c->P1 % 32 == 0 && c->H1 % 32 == 0 && c->H2 % 32 == 0) {
         float* t = nullptr;
         if ((rc = fa(&t, Bp * (c->P1 + c->att) / 2))) return rc;
         c->w_xa_h = reinterpret_cast<uint16_t*>(t);
+        HIPCHECK(c, hipMemset(t, 0, Bp * (c->P1 + c->att) * 2));
+        if ((rc = fa(&t, Bp * (c->P1 + c->att) / 2))) return rc;        // (the persistent bf16 kernel ping-pongs it by step parity)
+        c->w_xa2_h = reinterpret_cast<uint16_t*>(t);
         HIPCHECK(c, hipMemset(t, 0, Bp * (c->P1 + c->att) * 2));
         for (int i = 0; i < 2; ++i) {
             if ((rc = fa(&t, Bp * c->H1 / 2))) return rc;
@@ -2242,12 +2288,13 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
     // (run_cached, g_persist_event); the segment between them -- GST, value projection, the decode loop, the postnet: 95 % of the
     // call -- overlaps freely with other contexts' work.  The encoder / vocoder segments share their cached graphs with
     // gsttaco_encode / gsttaco_vocoder.
-    GraphKey kenc{1, B, Tv, 0, 0, 0, 0, 0, masked};
-    if ((rc = run_cached(c, s, kenc, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv, masked); }, true))) return rc;
+    const bool fork = gst && c->gst_fork;
+    GraphKey kenc{fork ? 6 : 1, B, Tv, fork ? Tref1 : 0, 0, 0, 0, 0, masked};
+    if ((rc = run_cached(c, s, kenc, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv, masked, fork ? Tref1 : 0); }, true))) return rc;
     GraphKey key{0, B, Tv, Tref1, steps, mask != nullptr, noise != nullptr, c->prof_every, masked};
     rc = run_cached(c, s, key, [&](hipStream_t st) {
         int r2 = 0;
-        if (gst) r2 = enqueue_gst(c, st, B, Tref1);
+        if (gst && !fork) r2 = enqueue_gst(c, st, B, Tref1);
         if (!r2) r2 = enqueue_value_proj(c, st, B, Tv);
         if (!r2) r2 = enqueue_decode(c, st, B, Tv, steps, mask != nullptr, noise != nullptr, masked);
         if (!r2) r2 = enqueue_postnet(c, st, B, steps * c->r, c->w_pre, c->w_mel);

@@ -312,6 +312,8 @@ struct PersistDecodeArgs {
     // state / workspace
     float* xa[2];                                      // blocked [24][MT][256], ping-pong by step parity
     float* h1[2]; float* h2[2];                        // blocked [64][MT][256]
+    uint16_t* xah[2]; uint16_t* h1h[2]; uint16_t* h2h[2];  // mixed precision: the bf16 mirrors (gt_blk_off_h) of xa / h1 / h2, ping-pong by step parity
+    int bf16;                                          // 1: the bf16 kernel (weights are the bf16 packs, activations travel as mirrors only)
     uint2* z0g;                                        // [B][256] {value bits, step tag}
     float* hpart;                                      // [2][32][512] recurrent halves of the chain workgroups' tiles
     float* stash;                                      // [256][16][512] the group kernels' chain workgroups park their tile state here during the chain
@@ -328,7 +330,7 @@ struct PersistDecodeArgs {
     unsigned long long* dbg;                           // diagnostic stamps [3 roles][32] or NULL (GSTTACO_STAMPS=1)
 };
 size_t gt_persist_decode_ctl_words();
-bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots, int split16);
+bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots, int split16, int bf16);
 int gt_persist_decode_max_batch();
 hipError_t gt_persist_decode_init();                   // opt in to > 64 KiB dynamic LDS; once, outside stream capture
 int gt_persist_decode_blocks_per_cu();

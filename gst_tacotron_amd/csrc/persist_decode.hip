@@ -483,10 +483,10 @@ __host__ __device__ constexpr int pd_lds_floats(int tvp, bool group_kernel = fal
 }
 static_assert(16 * PD_P <= 8 * PD_SLAB && 8 * PD_A <= 8 * PD_SLAB, "the chain's partial sums alias the reduction slabs");
 static_assert(pd_lds_floats(PD_TVMAX, true) * 4 + 64 <= 160 * 1024 && pd_lds_floats(PD_TVMAX, false) * 4 + 64 <= 160 * 1024, "one utterance's chain state must fit a CU's LDS");
-__device__ __forceinline__ PdChainLds pd_carve(float* smem, int tvp, int nslab = 8) {
+__device__ __forceinline__ PdChainLds pd_carve(float* smem, int tvp, int nslab = 8, int slab_floats = PD_SLAB) {
     PdChainLds L;
     L.partial = smem; L.red = smem;
-    L.y0 = smem + nslab * PD_SLAB; L.y1 = L.y0 + PD_P; L.qs = L.y1 + PD_P; L.vs = L.qs + PD_A; L.sc = L.vs + PD_A; L.nz = L.sc + tvp; L.pv = L.nz + tvp;
+    L.y0 = smem + nslab * slab_floats; L.y1 = L.y0 + PD_P; L.qs = L.y1 + PD_P; L.vs = L.qs + PD_A; L.sc = L.vs + PD_A; L.nz = L.sc + tvp; L.pv = L.nz + tvp;
     L.al = L.pv + tvp; L.ks1 = L.al + tvp; L.tile = L.ks1 + PD_P;
     return L;
 }
@@ -495,7 +495,8 @@ struct PdChainRegs { float bias1, biasq, sbias; int Tv; uint64_t seed; bool hash
 
 // HELPED: the workgroup's layer-1 recurrent half comes from a helper workgroup (the one-group kernel) and is fetched here
 // zt: 0, or a per-step opaque zero (the group kernels: nothing of the chain's address arithmetic may be hoisted out of the step loop)
-template <bool HELPED>
+// MIRROR (mixed precision): the prenet output and the context leave as the bf16 mirror (kernels.h gt_blk_off_h) only
+template <bool HELPED, bool MIRROR = false>
 __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v, int zt = 0) {
     const int tid = threadIdx.x + zt, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -616,6 +617,13 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
     // ---- S2p: the prenet output leaves now (the LSTM-1 workgroups multiply it while the attention below runs)
     float* xa = A.xa[par];
     if (tid < 64) {
+        if (MIRROR) {
+            const float4 y = *reinterpret_cast<const float4*>(L.y1 + 4 * tid);
+            uint2 pk;
+            pk.x = (uint32_t)gt_bf16_bits(y.x) | ((uint32_t)gt_bf16_bits(y.y) << 16);
+            pk.y = (uint32_t)gt_bf16_bits(y.z) | ((uint32_t)gt_bf16_bits(y.w) << 16);
+            pd_st2_sc1(reinterpret_cast<uint2*>(A.xah[par] + gt_blk_off_h(b, 4 * tid, MT)), pk);
+        } else
         pd_st4_sc1(xa + gt_blk_off(b, 4 * tid, MT), *reinterpret_cast<const float4*>(L.y1 + 4 * tid));
         pd_drain();
         if (tid == 0) pd_st1_sc1(A.ctl + PD_F_P + b * PD_FS, (uint32_t)t + 1u);
@@ -760,6 +768,12 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
                 for (int w = 0; w < 8; ++w) z += L.red[w * PD_A + 4 * tid + e];
                 c[e] = z;
             }
+            if (MIRROR) {
+                uint2 pk;
+                pk.x = (uint32_t)gt_bf16_bits(c[0]) | ((uint32_t)gt_bf16_bits(c[1]) << 16);
+                pk.y = (uint32_t)gt_bf16_bits(c[2]) | ((uint32_t)gt_bf16_bits(c[3]) << 16);
+                pd_st2_sc1(reinterpret_cast<uint2*>(A.xah[par] + gt_blk_off_h(b, PD_P + 4 * tid, MT)), pk);
+            } else
             pd_st4_sc1(xa + gt_blk_off(b, PD_P + 4 * tid, MT), make_float4(c[0], c[1], c[2], c[3]));
         }
         pd_drain();
@@ -1299,6 +1313,341 @@ __global__ __launch_bounds__(PD_NT) void gt_persist_decode_g_kernel(PersistDecod
     else if (PD_GONLY < 0 || PD_GONLY == 2) pd_g_run_tile<GM, MTG, false>(A, smem, &sh);
 }
 
+// ====================================================================================================================== bf16
+// Mixed precision (Use_Mixed_Precision: bf16 GEMM operands, fp32 accumulation / state / epilogues; BASELINE configs[4]) on the
+// persistent launch: ONE group of up to 64 rows (four M-tiles).  On bf16 MFMA (v_mfma_f32_16x16x32_bf16) the step's GEMMs are a few
+// hundred nanoseconds; what a step costs is its dependent phases and their epilogues, so the batch is NOT cut into groups of 32 rows
+// (each with its own epilogues): a wave's fragments of four M-tiles are as many registers as two in fp32.  Roles as in the group
+// kernels: workgroup b < B runs utterance b's chain (fp32, as in the launch path) and its gate tile with streamed weights, the next
+// pj_tiles x MT own a projection (tile, M-tile), the rest are plain.  Activations travel ONLY as the bf16 mirrors the launch path's
+// multi-chunk bodies read (kernels.h gt_blk_off_h: the MFMA's A operand as is), rounded once (RNE) by their producer -- the same
+// values the launch path's consumers get, in the same k-block -> wave assignment and summation orders (lean_body.h
+// gt_lean_core_bf16 / gt_lean_mc on eight waves; the recurrent halves in the front launch's 16-wave or the projection launch's
+// 8-wave order): bitwise the launches.
+constexpr int PDH_MT = 4;
+struct PdWh { u32x4 x1[2], h1[4], x2[4], h2[4]; };
+constexpr int PDH_SLAB = PDH_MT * 16 * 17;
+
+template <int KPW32>
+__device__ __forceinline__ void pdh_load_tile(const float* wp, int tile, int nkb32, u32x4 (&dst)[KPW32]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u32x4* wl = reinterpret_cast<const u32x4*>(wp) + ((size_t)tile * nkb32 + wave) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < KPW32; ++i) dst[i] = wl[(size_t)((wave + i * PD_NW < nkb32) ? i : 0) * PD_NW * 64];      // (past the end: re-read, never multiplied)
+}
+// the wave's fragments of 32-k blocks kb_off + wave + 8 i (i < KPW32, those below nkb32) of a mirror, all PDH_MT M-tiles
+template <int KPW32>
+__device__ __forceinline__ void pdh_xload(const uint16_t* base, int MT, int nkb32, int kb_off, u32x4 (&x)[PDH_MT][KPW32]) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto rs = gt_rsrc(base, 0x7FFFF000u);
+#pragma unroll
+    for (int i = 0; i < KPW32; ++i) {
+        const int kb = kb_off + ((wave + i * PD_NW < nkb32) ? wave + i * PD_NW : wave);
+#pragma unroll
+        for (int mt = 0; mt < PDH_MT; ++mt) {
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (kb * MT + min(mt, MT - 1)) * 1024, 16);
+            __builtin_memcpy(&x[mt][i], &t, 16);
+        }
+    }
+}
+template <int KPW32, int OFF, int STRIDE>
+__device__ __forceinline__ void pdh_mma(const u32x4 (&x)[PDH_MT][KPW32], const u32x4 (&w)[KPW32], int nkb32, f32x4 (&acc)[PDH_MT]) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int i = OFF; i < KPW32; i += STRIDE) {
+        if (wave + i * PD_NW < nkb32) {
+            bf16x8 bw;
+            __builtin_memcpy(&bw, &w[i], 16);
+#pragma unroll
+            for (int mt = 0; mt < PDH_MT; ++mt) {
+                bf16x8 a;
+                __builtin_memcpy(&a, &x[mt][i], 16);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void pdh_spill(float* lds, int slab, const f32x4 (&acc)[PDH_MT]) {
+    float (*part)[PDH_MT * 16][17] = reinterpret_cast<float (*)[PDH_MT * 16][17]>(lds);
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < PDH_MT; ++mt)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part[slab][mt * 16 + q * 4 + v][r] = acc[mt][v];
+}
+// elements (row = tid >> 4, col) and (row + 32, col): base + the first NSLAB slabs in ascending order
+template <int NSLAB>
+__device__ __forceinline__ void pdh_reduce(float* lds, const float (&base)[2], float (&z)[2]) {
+    __syncthreads();
+    const float (*part)[PDH_MT * 16][17] = reinterpret_cast<const float (*)[PDH_MT * 16][17]>(lds);
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        float v = base[e];
+#pragma unroll
+        for (int w = 0; w < NSLAB; ++w) v += part[w][row + 32 * e][col];
+        z[e] = v;
+    }
+    __syncthreads();
+}
+// gates (pd_gates_store's arithmetic) of both elements; h leaves as the bf16 mirror only: 4 units = one 8-byte write-through store
+__device__ __forceinline__ void pdh_gates_store(const float (&z)[2], float (&c)[2], uint16_t* hh, int tile, int M, int MT) {
+    const int col = threadIdx.x & 15;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int row = (threadIdx.x >> 4) + 32 * e;
+        const float zf = __shfl_down(z[e], 4, 16), zg = __shfl_down(z[e], 8, 16), zo = __shfl_down(z[e], 12, 16);
+        float hv = 0.f;
+        if (col < 4 && row < M) {
+            const float gi = gt_sigmoid(z[e]), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
+            c[e] = __builtin_fmaf(gf, c[e], gi * gg);
+            hv = go * gt_tanh(c[e]);
+        }
+        const float h1v = __shfl_down(hv, 1, 16), h2v = __shfl_down(hv, 2, 16), h3v = __shfl_down(hv, 3, 16);
+        if (col == 0 && row < M) {
+            uint2 pk;
+            pk.x = (uint32_t)gt_bf16_bits(hv) | ((uint32_t)gt_bf16_bits(h1v) << 16);
+            pk.y = (uint32_t)gt_bf16_bits(h2v) | ((uint32_t)gt_bf16_bits(h3v) << 16);
+            pd_st2_sc1(reinterpret_cast<uint2*>(hh + gt_blk_off_h(row, tile * 4, MT)), pk);
+        }
+    }
+}
+// sums of a recurrent-half tile: 16-wave order (fragments 0, 2 -> a; 1, 3 -> b; 16 slabs, or two passes over 8) or 8-wave order
+template <bool ORDER16>
+__device__ __forceinline__ void pdh_rec(const u32x4 (&x)[PDH_MT][4], const u32x4 (&w)[4], float bias, float* lds, bool two, float (&p)[2]) {
+    const int wave = threadIdx.x >> 6;
+    const float b2[2] = {bias, bias};
+    if (ORDER16) {
+        f32x4 a[PDH_MT], b[PDH_MT];
+#pragma unroll
+        for (int mt = 0; mt < PDH_MT; ++mt) { a[mt] = f32x4{0, 0, 0, 0}; b[mt] = f32x4{0, 0, 0, 0}; }
+        pdh_mma<4, 0, 2>(x, w, 32, a);
+        pdh_mma<4, 1, 2>(x, w, 32, b);
+        if (two) {
+            float z1[2];
+            pdh_spill(lds, wave, a);
+            pdh_reduce<8>(lds, b2, z1);
+            pdh_spill(lds, wave, b);
+            pdh_reduce<8>(lds, z1, p);
+        } else {
+            pdh_spill(lds, wave, a);
+            pdh_spill(lds, wave + 8, b);
+            pdh_reduce<16>(lds, b2, p);
+        }
+    } else {
+        f32x4 a[PDH_MT];
+#pragma unroll
+        for (int mt = 0; mt < PDH_MT; ++mt) a[mt] = f32x4{0, 0, 0, 0};
+        pdh_mma<4, 0, 1>(x, w, 32, a);
+        pdh_spill(lds, wave, a);
+        pdh_reduce<8>(lds, b2, p);
+    }
+}
+struct PdHS { float c1[2], c2[2], p1[2], p2[2]; };
+
+__device__ __forceinline__ void pdh_cell1(const PersistDecodeArgs& A, const u32x4 (&wx1)[2], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role, int zt) {
+    const int par = t & 1, MT = A.MT;
+    pd_wait_flags_all(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, sh);
+    if (sh->abort) return;
+    PD_STAMP(role, 2);
+    u32x4 x[PDH_MT][2];
+    pdh_xload<2>(A.xah[par], MT, PD_KBP / 2 + PD_KBC / 2, 0, x);
+    PD_PIN();
+    f32x4 a[PDH_MT];
+#pragma unroll
+    for (int mt = 0; mt < PDH_MT; ++mt) a[mt] = f32x4{0, 0, 0, 0};
+    pdh_mma<2, 0, 1>(x, wx1, PD_KBP / 2 + PD_KBC / 2, a);
+    pdh_spill(lds, threadIdx.x >> 6, a);
+    float z[2];
+    pdh_reduce<8>(lds, S.p1, z);
+    pdh_gates_store(z, S.c1, A.h1h[par], tile + zt, A.B, MT);
+    pd_arrive(A.ctl + zt + PD_CNT3);
+    PD_STAMP(role, 3);
+}
+template <bool STREAM_H2>
+__device__ __forceinline__ void pdh_cell2(const PersistDecodeArgs& A, const u32x4 (&wx2)[4], const u32x4 (&wh1)[4], u32x4 (&wh2)[4], int t, int tile, float* lds, PdHS& S,
+                                          PdShared* sh, int role, int zt) {
+    const int par = t & 1, MT = A.MT;
+    pd_wait_count(A, A.ctl + zt + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+    if (sh->abort) return;
+    PD_STAMP(role, 4);
+    u32x4 x[PDH_MT][4];
+    pdh_xload<4>(A.h1h[par], MT, PD_KBH / 2, 0, x);
+    PD_PIN();
+    f32x4 a[PDH_MT];
+#pragma unroll
+    for (int mt = 0; mt < PDH_MT; ++mt) a[mt] = f32x4{0, 0, 0, 0};
+    pdh_mma<4, 0, 1>(x, wx2, PD_KBH / 2, a);
+    pdh_spill(lds, threadIdx.x >> 6, a);
+    float z[2];
+    pdh_reduce<8>(lds, S.p2, z);
+    pdh_gates_store(z, S.c2, A.h2h[par], tile + zt, A.B, MT);
+    pd_arrive(A.ctl + zt + PD_CNT4);
+    PD_STAMP(role, 5);
+    if (STREAM_H2 && t + 1 < A.steps) pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, wh2);
+    pdh_rec<true>(x, wh1, A.b1h[tile * 16 + (threadIdx.x & 15)], lds, A.twopass != 0, S.p1);
+    PD_STAMP(role, 6);
+}
+template <bool WAIT>
+__device__ __forceinline__ void pdh_rec2(const PersistDecodeArgs& A, const u32x4 (&wh2)[4], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role, int zt) {
+    if (WAIT) {
+        pd_wait_count(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        if (sh->abort) return;
+    }
+    PD_STAMP(role, 7);
+    u32x4 x[PDH_MT][4];
+    pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
+    PD_PIN();
+    const float bias = A.b2h[tile * 16 + (threadIdx.x & 15)];
+    if (tile < A.co_tiles) pdh_rec<false>(x, wh2, bias, lds, A.twopass != 0, S.p2);
+    else pdh_rec<true>(x, wh2, bias, lds, A.twopass != 0, S.p2);
+    PD_STAMP(role, 8);
+}
+// projection tile `ptile`, M-tile `pmt` from the mirrors of h2 (32-k blocks 0..31) and of the context (the last 4 of xa's 12)
+__device__ __forceinline__ void pdh_proj(const PersistDecodeArgs& A, const u32x4 (&wp)[5], int t, int ptile, int pmt, float* lds) {
+    const int par = t & 1, MT = A.MT;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const auto rh = gt_rsrc(A.h2h[par], 0x7FFFF000u);
+    const auto rx = gt_rsrc(A.xah[par], 0x7FFFF000u);
+    constexpr int NKB = PD_KBPJ / 2;
+    u32x4 x[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int kb = (wave + i * PD_NW < NKB) ? wave + i * PD_NW : wave;          // wave-uniform
+        const auto tv = kb < PD_KBH / 2 ? __builtin_amdgcn_raw_buffer_load_b128(rh, lane * 16, (kb * MT + pmt) * 1024, 16)
+                                        : __builtin_amdgcn_raw_buffer_load_b128(rx, lane * 16, ((kb - PD_KBH / 2 + PD_KBP / 2) * MT + pmt) * 1024, 16);
+        __builtin_memcpy(&x[i], &tv, 16);
+    }
+    PD_PIN();
+    f32x4 a0 = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        if (wave + i * PD_NW < NKB) {
+            bf16x8 av, bw;
+            __builtin_memcpy(&av, &x[i], 16);
+            __builtin_memcpy(&bw, &wp[i], 16);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw, a0, 0, 0, 0);
+        }
+    }
+    const f32x4 zero = {0, 0, 0, 0};
+    pd_spill(lds, threadIdx.x >> 6, a0, zero);
+    const float v = pd_reduce<8>(lds, A.bp[ptile * 16 + (threadIdx.x & 15)]);
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const int grow = pmt * 16 + row, gcol = ptile * 16 + col;
+    if (row < 16 && grow < A.B) {
+        if (gcol >= A.z_col0) {
+            if (gcol < A.z_col0 + PD_P) {
+                uint2 g;
+                g.x = __builtin_bit_cast(uint32_t, v); g.y = (uint32_t)t + 1u;
+                pd_st2_sc1(A.z0g + (size_t)grow * PD_P + (gcol - A.z_col0), g);
+            }
+        } else if (gcol < A.n_split) {
+            A.pre[(size_t)grow * A.ld_pre + (size_t)t * A.n_split + gcol] = v;
+        } else if (gcol < A.n_out) {
+            A.stop[(size_t)grow * A.steps + t] = v;
+        }
+    }
+}
+
+template <bool CHAIN>
+__device__ __forceinline__ void pdh_run_tile(const PersistDecodeArgs& A, float* smem, PdShared* sh) {
+    float* lds = smem;
+    const int tile = blockIdx.x, b = blockIdx.x, tid = threadIdx.x, col = tid & 15;
+    constexpr int role = CHAIN ? 0 : 2;
+    PdWh W;
+    PdHS S;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { S.c1[e] = 0.f; S.c2[e] = 0.f; S.p1[e] = A.b1h[tile * 16 + col]; S.p2[e] = A.b2h[tile * 16 + col]; }
+    PdChainLds L{};
+    PdChainRegs R{};
+    if (CHAIN) {
+        L = pd_carve(smem, A.tvp, A.twopass ? 8 : 16, PDH_SLAB);
+        R.Tv = A.tok_len ? max(1, min(A.Tv, (int)A.tok_len[b])) : A.Tv;
+        R.drop = A.drop_rate > 0.f;
+        R.hashed = R.drop && A.keep_hash != 0;
+        R.noisy = A.sigmoid_noise > 0.f;
+        R.seed = R.hashed ? *A.seed_ptr : 0ull;
+        R.bias1 = tid < PD_P ? A.b1[tid] : 0.f;
+        R.biasq = tid < PD_A ? A.bq[tid] : 0.f;
+        R.sbias = A.score_bias[0];
+        const float4* src = reinterpret_cast<const float4*>(A.pm + (size_t)b * A.Tv * PD_A);
+        for (int e = tid; e < A.tvp * PD_A / 4; e += PD_NT) {
+            const int row = e / (PD_A / 4), c4 = e % (PD_A / 4);
+            *reinterpret_cast<float4*>(L.tile + row * PD_LDV + 4 * c4) = row < R.Tv ? src[(size_t)row * (PD_A / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < PD_A) L.vs[tid] = A.av[tid];
+        if (tid < A.tvp) L.pv[tid] = tid == 0 ? 1.f : 0.f;
+    } else {
+        pdh_load_tile<2>(A.w1x, tile, PD_KBP / 2 + PD_KBC / 2, W.x1); pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2);
+        pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1); pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, W.h2);
+    }
+    __syncthreads();
+    for (int t = 0; t < A.steps; ++t) {
+        PD_STAMP(role, 0);
+        PD_ZT(zt);
+        if (CHAIN) {
+            float unused = 0.f;
+            int bs = b;
+            asm volatile("" : "+s"(bs));
+            pd_chain<false, true>(A, L, R, t, bs, sh, unused, zt);
+            if (sh->abort) return;
+            PD_STAMP(role, 1);
+            PD_PIN();
+            pdh_load_tile<2>(A.w1x, tile, PD_KBP / 2 + PD_KBC / 2, W.x1);
+            pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2); pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1);        // (arrive during cell 1)
+        }
+        pdh_cell1(A, W.x1, t, tile, lds, S, sh, role, zt);
+        if (sh->abort) return;
+        pdh_cell2<CHAIN>(A, W.x2, W.h1, W.h2, t, tile, lds, S, sh, role, zt);
+        if (sh->abort) return;
+        if (t + 1 == A.steps) break;
+        pdh_rec2<true>(A, W.h2, t, tile, lds, S, sh, role, zt);
+        if (sh->abort) return;
+    }
+}
+
+__device__ __forceinline__ void pdh_run_proj(const PersistDecodeArgs& A, float* lds, PdShared* sh) {
+    const int tile = blockIdx.x, col = threadIdx.x & 15;
+    const int pi = tile - A.n_chain, ptile = pi % A.pj_tiles, pmt = pi / A.pj_tiles;
+    PdWh W;
+    pdh_load_tile<2>(A.w1x, tile, PD_KBP / 2 + PD_KBC / 2, W.x1); pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2);
+    pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1); pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, W.h2);
+    u32x4 wpj[5];
+    pdh_load_tile<5>(A.wp, ptile, PD_KBPJ / 2, wpj);
+    PdHS S;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { S.c1[e] = 0.f; S.c2[e] = 0.f; S.p1[e] = A.b1h[tile * 16 + col]; S.p2[e] = A.b2h[tile * 16 + col]; }
+    for (int t = 0; t < A.steps; ++t) {
+        PD_STAMP(1, 0);
+        PD_ZT(zt);
+        pdh_cell1(A, W.x1, t, tile, lds, S, sh, 1, zt);
+        if (sh->abort) return;
+        pdh_cell2<false>(A, W.x2, W.h1, W.h2, t, tile, lds, S, sh, 1, zt);
+        if (sh->abort) return;
+        pd_wait_count(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        if (sh->abort) return;
+        pdh_proj(A, wpj, t, ptile, pmt, lds);
+        PD_STAMP(1, 6);
+        if (t + 1 == A.steps) break;
+        pdh_rec2<false>(A, W.h2, t, tile, lds, S, sh, 1, zt);
+    }
+}
+
+__global__ __launch_bounds__(PD_NT) void gt_persist_decode_h_kernel(PersistDecodeArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ PdShared sh;
+    if (threadIdx.x == 0) sh.abort = 0;
+    __syncthreads();
+    const int tile = blockIdx.x;
+    if (tile < A.n_chain) pdh_run_tile<true>(A, smem, &sh);
+    else if (tile < A.n_chain + A.pj_tiles * A.MT) pdh_run_proj(A, smem, &sh);
+    else pdh_run_tile<false>(A, smem, &sh);
+}
+
 // z0 granules of step 0: the first frame is zero (Taco2.py:162-165), so prenet 0's pre-activations are its bias; + the control words
 __global__ void gt_persist_decode_init_kernel(uint2* z0g, const float* b0, uint32_t* ctl, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1317,11 +1666,21 @@ size_t gt_persist_decode_ctl_words() { return PD_CTL_WORDS; }
 int gt_persist_decode_max_batch() { return PD_BMAX; }
 
 // `split16`: a batch of 17..32 rows as two groups of 16 (experiment; the default is the one-group kernel with its helper workgroups)
-bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots, int split16) {
+// the bf16 kernel's LDS: slabs of 64 rows; the chain workgroups' 16 (or, beside more than 128 tokens, 8) + their chain state
+__host__ __device__ constexpr int pdh_chain_floats(int tvp, int nslab) { return nslab * PDH_SLAB + 3 * PD_P + 2 * PD_A + 4 * tvp + tvp * PD_LDV; }
+__host__ __device__ constexpr int pdh_chain_slabs(int tvp) { return pdh_chain_floats(tvp, 16) * 4 + 64 <= 160 * 1024 ? 16 : 8; }
+__host__ __device__ constexpr int pdh_lds_floats(int tvp) {
+    return pdh_chain_floats(tvp, pdh_chain_slabs(tvp)) > 16 * PDH_SLAB ? pdh_chain_floats(tvp, pdh_chain_slabs(tvp)) : 16 * PDH_SLAB;
+}
+constexpr int PDH_TVMAX = 192, PDH_BMAX = 16 * PDH_MT;
+static_assert(pdh_lds_floats(PDH_TVMAX) * 4 + 64 <= 160 * 1024, "the bf16 kernel's chain state must fit a CU's LDS");
+
+bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots, int split16, int bf16) {
     (void)mel; (void)r;
     if (!(P0 == PD_P && P1 == PD_P && A == PD_A && H1 == PD_H && H2 == PD_H && B >= 1 && Tv >= 1 && Tv <= PD_TVMAX && pj_nkb == PD_KBPJ && pj_tiles >= 1 &&
           slots >= PD_NWG))
         return false;
+    if (bf16) return B <= PDH_BMAX && Tv <= PDH_TVMAX && B + pj_tiles * ((B + 15) / 16) <= PD_NWG;
     if (B <= 32 && !(split16 && B > 16)) return PD_UTT + pj_tiles * ((B + 15) / 16) + PD_HELP <= PD_NWG;
     return B <= PD_BMAX && B + pj_tiles * (B <= 32 ? 1 : 2) <= PD_NWG;
 }
@@ -1335,7 +1694,8 @@ PdKernel pd_kernel_for(int B, int split16, int* G, int* mtg) {
     *mtg = 2; *G = (B + 31) / 32;
     return B <= 64 ? gt_persist_decode_g_kernel<2, 2> : gt_persist_decode_g_kernel<4, 2>;
 }
-const PdKernel kPdKernels[] = {gt_persist_decode_kernel, gt_persist_decode_g_kernel<2, 1>, gt_persist_decode_g_kernel<2, 2>, gt_persist_decode_g_kernel<4, 2>};
+const PdKernel kPdKernels[] = {gt_persist_decode_kernel, gt_persist_decode_g_kernel<2, 1>, gt_persist_decode_g_kernel<2, 2>, gt_persist_decode_g_kernel<4, 2>,
+                               gt_persist_decode_h_kernel};
 }  // namespace
 
 hipError_t gt_persist_decode_init() {
@@ -1359,6 +1719,16 @@ int gt_persist_decode_blocks_per_cu() {
 
 hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a_in, const float* b0, int split16, hipStream_t stream) {
     PersistDecodeArgs a = a_in;
+    if (a.bf16) {           // mixed precision: one group of up to 64 rows
+        a.G = 1;
+        a.tvp = (a.Tv + 63) / 64 * 64;
+        a.n_chain = a.B;
+        a.twopass = pdh_chain_slabs(a.tvp) == 8 ? 1 : 0;
+        const int n = PD_CTL_WORDS > a.B * PD_P ? PD_CTL_WORDS : a.B * PD_P;
+        hipLaunchKernelGGL(gt_persist_decode_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.z0g, b0, a.ctl, a.B);
+        hipLaunchKernelGGL(gt_persist_decode_h_kernel, dim3(PD_NWG), dim3(PD_NT), (size_t)pdh_lds_floats(a.tvp) * 4, stream, a);
+        return hipGetLastError();
+    }
     int mtg = 2;
     const PdKernel k = pd_kernel_for(a.B, split16, &a.G, &mtg);
     a.tvp = (a.Tv + 63) / 64 * 64;

@@ -314,8 +314,8 @@ class GST_Tacotron:
         self.ctx.check(self.ctx.lib.gsttaco_set_graph_policy(self.ctx.handle, int(max_cached), int(capture_after)))
 
     def synchronize(self):
-        """Synchronises the current stream and raises GstTacoError if a hand-off wait of a persistent BiLSTM launch or of a fused
-        decode-LSTM launch gave up since the last check (``gsttaco_synchronize``, the one place that clears the condition): the
+        """Synchronises the current stream and raises GstTacoError if a hand-off wait of the persistent decode launch, of a persistent
+        BiLSTM launch or of a fused decode-LSTM launch gave up since the last check (``gsttaco_synchronize``, the one place that clears the condition): the
         outputs of the calls since then are invalid and should be repeated -- the context runs the launch-per-step forms from
         then on.  ``Inference`` calls this before it returns."""
         with torch.cuda.device(self.device):
@@ -327,7 +327,7 @@ class GST_Tacotron:
 
     def handoff_error(self):
         """Non-zero while a give-up is pending on this context, i.e. raised and not yet reported by ``synchronize`` (bit 0: fused
-        decode-LSTM launch, bit 8: persistent BiLSTM; ``gsttaco_debug_handoff_error``)."""
+        decode-LSTM launch, bit 8: persistent BiLSTM, bit 16: persistent decode launch; ``gsttaco_debug_handoff_error``)."""
         out = ctypes.c_uint32(0)
         self.ctx.check(self.ctx.lib.gsttaco_debug_handoff_error(self.ctx.handle, ctypes.byref(out)))
         return int(out.value)

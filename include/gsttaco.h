@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define GSTTACO_ABI_VERSION 11
+#define GSTTACO_ABI_VERSION 12
 #define GSTTACO_MAX_LAYERS 8
 
 enum {
@@ -265,22 +265,24 @@ int gsttaco_debug_stamps(gsttaco_ctx* ctx, unsigned long long* host_out96);
  *   - gsttaco_synchronize(ctx, stream) synchronises the stream and returns GSTTACO_E_HIP if that happened since the last check:
  *     the outputs of the calls since then are invalid, repeat them.  It is the ONLY place that clears the condition: calls
  *     enqueued behind the one that gave up do not erase it (they notice the word when they are enqueued, keep it in a sticky
- *     per-context flag, and already run the launch-per-step / two-launch form);
+ *     per-context flag, and already run the next launch form down -- and are correct: each launch form has a give-up word of its
+ *     own, so a give-up of the persistent decode launch does not make the fused LSTM launches enqueued behind it leave early);
  *   - the next compute call that notices the word switches the context to the launch-per-step / two-launch form (bitwise the
  *     same results in fp32; under Use_Mixed_Precision the per-step BiLSTM kernel sums in a different order: within the mixed
  *     tolerance), succeeds, and leaves a "warning: ..." text in gsttaco_last_error.
  * Nothing stays poisoned and nothing hangs.  gsttaco_debug_handoff_error synchronises the device and returns what is pending,
- * i.e. raised and not yet reported by gsttaco_synchronize (bit 0: fused decode-LSTM launch, bit 1: persistent decode launch,
- * bit 8: persistent BiLSTM; 0 = clear). */
+ * i.e. raised and not yet reported by gsttaco_synchronize (bit 0: fused decode-LSTM launch, bit 8: persistent BiLSTM, bit 16:
+ * persistent decode launch; 0 = clear). */
 int gsttaco_synchronize(gsttaco_ctx* ctx, void* stream);
 int gsttaco_debug_handoff_error(gsttaco_ctx* ctx, uint32_t* host_out);
 /* Test support: out[0] = persistent BiLSTM launches this context has enqueued (eagerly or into a captured graph), out[1] = 1
  * while the context uses the persistent launch, 0 once it has fallen back to one launch per time step; out[2] / out[3] the same
- * for the persistent DECODE launch (the whole decoder loop of Taco2.py:153-228 as one launch: batch <= 32, T_v <= 128, fp32, the
- * reference's decoder sizes, one live context; GSTTACO_PERSIST_DECODE=0 or a give-up: launches per step, bitwise the same). */
+ * for the persistent DECODE launch (the whole decoder loop of Taco2.py:153-228 as one launch: batch <= 128 -- above 32 rows as
+ * groups of 32 through one set of resident weights --, T_v <= 256, fp32, the reference's decoder sizes, one live context;
+ * GSTTACO_PERSIST_DECODE=0, GSTTACO_PERSIST_ROWS=<max batch> or a give-up: launches per step, bitwise the same). */
 int gsttaco_debug_counters(const gsttaco_ctx* ctx, uint64_t out[4]);
-/* Test support (fault injection).  bits 0..7 / 8..15: raise the fused launch's / the persistent BiLSTM's give-up word as a kernel
- * would.  bits 16..: n > 0 makes member n - 1 of every group of the NEXT persistent launches exit at once and the next fused
+/* Test support (fault injection).  bits 0..6 / 7 / 8..15: raise the fused launch's / the persistent decode launch's / the persistent
+ * BiLSTM's give-up word as a kernel would.  bits 16..: n > 0 makes member n - 1 of every group of the NEXT persistent launches exit at once and the next fused
  * launches expect one arrival too many, so that their waits really run into the bound. */
 int gsttaco_debug_raise_handoff_error(gsttaco_ctx* ctx, uint32_t bits);
 /* Test support: the prenet keep-masks [steps][mask0 B*P0 | mask1 B*P1] (0/1) and SMA noise [steps][B][Tv] the LAST

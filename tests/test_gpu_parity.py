@@ -321,6 +321,9 @@ PERSIST_CASES = [
     # groups of 32 rows through one set of resident weights (round 5): 2 groups up to 64 rows, 4 up to 128; partial last groups and M-tiles
     (37, 60, "SMA", "hashed", 100, {}), (64, 128, "BMA", "injected", 60, {}), (65, 50, "SMA", "masked", 100, {}), (128, 128, "SMA", "hashed", 100, {}),
     (128, 256, "BMA", "masked", 60, {}), (100, 187, "SMA", "rate25", 60, {}),
+    # mixed precision (round 5): the bf16 kernel -- one group of up to 64 rows, activations as bf16 mirrors only -- against the bf16 launch path
+    (64, 128, "SMA", "hashed", 100, {"MIXED": "1"}), (40, 60, "BMA", "injected", 100, {"MIXED": "1"}), (20, 150, "SMA", "masked", 100, {"MIXED": "1"}),
+    (57, 100, "SMA", "rate25", 60, {"MIXED": "1"}), (5, 33, "BMA", "nodrop", 100, {"MIXED": "1"}),
     # 17..32 rows as two groups of 16 (GSTTACO_PERSIST_SPLIT16=1: the measured alternative to the helpers of the one-group kernel)
     (32, 128, "SMA", "hashed", 100, {"GSTTACO_PERSIST_SPLIT16": "1"}), (23, 70, "BMA", "injected", 100, {"GSTTACO_PERSIST_SPLIT16": "1"}),
 ]
@@ -343,6 +346,9 @@ def test_persistent_decode_launch_is_bitwise_the_launches(monkeypatch, B, Tv, at
     Tref = 60
     rate = {"rate25": 0.25, "nodrop": 0.0}.get(mode, 0.5)
     hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, Tref, steps, seed=40 + B, att=att, rate=rate)
+    env = dict(env)
+    mixed = env.pop("MIXED", None) is not None
+    hp = dict(hp); hp["Use_Mixed_Precision"] = mixed
     kw = dict(steps=steps)
     if mode == "injected" or mode == "masked":
         kw.update(prenet_masks=masks, attn_noise=noise)
@@ -365,7 +371,7 @@ def test_persistent_decode_launch_is_bitwise_the_launches(monkeypatch, B, Tv, at
         n_persist, on = m.decode_counters()            # (enqueued once: the second call replays the captured graph)
         assert (n_persist >= 1 and on == 1) if flag == "1" else (n_persist == 0 and on == 0)
         outs[flag] = (mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy())
-        if flag == "1" and mode == "injected" and B <= 32:
+        if flag == "1" and mode == "injected" and B <= 32 and not mixed:
             ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
             assert np.abs(outs[flag][0] - ref[0]).max() <= TOL and np.abs(outs[flag][2] - ref[3]).max() <= TOL
         del m, mel, stop, align

@@ -1,17 +1,26 @@
-"""Diagnostic: phase stamps of the persistent decode launch at the middle decode step (GSTTACO_STAMPS=1): chain workgroup 0,
-projection workgroup 32, plain workgroup 255 (csrc/persist_decode.hip PD_STAMP)."""
+"""Diagnostic: phase stamps of the persistent decode launch (one-group kernel, <= 32 utterances) at the middle decode step
+(GSTTACO_STAMPS=1): chain workgroup 0, projection workgroup 32, plain workgroup 255 (csrc/persist_decode.hip PD_STAMP).
+    python tools/stamps_persist.py [batch <= 32] [tokens <= 256]"""
 import ctypes, os, sys
 os.environ["GSTTACO_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gst_tacotron_amd import synthetic, weights
 from gst_tacotron_amd.model import GST_Tacotron
-hp, inputs = synthetic.config_inputs("cfg2", batch=32)
+import numpy as np
+nums = [int(a) for a in sys.argv[1:] if a.isdigit()]
+B = nums[0] if nums else 32
+Tv = nums[1] if len(nums) > 1 else 128
+hp, inputs = synthetic.config_inputs("cfg2", batch=B)
 w = weights.synthetic_weights(hp, seed=0)
-m = GST_Tacotron(hyper_parameters=hp, max_batch=32, max_tokens=128, max_ref_frames=257)
+tok = inputs["tokens"]
+if Tv != tok.shape[1]:
+    tok, _ = synthetic.make_tokens(np.random.default_rng(1), B, Tv)
+print("batch", B, "tokens", Tv)
+m = GST_Tacotron(hyper_parameters=hp, max_batch=B, max_tokens=Tv, max_ref_frames=257)
 m.Restore(weights=w)
 for i in range(3):
-    m.Inference_Step(inputs["tokens"], None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"], seed=i)
+    m.Inference_Step(tok, None, None, inputs["mels_for_gst"], inputs["mel_lengths_for_gst"], seed=i)
 torch.cuda.synchronize()
 assert m.decode_counters()[0] > 0, "the persistent decode launch was not taken"
 buf = (ctypes.c_uint64 * 96)()

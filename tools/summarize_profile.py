@@ -69,8 +69,18 @@ if os.path.exists(bl) and res:
             continue
         n, r = max(hits, key=lambda x: x[1]["dispatches"])
         traffic = r["hbm_read_bytes_corrected"] + r["hbm_write_bytes"]
-        if "compulsory_bytes_per_launch" in v:      # the persistent decode launch: weights once per launch + the activations of every step
-            v = dict(v, bytes=v["compulsory_bytes_per_launch"])
+        if "compulsory_bytes_per_launch" in v:
+            # The persistent decode launch keeps its weights in registers: what it MUST move is every weight once per LAUNCH + the activations of
+            # every step (compulsory) -- that is what the counters can be held to.  The bench line's headline `frac` prices SURVEY 8(d)'s
+            # ALGORITHMIC bytes (every weight once per STEP), which exceed the traffic by design; both are stated, the ratio too.
+            comp, alg = v["compulsory_bytes_per_launch"], v.get("algorithmic_bytes_per_launch", v["bytes"])
+            ok = comp <= 1.02 * traffic
+            rows_chk.append(f"{'ok ' if ok else 'BAD'} {sym}: compulsory {comp / 1e6:.2f} MB <= PMC traffic {traffic / 1e6:.2f} MB per launch (x{traffic / max(comp, 1):.2f}); "
+                            f"the headline roofline.frac prices the ALGORITHMIC {alg / 1e6:.1f} MB per launch (SURVEY 8(d): weights once per step) = "
+                            f"x{alg / max(traffic, 1):.1f} the counted traffic -- register-resident weights, see roofline.limiter / frac_traffic")
+            if not ok:
+                violations.append(sym)
+            continue
         ok = v["bytes"] <= 1.02 * traffic
         rows_chk.append(f"{'ok ' if ok else 'BAD'} {sym}: algorithmic {v['bytes'] / 1e6:.2f} MB, PMC traffic {traffic / 1e6:.2f} MB per launch (x{traffic / max(v['bytes'], 1):.2f})")
         if not ok:
