@@ -2038,7 +2038,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     if ((rc = fa(&c->w_xa2, Bp * (c->P1 + c->att)))) return rc;
     HIPCHECK(c, hipMemset(c->w_xa2, 0, Bp * (c->P1 + c->att) * sizeof(float)));
     if ((rc = dev_alloc(c, (void**)&c->w_z0g, std::max<size_t>(32, B) * 256 * sizeof(uint2)))) return rc;
-    if ((rc = fa(&c->w_hpart, (size_t)2 * 32 * 512))) return rc;
+    if ((rc = fa(&c->w_hpart, (size_t)2 * 64 * 1024))) return rc;         // (fp32 kernel: [2][32 tiles][512]; bf16 kernel: [2][64 tiles][1024])
     if (B > 16 && (rc = fa(&c->w_stash, (size_t)256 * 16 * 512))) return rc;      // (the group kernels: batches above 32 rows, or 17..32 as two groups of 16)
     if ((rc = dev_alloc(c, (void**)&c->w_pctl, gt_persist_decode_ctl_words() * sizeof(uint32_t)))) return rc;
     // the give-up words of the in-kernel hand-offs live in host-mapped memory: the device raises them with a system-scope

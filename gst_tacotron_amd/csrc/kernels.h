@@ -315,7 +315,7 @@ struct PersistDecodeArgs {
     uint16_t* xah[2]; uint16_t* h1h[2]; uint16_t* h2h[2];  // mixed precision: the bf16 mirrors (gt_blk_off_h) of xa / h1 / h2, ping-pong by step parity
     int bf16;                                          // 1: the bf16 kernel (weights are the bf16 packs, activations travel as mirrors only)
     uint2* z0g;                                        // [B][256] {value bits, step tag}
-    float* hpart;                                      // [2][32][512] recurrent halves of the chain workgroups' tiles
+    float* hpart;                                      // [2][32][512] (bf16 kernel: [2][64][1024]) recurrent halves of the chain workgroups' tiles
     float* stash;                                      // [256][16][512] the group kernels' chain workgroups park their tile state here during the chain
     uint32_t* ctl;                                     // gt_persist_decode_ctl_words() words, zeroed by the launcher
     uint32_t* err;                                     // host-mapped give-up word of this launch

@@ -57,7 +57,7 @@ constexpr uint32_t PD_SPIN_MAX = 1u << 20;
 #endif
 // (per utterance: a prenet flag and a context flag; per group of rows: the two arrival counters; per chain tile: two helper flags)
 constexpr int PD_F_P = 0, PD_F_C = PD_BMAX * 32, PD_CNT3 = 2 * PD_BMAX * 32, PD_CNT4 = PD_CNT3 + PD_GMAX * PD_NSH * 32,
-              PD_F_H = PD_CNT4 + PD_GMAX * PD_NSH * 32, PD_CTL_WORDS = PD_F_H + 64 * 32;
+              PD_F_H = PD_CNT4 + PD_GMAX * PD_NSH * 32, PD_CTL_WORDS = PD_F_H + 128 * 32;     // (helper flags: 2 x 32 tiles, bf16 kernel 2 x 64)
 
 __device__ __forceinline__ uint32_t pd_ld_sc1(const uint32_t* p) {
     uint32_t v;
@@ -493,19 +493,16 @@ __device__ __forceinline__ PdChainLds pd_carve(float* smem, int tvp, int nslab =
 
 struct PdChainRegs { float bias1, biasq, sbias; int Tv; uint64_t seed; bool hashed, drop, noisy; };
 
-// HELPED: the workgroup's layer-1 recurrent half comes from a helper workgroup (the one-group kernel) and is fetched here
-// zt: 0, or a per-step opaque zero (the group kernels: nothing of the chain's address arithmetic may be hoisted out of the step loop)
-// MIRROR (mixed precision): the prenet output and the context leave as the bf16 mirror (kernels.h gt_blk_off_h) only
-template <bool HELPED, bool MIRROR = false>
-__device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v, int zt = 0) {
+// ---- ALL of prenet-1's weights for step t, requested before the projection's hand-off is even looked at (the bf16 kernel: a phase
+// earlier still, in front of the recurrent half of the step before).  Launch-path wave kp (of 16) owns rows 16 kp .. 16 kp + 15,
+// lane = 4 output columns; this wave plays kp = wave and kp = wave + 8.  Hashed dropout (throughput mode): rows whose input the keep
+// decisions zero are not requested (they would multiply an exact zero).
+// WHICH: 3 = both halves, 1 = the first (virtual wave kp = wave), 2 = the second (kp = wave + 8)
+template <int WHICH = 3>
+__device__ __forceinline__ void pd_chain_issue(const PersistDecodeArgs& A, const PdChainRegs& R, int t, int b, int zt, float4 (&ra)[16], float4 (&rb)[16]) {
     const int tid = threadIdx.x + zt, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int par = t & 1, Tv = R.Tv, TvFull = A.Tv, MT = A.MT;
-    // ---- ALL of prenet-1's weights for this step, requested before the projection's hand-off is even looked at.  Launch-path wave
-    // kp (of 16) owns rows 16 kp .. 16 kp + 15, lane = 4 output columns; this wave plays kp = wave and kp = wave + 8.  Hashed
-    // dropout (throughput mode): rows whose input the keep decisions zero are not requested (they would multiply an exact zero).
     const auto rsW1 = gt_rsrc(A.W1, (uint32_t)(PD_P * PD_P) * 4u);
-    const auto rsWq = gt_rsrc(A.Wq, (uint32_t)(PD_P * PD_A) * 4u);
     uint32_t rba = 0xFFFFu, rbb = 0xFFFFu;
     if (R.hashed) {
         const uint32_t w0 = gt_keep_word(R.seed, (uint32_t)t, 0u, (uint32_t)b, (uint32_t)wave >> 1);
@@ -517,17 +514,30 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
     // CU's address pipe 85 % of a real one -- tools/oob_cost.hip -- and the pipe time of these 32 requests per wave is what decides
     // whether the weights are there when the projection's hand-off arrives.  The matching FMAs are skipped too: they would add
     // x = 0 times anything.)
-    float4 ra[16], rb[16];
+    if (WHICH & 1) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((rba >> i) & 1u) ra[i] = gt_bload4(rsW1, (uint32_t)lane * 16u, (uint32_t)((16 * wave + i) * PD_P * 4));
+        for (int i = 0; i < 16; ++i) {
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((rba >> i) & 1u) ra[i] = gt_bload4(rsW1, (uint32_t)lane * 16u, (uint32_t)((16 * wave + i) * PD_P * 4));
+        }
     }
+    if (WHICH & 2) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((rbb >> i) & 1u) rb[i] = gt_bload4(rsW1, (uint32_t)lane * 16u, (uint32_t)((16 * (wave + 8) + i) * PD_P * 4));
+        for (int i = 0; i < 16; ++i) {
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((rbb >> i) & 1u) rb[i] = gt_bload4(rsW1, (uint32_t)lane * 16u, (uint32_t)((16 * (wave + 8) + i) * PD_P * 4));
+        }
     }
+}
+
+// the chain behind its weight requests (pd_chain_issue)
+template <bool HELPED, bool MIRROR>
+__device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v, int zt,
+                                              float4 (&ra)[16], float4 (&rb)[16]) {
+    const int tid = threadIdx.x + zt, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int par = t & 1, Tv = R.Tv, TvFull = A.Tv, MT = A.MT;
+    const auto rsWq = gt_rsrc(A.Wq, (uint32_t)(PD_P * PD_A) * 4u);
     // small per-step operands: noise row, injected keep masks (parity mode)
     float nzv = 0.f, k0 = 1.f, k1 = 1.f;
     if (R.noisy && tid < Tv) nzv = A.noise[((size_t)t * A.B + b) * TvFull + tid];
@@ -780,6 +790,16 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
         if (tid == 0) pd_st1_sc1(A.ctl + PD_F_C + b * PD_FS, (uint32_t)t + 1u);
     }
     PD_STAMP(0, 20);
+}
+
+// HELPED: the workgroup's layer-1 recurrent half comes from a helper workgroup (the one-group kernel) and is fetched here
+// zt: 0, or a per-step opaque zero (the group kernels: nothing of the chain's address arithmetic may be hoisted out of the step loop)
+// MIRROR (mixed precision): the prenet output and the context leave as the bf16 mirror (kernels.h gt_blk_off_h) only
+template <bool HELPED, bool MIRROR = false>
+__device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v, int zt = 0) {
+    float4 ra[16], rb[16];
+    pd_chain_issue(A, R, t, b, zt, ra, rb);
+    pd_chain_rest<HELPED, MIRROR>(A, L, R, t, b, sh, p1v, zt, ra, rb);
 }
 
 // ====================================================================================================================== roles
@@ -1324,7 +1344,7 @@ __global__ __launch_bounds__(PD_NT) void gt_persist_decode_g_kernel(PersistDecod
 // values the launch path's consumers get, in the same k-block -> wave assignment and summation orders (lean_body.h
 // gt_lean_core_bf16 / gt_lean_mc on eight waves; the recurrent halves in the front launch's 16-wave or the projection launch's
 // 8-wave order): bitwise the launches.
-constexpr int PDH_MT = 4;
+constexpr int PDH_MT = 4, PDH_BMAX = 16 * PDH_MT;
 struct PdWh { u32x4 x1[2], h1[4], x2[4], h2[4]; };
 constexpr int PDH_SLAB = PDH_MT * 16 * 17;
 
@@ -1390,6 +1410,7 @@ __device__ __forceinline__ void pdh_reduce(float* lds, const float (&base)[2], f
 #pragma unroll
         for (int w = 0; w < NSLAB; ++w) v += part[w][row + 32 * e][col];
         z[e] = v;
+        asm volatile("" : "+v"(z[e]));      // (one element's reads at a time: with both elements' 32 reads in flight the allocator spilled)
     }
     __syncthreads();
 }
@@ -1448,11 +1469,63 @@ __device__ __forceinline__ void pdh_rec(const u32x4 (&x)[PDH_MT][4], const u32x4
 }
 struct PdHS { float c1[2], c2[2], p1[2], p2[2]; };
 
+// The chain workgroups' recurrent halves are computed by HELPER workgroups -- plain workgroup i helps chain tile i; at <= 64 rows there
+// are more plain workgroups than chains -- from the state fragments the helper holds anyway, and handed back through memory
+// (hpart [layer][tile][64 rows][16 columns], one tagged flag per layer and tile).  A chain workgroup's step is then chain -> cell 1 ->
+// cell 2 and straight on to the next chain, whose prenet-0 hand-off is what it waits for: the step's critical path no longer carries
+// its two recurrent halves (1.4 us each + the wait for the h2 arrivals between them), which the helpers multiply while they would
+// otherwise wait for the chains.
+constexpr int PDH_HP = PDH_MT * 16 * 16;     // floats of one handed-back tile
+__device__ __forceinline__ void pdh_publish(const float (&v)[2], float* dst, uint32_t* flag, uint32_t tag) {
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float v1 = __shfl_down(v[e], 1, 16), v2 = __shfl_down(v[e], 2, 16), v3 = __shfl_down(v[e], 3, 16);
+        if ((col & 3) == 0) pd_st4_sc1(dst + (row + 32 * e) * 16 + col, make_float4(v[e], v1, v2, v3));
+    }
+    pd_drain();
+    __syncthreads();
+    if (threadIdx.x == 0) pd_st1_sc1(flag, tag);
+}
+// a chain workgroup's wait for every context flag (<= 64 utterances: one per lane) AND, in the same polls, for its two helpers' flags
+__device__ __forceinline__ void pdh_wait_flags_helped(const PersistDecodeArgs& A, const uint32_t* f, uint32_t want, const uint32_t* fh1, const uint32_t* fh2, uint32_t want_h,
+                                                      PdShared* sh) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const bool h0 = lane < A.B;
+        const uint32_t* p0 = f + (h0 ? lane : 0) * PD_FS;
+        const uint32_t* p1 = lane == 0 ? fh1 : fh2;
+        uint32_t spins = 0;
+        for (;;) {
+            uint32_t v0, v1;
+            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
+            const bool ok = (!h0 || v0 >= want) && (lane > 1 || v1 >= want_h);
+            if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(ok))) == 64) break;
+            if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
+            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
+        }
+    }
+    __syncthreads();
+}
+
+// HELPED (chain workgroups): the recurrent halves of this step arrive from the helpers; they are requested behind the flag wait and
+// land under the fragments and MFMAs
+template <bool HELPED>
 __device__ __forceinline__ void pdh_cell1(const PersistDecodeArgs& A, const u32x4 (&wx1)[2], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role, int zt) {
     const int par = t & 1, MT = A.MT;
-    pd_wait_flags_all(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, sh);
+    if (HELPED) pdh_wait_flags_helped(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, A.ctl + zt + PD_F_H + tile * 32, A.ctl + zt + PD_F_H + (PDH_BMAX + tile) * 32, (uint32_t)t, sh);
+    else pd_wait_flags_all(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, sh);
     if (sh->abort) return;
     PD_STAMP(role, 2);
+    if (HELPED && t > 0) {
+        const auto rh = gt_rsrc(A.hpart, 2u * PDH_BMAX * PDH_HP * 4u);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t off = (uint32_t)((tile * PDH_HP + (threadIdx.x + zt) + 512 * e) * 4);
+            S.p1[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (int)off, 0, 16));
+            S.p2[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (int)off, PDH_BMAX * PDH_HP * 4, 16));
+        }
+    }
     u32x4 x[PDH_MT][2];
     pdh_xload<2>(A.xah[par], MT, PD_KBP / 2 + PD_KBC / 2, 0, x);
     PD_PIN();
@@ -1467,14 +1540,13 @@ __device__ __forceinline__ void pdh_cell1(const PersistDecodeArgs& A, const u32x
     pd_arrive(A.ctl + zt + PD_CNT3);
     PD_STAMP(role, 3);
 }
-template <bool STREAM_H2>
-__device__ __forceinline__ void pdh_cell2(const PersistDecodeArgs& A, const u32x4 (&wx2)[4], const u32x4 (&wh1)[4], u32x4 (&wh2)[4], int t, int tile, float* lds, PdHS& S,
-                                          PdShared* sh, int role, int zt) {
+// cell 2; the h1 fragments stay in `x` for the recurrent halves that follow (pdh_rec1)
+__device__ __forceinline__ void pdh_cell2(const PersistDecodeArgs& A, const u32x4 (&wx2)[4], u32x4 (&x)[PDH_MT][4], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role,
+                                          int zt) {
     const int par = t & 1, MT = A.MT;
     pd_wait_count(A, A.ctl + zt + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
     if (sh->abort) return;
     PD_STAMP(role, 4);
-    u32x4 x[PDH_MT][4];
     pdh_xload<4>(A.h1h[par], MT, PD_KBH / 2, 0, x);
     PD_PIN();
     f32x4 a[PDH_MT];
@@ -1487,24 +1559,51 @@ __device__ __forceinline__ void pdh_cell2(const PersistDecodeArgs& A, const u32x
     pdh_gates_store(z, S.c2, A.h2h[par], tile + zt, A.B, MT);
     pd_arrive(A.ctl + zt + PD_CNT4);
     PD_STAMP(role, 5);
-    if (STREAM_H2 && t + 1 < A.steps) pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, wh2);
-    pdh_rec<true>(x, wh1, A.b1h[tile * 16 + (threadIdx.x & 15)], lds, A.twopass != 0, S.p1);
-    PD_STAMP(role, 6);
 }
-template <bool WAIT>
-__device__ __forceinline__ void pdh_rec2(const PersistDecodeArgs& A, const u32x4 (&wh2)[4], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role, int zt) {
+// layer-1 recurrent half of tile `tl` for the next step from the fragments cell 2 left in `x` (own tile: into `p`; a chain tile's: published)
+__device__ __forceinline__ void pdh_rec1(const PersistDecodeArgs& A, const u32x4 (&x)[PDH_MT][4], const u32x4 (&wh1)[4], int tl, float* lds, bool two, float (&p)[2]) {
+    pdh_rec<true>(x, wh1, A.b1h[tl * 16 + (threadIdx.x & 15)], lds, two, p);
+}
+// layer-2 recurrent half for the next step: this workgroup's tile and, HELP, chain tile `help` (published)
+template <bool WAIT, bool HELP>
+__device__ __forceinline__ void pdh_rec2(const PersistDecodeArgs& A, u32x4 (&wh2)[4], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role, int zt, int help) {
+    if (HELP) pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, wh2);      // (a helper streams its own W2h: arrives during the wait)
     if (WAIT) {
         pd_wait_count(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
         if (sh->abort) return;
     }
     PD_STAMP(role, 7);
-    u32x4 x[PDH_MT][4];
-    pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
-    PD_PIN();
-    const float bias = A.b2h[tile * 16 + (threadIdx.x & 15)];
-    if (tile < A.co_tiles) pdh_rec<false>(x, wh2, bias, lds, A.twopass != 0, S.p2);
-    else pdh_rec<true>(x, wh2, bias, lds, A.twopass != 0, S.p2);
+    const int col = threadIdx.x & 15;
+    // (the summation order is a property of the tile.  Each arm loads its own fragments: shared between the arms of a branch, the
+    // allocator gave up on packing them and spilled -- the group kernels' pd_g_rec_all met the same)
+    if (tile < A.co_tiles) {
+        u32x4 x[PDH_MT][4];
+        pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
+        PD_PIN();
+        pdh_rec<false>(x, wh2, A.b2h[tile * 16 + col], lds, false, S.p2);
+    } else {
+        u32x4 x[PDH_MT][4];
+        pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
+        PD_PIN();
+        pdh_rec<true>(x, wh2, A.b2h[tile * 16 + col], lds, false, S.p2);
+    }
     PD_STAMP(role, 8);
+    if (HELP) {         // (behind the own half: the chain workgroup needs it at its next cell 2, a whole chain away)
+        pdh_load_tile<4>(A.w2h, help, PD_KBH / 2, wh2);
+        float v[2];
+        if (help < A.co_tiles) {
+            u32x4 x[PDH_MT][4];
+            pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
+            PD_PIN();
+            pdh_rec<false>(x, wh2, A.b2h[help * 16 + col], lds, false, v);
+        } else {
+            u32x4 x[PDH_MT][4];
+            pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
+            PD_PIN();
+            pdh_rec<true>(x, wh2, A.b2h[help * 16 + col], lds, false, v);
+        }
+        pdh_publish(v, A.hpart + (size_t)(PDH_BMAX + help) * PDH_HP, A.ctl + zt + PD_F_H + (PDH_BMAX + help) * 32, (uint32_t)t + 1u);
+    }
 }
 // projection tile `ptile`, M-tile `pmt` from the mirrors of h2 (32-k blocks 0..31) and of the context (the last 4 of xa's 12)
 __device__ __forceinline__ void pdh_proj(const PersistDecodeArgs& A, const u32x4 (&wp)[5], int t, int ptile, int pmt, float* lds) {
@@ -1553,8 +1652,10 @@ __device__ __forceinline__ void pdh_proj(const PersistDecodeArgs& A, const u32x4
     }
 }
 
-template <bool CHAIN>
-__device__ __forceinline__ void pdh_run_tile(const PersistDecodeArgs& A, float* smem, PdShared* sh) {
+// CHAIN: utterance blockIdx.x's chain, then cell 1 and cell 2 of its tile with W1x / W2x streamed (its recurrent halves come from a
+// helper); else a plain workgroup: its tile's four halves with resident weights and, HELP, the recurrent halves of chain tile `help`
+template <bool CHAIN, bool HELP>
+__device__ __forceinline__ void pdh_run_tile(const PersistDecodeArgs& A, float* smem, PdShared* sh, int help) {
     float* lds = smem;
     const int tile = blockIdx.x, b = blockIdx.x, tid = threadIdx.x, col = tid & 15;
     constexpr int role = CHAIN ? 0 : 2;
@@ -1565,7 +1666,7 @@ __device__ __forceinline__ void pdh_run_tile(const PersistDecodeArgs& A, float* 
     PdChainLds L{};
     PdChainRegs R{};
     if (CHAIN) {
-        L = pd_carve(smem, A.tvp, A.twopass ? 8 : 16, PDH_SLAB);
+        L = pd_carve(smem, A.tvp, 8, PDH_SLAB);
         R.Tv = A.tok_len ? max(1, min(A.Tv, (int)A.tok_len[b])) : A.Tv;
         R.drop = A.drop_rate > 0.f;
         R.hashed = R.drop && A.keep_hash != 0;
@@ -1582,8 +1683,10 @@ __device__ __forceinline__ void pdh_run_tile(const PersistDecodeArgs& A, float* 
         if (tid < PD_A) L.vs[tid] = A.av[tid];
         if (tid < A.tvp) L.pv[tid] = tid == 0 ? 1.f : 0.f;
     } else {
+        // (a helper keeps the input halves resident and streams the recurrent tiles -- its own, then the chain tile's, through the same
+        // registers: four resident tiles and a streamed fifth did not fit beside the 64-row fragments)
         pdh_load_tile<2>(A.w1x, tile, PD_KBP / 2 + PD_KBC / 2, W.x1); pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2);
-        pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1); pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, W.h2);
+        if (!HELP) { pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1); pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, W.h2); }
     }
     __syncthreads();
     for (int t = 0; t < A.steps; ++t) {
@@ -1598,18 +1701,31 @@ __device__ __forceinline__ void pdh_run_tile(const PersistDecodeArgs& A, float* 
             PD_STAMP(role, 1);
             PD_PIN();
             pdh_load_tile<2>(A.w1x, tile, PD_KBP / 2 + PD_KBC / 2, W.x1);
-            pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2); pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1);        // (arrive during cell 1)
+            pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2);        // (arrives during cell 1)
         }
-        pdh_cell1(A, W.x1, t, tile, lds, S, sh, role, zt);
+        pdh_cell1<CHAIN>(A, W.x1, t, tile, lds, S, sh, role, zt);
         if (sh->abort) return;
-        pdh_cell2<CHAIN>(A, W.x2, W.h1, W.h2, t, tile, lds, S, sh, role, zt);
+        if (HELP && t + 1 < A.steps) pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1);      // (streamed: arrives during the wait for h1)
+        u32x4 x[PDH_MT][4];
+        pdh_cell2(A, W.x2, x, t, tile, lds, S, sh, role, zt);
         if (sh->abort) return;
+        if (CHAIN) continue;                          // (a chain workgroup goes straight on to the next chain)
         if (t + 1 == A.steps) break;
-        pdh_rec2<true>(A, W.h2, t, tile, lds, S, sh, role, zt);
+        pdh_rec1(A, x, W.h1, tile, lds, false, S.p1);
+        PD_STAMP(role, 6);
+        if (HELP) {         // (the chain workgroup needs it at its NEXT cell 1, a whole chain away: own half first)
+            pdh_load_tile<4>(A.w1h, help, PD_KBH / 2, W.h1);
+            float v[2];
+            pdh_rec1(A, x, W.h1, help, lds, false, v);
+            pdh_publish(v, A.hpart + (size_t)help * PDH_HP, A.ctl + zt + PD_F_H + help * 32, (uint32_t)t + 1u);
+        }
+        pdh_rec2<true, HELP>(A, W.h2, t, tile, lds, S, sh, role, zt, help);
         if (sh->abort) return;
     }
 }
 
+// a projection (tile, M-tile) + the LSTM tile, everything resident; the projection comes FIRST behind the h2 arrivals (the chains wait
+// for it), the recurrent halves of layer 1 (h1 re-read) and of layer 2 behind it
 __device__ __forceinline__ void pdh_run_proj(const PersistDecodeArgs& A, float* lds, PdShared* sh) {
     const int tile = blockIdx.x, col = threadIdx.x & 15;
     const int pi = tile - A.n_chain, ptile = pi % A.pj_tiles, pmt = pi / A.pj_tiles;
@@ -1624,16 +1740,25 @@ __device__ __forceinline__ void pdh_run_proj(const PersistDecodeArgs& A, float* 
     for (int t = 0; t < A.steps; ++t) {
         PD_STAMP(1, 0);
         PD_ZT(zt);
-        pdh_cell1(A, W.x1, t, tile, lds, S, sh, 1, zt);
+        pdh_cell1<false>(A, W.x1, t, tile, lds, S, sh, 1, zt);
         if (sh->abort) return;
-        pdh_cell2<false>(A, W.x2, W.h1, W.h2, t, tile, lds, S, sh, 1, zt);
-        if (sh->abort) return;
+        {
+            u32x4 x[PDH_MT][4];
+            pdh_cell2(A, W.x2, x, t, tile, lds, S, sh, 1, zt);
+            if (sh->abort) return;
+        }
         pd_wait_count(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
         if (sh->abort) return;
         pdh_proj(A, wpj, t, ptile, pmt, lds);
         PD_STAMP(1, 6);
         if (t + 1 == A.steps) break;
-        pdh_rec2<false>(A, W.h2, t, tile, lds, S, sh, 1, zt);
+        {   // (the h1 fragments again: kept in registers across the projection they cost this role spills; nobody waits for this half)
+            u32x4 x[PDH_MT][4];
+            pdh_xload<4>(A.h1h[t & 1], A.MT, PD_KBH / 2, 0, x);
+            PD_PIN();
+            pdh_rec1(A, x, W.h1, tile, lds, false, S.p1);
+        }
+        pdh_rec2<false, false>(A, W.h2, t, tile, lds, S, sh, 1, zt, -1);
     }
 }
 
@@ -1643,9 +1768,15 @@ __global__ __launch_bounds__(PD_NT) void gt_persist_decode_h_kernel(PersistDecod
     if (threadIdx.x == 0) sh.abort = 0;
     __syncthreads();
     const int tile = blockIdx.x;
-    if (tile < A.n_chain) pdh_run_tile<true>(A, smem, &sh);
-    else if (tile < A.n_chain + A.pj_tiles * A.MT) pdh_run_proj(A, smem, &sh);
-    else pdh_run_tile<false>(A, smem, &sh);
+    const int n_pj = A.pj_tiles * A.MT;
+#ifndef PD_HONLY
+#define PD_HONLY -1         // (register-budget diagnosis: compile one role alone)
+#endif
+    if (tile < A.n_chain) { if (PD_HONLY < 0 || PD_HONLY == 0) pdh_run_tile<true, false>(A, smem, &sh, -1); }
+    else if (tile < A.n_chain + n_pj) { if (PD_HONLY < 0 || PD_HONLY == 1) pdh_run_proj(A, smem, &sh); }
+    else if (tile - (A.n_chain + n_pj) < A.n_chain) {       // (helps chain tile `index among the plain`)
+        if (PD_HONLY < 0 || PD_HONLY == 2) pdh_run_tile<false, true>(A, smem, &sh, tile - (A.n_chain + n_pj));
+    } else if (PD_HONLY < 0 || PD_HONLY == 3) pdh_run_tile<false, false>(A, smem, &sh, -1);
 }
 
 // z0 granules of step 0: the first frame is zero (Taco2.py:162-165), so prenet 0's pre-activations are its bias; + the control words
@@ -1668,11 +1799,11 @@ int gt_persist_decode_max_batch() { return PD_BMAX; }
 // `split16`: a batch of 17..32 rows as two groups of 16 (experiment; the default is the one-group kernel with its helper workgroups)
 // the bf16 kernel's LDS: slabs of 64 rows; the chain workgroups' 16 (or, beside more than 128 tokens, 8) + their chain state
 __host__ __device__ constexpr int pdh_chain_floats(int tvp, int nslab) { return nslab * PDH_SLAB + 3 * PD_P + 2 * PD_A + 4 * tvp + tvp * PD_LDV; }
-__host__ __device__ constexpr int pdh_chain_slabs(int tvp) { return pdh_chain_floats(tvp, 16) * 4 + 64 <= 160 * 1024 ? 16 : 8; }
+__host__ __device__ constexpr int pdh_chain_slabs(int) { return 8; }      // (the chain workgroups' recurrent halves are the helpers': cell reductions only)
 __host__ __device__ constexpr int pdh_lds_floats(int tvp) {
     return pdh_chain_floats(tvp, pdh_chain_slabs(tvp)) > 16 * PDH_SLAB ? pdh_chain_floats(tvp, pdh_chain_slabs(tvp)) : 16 * PDH_SLAB;
 }
-constexpr int PDH_TVMAX = 192, PDH_BMAX = 16 * PDH_MT;
+constexpr int PDH_TVMAX = 192;
 static_assert(pdh_lds_floats(PDH_TVMAX) * 4 + 64 <= 160 * 1024, "the bf16 kernel's chain state must fit a CU's LDS");
 
 bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots, int split16, int bf16) {
@@ -1680,7 +1811,7 @@ bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, 
     if (!(P0 == PD_P && P1 == PD_P && A == PD_A && H1 == PD_H && H2 == PD_H && B >= 1 && Tv >= 1 && Tv <= PD_TVMAX && pj_nkb == PD_KBPJ && pj_tiles >= 1 &&
           slots >= PD_NWG))
         return false;
-    if (bf16) return B <= PDH_BMAX && Tv <= PDH_TVMAX && B + pj_tiles * ((B + 15) / 16) <= PD_NWG;
+    if (bf16) return B <= PDH_BMAX && Tv <= PDH_TVMAX && 2 * B + pj_tiles * ((B + 15) / 16) <= PD_NWG;     // (a chain and a helper per utterance)
     if (B <= 32 && !(split16 && B > 16)) return PD_UTT + pj_tiles * ((B + 15) / 16) + PD_HELP <= PD_NWG;
     return B <= PD_BMAX && B + pj_tiles * (B <= 32 ? 1 : 2) <= PD_NWG;
 }
@@ -1723,7 +1854,7 @@ hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a_in, const float* 
         a.G = 1;
         a.tvp = (a.Tv + 63) / 64 * 64;
         a.n_chain = a.B;
-        a.twopass = pdh_chain_slabs(a.tvp) == 8 ? 1 : 0;
+        a.twopass = 0;          // (the workgroups that sum recurrent halves have 16 slabs: no chain state beside them)
         const int n = PD_CTL_WORDS > a.B * PD_P ? PD_CTL_WORDS : a.B * PD_P;
         hipLaunchKernelGGL(gt_persist_decode_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.z0g, b0, a.ctl, a.B);
         hipLaunchKernelGGL(gt_persist_decode_h_kernel, dim3(PD_NWG), dim3(PD_NT), (size_t)pdh_lds_floats(a.tvp) * 4, stream, a);
