@@ -451,10 +451,11 @@ def main():
         step_bytes_all, w_bytes, act_bytes = survey_step_bytes(model.dims, B, Tv, args.mixed)
         ms_total, cnt_total = prof[2][0], prof[2][1]
         prof = {2: (ms_total / n_steps_dec, cnt_total * n_steps_dec, step_bytes_all)}
-        kname = "gt_persist_decode_kernel" if B <= 32 else "gt_persist_decode_g_kernel"
+        kname = "gt_persist_decode_h_kernel" if args.mixed else "gt_persist_decode_kernel" if B <= 32 else "gt_persist_decode_g_kernel"
         KNAMES[2] = (kname + ", 1 / {} of it (the whole decoder loop as ONE persistent launch: weights resident in registers, "
                      "processed memory in LDS, in-kernel hand-offs; a step = prenet + query + attention + both LSTM cells + projection".format(n_steps_dec) +
-                     ("" if B <= 32 else "; {} groups of 32 rows through the resident weights".format((B + 31) // 32)) + ")")
+                     ("; bf16 operands, one group of up to 64 rows, activations as bf16 mirrors" if args.mixed else
+                      "" if B <= 32 else "; {} groups of 32 rows through the resident weights".format((B + 31) // 32)) + ")")
         KPMC[2] = kname
     elif prof[1][1] == 0 and prof[0][1] > 0:
         # both decode LSTM cells ran as ONE launch (gt_lstm12_kernel, in-kernel hand-off of h1): one bracket, both cells' bytes

@@ -531,7 +531,9 @@ __device__ __forceinline__ void pd_chain_issue(const PersistDecodeArgs& A, const
 }
 
 // the chain behind its weight requests (pd_chain_issue)
-template <bool HELPED, bool MIRROR>
+// TV128: at most 128 tokens (the headline shape: two score passes, one context chunk -- as compile-time constants they are worth
+// ~0.2 us per step, same-box A/B profiles/r05_ab.txt)
+template <bool HELPED, bool MIRROR, bool TV128 = false>
 __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v, int zt,
                                               float4 (&ra)[16], float4 (&rb)[16]) {
     const int tid = threadIdx.x + zt, lane = tid & 63;
@@ -681,7 +683,7 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
     __syncthreads();
     PD_STAMP(0, 17);
     // ---- scores (Steps.py:126-152): 8 lanes per memory row, 4 x 16-byte pieces each; rows tid / 8, 64 + tid / 8, ... (tvp / 64 passes)
-    const int npass = A.tvp >> 6;
+    const int npass = TV128 ? 2 : A.tvp >> 6;
 #pragma unroll 1
     for (int hh = 0; hh < npass; ++hh) {
         const int row = hh * 64 + (tid >> 3), li = tid & 7;
@@ -745,7 +747,7 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
         // (beyond 128 tokens the launch path streams the memory through its 128-row tile and sums the row chunks last to first,
         // each chunk into its own pair of partial sums: the same order here, where every row is resident)
         const int ca = tid & (PD_A - 1);
-        const int nchunks = (Tv + 127) >> 7;
+        const int nchunks = TV128 ? 1 : (Tv + 127) >> 7;
 #pragma unroll 1
         for (int hh = 0; hh < 2; ++hh) {
             const int cp = hh * 4 + (tid >> 7);
@@ -795,11 +797,11 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
 // HELPED: the workgroup's layer-1 recurrent half comes from a helper workgroup (the one-group kernel) and is fetched here
 // zt: 0, or a per-step opaque zero (the group kernels: nothing of the chain's address arithmetic may be hoisted out of the step loop)
 // MIRROR (mixed precision): the prenet output and the context leave as the bf16 mirror (kernels.h gt_blk_off_h) only
-template <bool HELPED, bool MIRROR = false>
+template <bool HELPED, bool MIRROR = false, bool TV128 = false>
 __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v, int zt = 0) {
     float4 ra[16], rb[16];
     pd_chain_issue(A, R, t, b, zt, ra, rb);
-    pd_chain_rest<HELPED, MIRROR>(A, L, R, t, b, sh, p1v, zt, ra, rb);
+    pd_chain_rest<HELPED, MIRROR, TV128>(A, L, R, t, b, sh, p1v, zt, ra, rb);
 }
 
 // ====================================================================================================================== roles
@@ -844,7 +846,8 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
             for (int k = 0; k < 8; ++k) if (t == ts[k]) A.dbg[24 + k] = __builtin_amdgcn_s_memrealtime();
         }
         if (live) {
-            pd_chain<true>(A, L, R, t, b, sh, p1v);
+            if (A.tvp == 128) pd_chain<true, false, true>(A, L, R, t, b, sh, p1v);
+            else pd_chain<true>(A, L, R, t, b, sh, p1v);
             if (sh->abort) return;
         } else if (t > 0) {                                     // no chain to hide it behind: fetch the layer-1 half directly
             pd_wait_flags(A, A.ctl + PD_F_H + tile * 32, 1, (uint32_t)t, sh);
