@@ -29,9 +29,12 @@ def test_config3_full_size_all_500_steps_with_padding_masks():
     Tref = int(ml.max())
     mels, ml = synthetic.make_ref_mels(rng, B, Tref, lengths=ml)
     masks, noise = synthetic.make_randomness(rng, steps, B, Tv, [256, 256])
+    import gc
+    gc.collect()
     m = _model(hp, w, B, Tv, Tref + 1)
     mel, stop, _, align = m.Inference_Step(tokens, lens, None, mels, ml, prenet_masks=masks, attn_noise=noise, masked=True)
-    torch.cuda.synchronize()
+    m.synchronize()
+    assert m.decode_counters()[0] >= 1 and m.decode_counters()[1] == 1       # (round 5: 128 rows x 256 tokens on the group kernel, four groups)
     mel, stop, align = mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy()
     assert mel.shape == (B, 1000, 80) and stop.shape == (B, 500) and align.shape == (B, 500, Tv)
     assert np.isfinite(mel).all() and align.min() >= 0.0
@@ -94,10 +97,14 @@ def test_config5_shard_bf16_batch64_max_step_1000_round_robin_speakers():
     decoded alone; the mode stays within MIXED_VS_FP32-like distance of the fp32 path."""
     import torch
     B = 64
+    import gc
+    gc.collect()
     hp, w, tokens, tl, mels, ml, masks, noise, m = _cfg5_shard(B)
     assert sorted(set(ml.tolist())) == [88, 103, 126, 150, 191, 204, 209]     # the seven wavs' trimmed lengths in frames
     mel, stop, _, align = m.Inference_Step(tokens, None, None, mels, ml, prenet_masks=masks, attn_noise=noise)
-    torch.cuda.synchronize()
+    m.synchronize()
+    n_persist, on = m.decode_counters()      # (round 5: the shard's decode loop is the bf16 persistent kernel -- fail, do not fall back)
+    assert on == 1 and n_persist >= 1, (n_persist, on, m.last_message())
     mel, align = mel.cpu().numpy(), align.cpu().numpy()
     assert mel.shape == (B, 1000, 80) and stop.shape == (B, 500) and align.shape == (B, 500, 128)
     assert np.isfinite(mel).all() and align.min() >= 0.0
@@ -128,10 +135,13 @@ def test_config5_two_utterances_against_the_bf16_emulating_oracle():
     import time
     import torch
     from oracle import oracle_np
+    import gc
+    gc.collect()
     hp, w, tokens, tl, mels, ml, masks, noise, m = _cfg5_shard(2)
     mel, stop, _, align, pre = m.Inference_Step(tokens, None, None, mels, ml, prenet_masks=masks, attn_noise=noise,
                                                 return_pre_mel=True)
-    torch.cuda.synchronize()
+    m.synchronize()
+    assert m.decode_counters()[0] >= 1 and m.decode_counters()[1] == 1       # (all 500 steps on the bf16 persistent kernel)
     t0 = time.time()
     assert m.decode_plan(128)[1] is True          # (the form the oracle emulates is stated here, not asked of the product: DESIGN 3.1b)
     ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, dt=np.float64, mixed=True, fused_prenet0=True)
