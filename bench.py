@@ -194,6 +194,19 @@ def survey_step_bytes(d, B, Tv, mixed):
     return weights + acts, weights, acts
 
 
+def persistent_compulsory_bytes(d, B, Tv, mixed, steps):
+    """What a persistent decode launch MUST move per launch, whatever it keeps resident: every weight once, the processed memory once
+    (it lives in LDS afterwards), and per step the exchanged activations -- [prenet | context], h1, h2: written once and read at least
+    once, at the width they travel in (4 bytes; 2 as bf16 mirrors under mixed precision) --, the noise row read and the outputs
+    written (mel frames + stop logit + alignment row)."""
+    P1, A_ = d.prenet[1], d.att
+    H1, H2 = d.dec_rnn[0], d.dec_rnn[1]
+    weights = survey_step_bytes(d, B, Tv, mixed)[1]
+    sb = 2 if mixed else 4
+    per_step = B * ((P1 + A_ + H1 + H2) * sb * 2 + (d.mel * d.r + 1 + Tv) * 4 + Tv * 4)
+    return weights + B * Tv * A_ * 4 + steps * per_step
+
+
 def ideal_ms(d, B, Tv, Tref, mixed, steps):
     """SURVEY 8(d) "Ideal time": decode = steps x step bytes / 8 TB/s; postnet, encoder, value projection and GST at the dense MFMA peak
     of the compute dtype.  configs[1]: 3.8 + 1.8 + 0.3 = 5.9 ms."""
@@ -595,8 +608,9 @@ def main():
                                      "persistent_decode.frac_compulsory and frac_traffic" if persistent else None),
                          "frac_traffic": (traffic / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and dur_us) else None,
                          "persistent_decode": ({"launch_us": ms1 * 1e3 * n_steps_dec, "steps_per_launch": n_steps_dec,
-                                                "compulsory_bytes_per_step": w_bytes / n_steps_dec + act_bytes,
-                                                "frac_compulsory": (w_bytes / n_steps_dec + act_bytes) / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                "compulsory_bytes_per_step": persistent_compulsory_bytes(model.dims, B, Tv, args.mixed, n_steps_dec) / n_steps_dec,
+                                                "frac_compulsory": persistent_compulsory_bytes(model.dims, B, Tv, args.mixed, n_steps_dec) / n_steps_dec /
+                                                                   (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                                 "note": "achieved / frac price the step at SURVEY 8(d)'s algorithmic bytes (every weight once per step); "
                                                         "this kernel reads the weights once per LAUNCH -- frac_compulsory counts them so, frac_traffic is "
                                                         "what the counters saw (polling included): the step is bound by its dependent hand-offs "
@@ -619,7 +633,7 @@ def main():
                                          "TFLOP/s": step_flop / (step_us * 1e-6) / 1e12 if step_us > 0 else 0.0, "frac_mfma": step_frac_mfma,
                                          "kernels": {str(k): dict({"name": KNAMES[k], "avg_us": prof[k][0] * 1e3, "bytes": prof[k][2]},
                                                                   **({"algorithmic_bytes_per_launch": prof[k][2] * n_steps_dec,
-                                                                      "compulsory_bytes_per_launch": w_bytes + act_bytes * n_steps_dec}
+                                                                      "compulsory_bytes_per_launch": persistent_compulsory_bytes(model.dims, B, Tv, args.mixed, n_steps_dec)}
                                                                      if persistent else {}))
                                                      for k in prof}}},
         }

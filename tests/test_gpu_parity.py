@@ -308,7 +308,11 @@ def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers(monkeypatch, 
     assert time.perf_counter() - t0 < 10.0
     out = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=3)[0].cpu().numpy()
     m.synchronize()
-    assert np.array_equal(out, ref) and "warning" in m.last_message() and m.handoff_error() == 0
+    if mixed:       # (the injected fault also drops a member of the encoder's persistent BiLSTM; its per-step bf16 fallback sums in another order)
+        assert np.abs(out - ref).max() <= MIXED_TOL
+    else:
+        assert np.array_equal(out, ref)
+    assert "warning" in m.last_message() and m.handoff_error() == 0
     assert m.decode_counters()[1] == 0
 
 
