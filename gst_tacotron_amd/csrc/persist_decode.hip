@@ -952,835 +952,8 @@ __global__ __launch_bounds__(PD_NT) void gt_persist_decode_kernel(PersistDecodeA
 }
 
 
-// ====================================================================================================================== groups
-// Batches above 32 rows (and, as an experiment, 17..32 rows as two groups of 16): G groups of 16 MTG rows go through ONE set of
-// resident weights.  Every workgroup still owns gate tile `blockIdx.x` of both cells and runs each GEMM phase group by group:
-//   * ONE wait per phase for all groups (context flags, h1 arrivals, h2 arrivals) instead of one per group -- a satisfied wait still
-//     costs a poll's round trip;
-//   * the NEXT group's activation fragments are requested while the current group is multiplied (cell 1: a second fragment buffer;
-//     the K = 1024 phases: each fragment re-requested right behind the MFMAs that consumed it, lean_body.h's multi-chunk order), so a
-//     group's hand-off and fragment latencies hide behind its neighbours' arithmetic -- v1 of this kernel ran them back to back and
-//     spent 30 of 59 us per step at 128 rows waiting for fragments (profiles/r05_group_stamps.txt).
-// Per group the arithmetic is the one-group kernel's (= the launch path's single-chunk bodies', which its multi-chunk bodies
-// reproduce per 32-row chunk): bitwise the launches at any batch.  Roles: workgroup b < B runs utterance b's chain, then its tile for
-// every group with the tile's weights STREAMED (the chain's operands own the registers meanwhile; nobody helps: with one chain per
-// CU on half of the chip there is no idle half to help from); the next pj_tiles x MTG own a projection (tile, M-tile of the group);
-// the rest are plain.  Control: per-group arrival counters, per-utterance flags as before.
-template <int GM> struct PdG { float c1[GM], c2[GM], p1[GM], p2[GM]; };
-
-// `zt`: a per-step opaque zero added into every per-thread global address of these bodies.  Without it the step loop's invariant
-// addresses -- flags, counter shards and state rows of every group and parity: dozens of 64-bit pairs at four groups -- are hoisted
-// out of the loop and live across the chain, which needs the whole register file: they spill, and a scratch reload waits for vmcnt(0).
-#define PD_ZT(zt) int zt = 0; asm volatile("" : "+v"(zt))
-
-// ---- one wait for ALL groups: the context flags of every utterance (two per lane: B <= 128) ...
-__device__ __forceinline__ void pd_wait_flags_all(const PersistDecodeArgs& A, const uint32_t* f, uint32_t want, PdShared* sh) {
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        const bool h0 = lane < A.B, h1 = lane + 64 < A.B;
-        const uint32_t* p0 = f + (h0 ? lane : 0) * PD_FS;
-        const uint32_t* p1 = f + (h1 ? lane + 64 : 0) * PD_FS;
-        uint32_t spins = 0;
-        for (;;) {
-            uint32_t v0, v1;
-            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
-            const bool ok = (!h0 || v0 >= want) && (!h1 || v1 >= want);
-            if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(ok))) == 64) break;
-            if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
-            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
-        }
-    }
-    __syncthreads();
-}
-// ... and the arrival counters of groups [0, G) (PD_NSH shards each, one per lane; all requested, then one wait)
-template <int GM>
-__device__ __forceinline__ void pd_wait_count_all(const PersistDecodeArgs& A, const uint32_t* c, uint32_t want, PdShared* sh) {
-    static_assert(PD_NSH == 64, "one counter shard per lane");
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        uint32_t spins = 0;
-        for (;;) {
-            uint32_t u[GM];
-#pragma unroll
-            for (int g = 0; g < GM; ++g) {
-                u[g] = want;
-                if (g < A.G) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(u[g]) : "v"(c + g * (PD_NSH * 32) + lane * 32) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bool ok = true;
-#pragma unroll
-            for (int g = 0; g < GM; ++g) {
-                if (g < A.G) {
-                    asm volatile("" : "+v"(u[g]));
-                    uint32_t v = u[g];
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
-                    ok = ok && __builtin_amdgcn_readfirstlane(v) >= want;
-                }
-            }
-            if (ok) break;
-            if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
-            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
-        }
-    }
-    __syncthreads();
-}
-
-// the wave's eight K = 1024 fragments times one weight tile.  ORDER16: two accumulator pairs, fragments 0, 2, 4, 6 -> a, 1, 3, 5, 7 -> b
-// (the launch path's 16-wave order, pd_rec_tile); else all eight -> a in ascending order.  RELOAD: fragment i of group `gn` is requested
-// right behind the MFMAs that consumed fragment i (gn = the group itself when there is no next one: re-read, never multiplied).
-template <int MTG, bool ORDER16, bool RELOAD>
-__device__ __forceinline__ void pd_g_mma8(float4 (&x0)[8], float4 (&x1)[8], const float4 (&w)[8], f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1,
-                                          const float* base, int MT, int gn) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const auto rs = gt_rsrc(base, 0x7FFFF000u);
-    const uint32_t m0 = (uint32_t)(MTG * gn) * 1024u, m1 = (uint32_t)min(MTG * gn + 1, MT - 1) * 1024u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        f32x4& c0 = (ORDER16 && (i & 1)) ? b0 : a0;
-        f32x4& c1 = (ORDER16 && (i & 1)) ? b1 : a1;
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].x, w[i].x, c0, 0, 0, 0); if (MTG == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].x, w[i].x, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].y, w[i].y, c0, 0, 0, 0); if (MTG == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].y, w[i].y, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].z, w[i].z, c0, 0, 0, 0); if (MTG == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].z, w[i].z, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[i].w, w[i].w, c0, 0, 0, 0); if (MTG == 2) c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[i].w, w[i].w, c1, 0, 0, 0);
-        if (RELOAD) {
-            PD_PIN();
-            const uint32_t so = (uint32_t)((wave + i * PD_NW) * MT) * 1024u;
-            x0[i] = gt_bload4_sc1(rs, (uint32_t)lane * 16u, so + m0);
-            if (MTG == 2) x1[i] = gt_bload4_sc1(rs, (uint32_t)lane * 16u, so + m1);
-            PD_PIN();
-        }
-    }
-}
-// sums of a recurrent-half tile from its accumulators (pd_rec_tile's orders).  TWOPASS: the 16-slab sum through EIGHT slabs -- virtual
-// waves 0..7, then 8..15 onto the running sum: the same sequence of additions (chain workgroups: their LDS holds the processed memory).
-// `cnt`: a deferred arrival (pd_reduce_arrive) or NULL
-template <bool ORDER16, bool TWOPASS>
-__device__ __forceinline__ float pd_g_rec_sum(float* lds, float bias, const f32x4& a0, const f32x4& a1, const f32x4& b0, const f32x4& b1, uint32_t* cnt = nullptr,
-                                              bool two = true) {
-    const int wave = threadIdx.x >> 6;
-    if (ORDER16) {
-        if (TWOPASS && two) {
-            pd_spill(lds, wave, a0, a1);
-            const float z = pd_reduce_arrive<8>(lds, bias, cnt);
-            pd_spill(lds, wave, b0, b1);
-            return pd_reduce<8>(lds, z);
-        }
-        pd_spill(lds, wave, a0, a1);
-        pd_spill(lds, wave + 8, b0, b1);
-        return pd_reduce_arrive<16>(lds, bias, cnt);
-    }
-    pd_spill(lds, wave, a0, a1);
-    return pd_reduce_arrive<8>(lds, bias, cnt);
-}
-
-// ---- the phases, for all groups.  State access: `c(g)` / `p(g)` return references (registers, or LDS in the projection role).
-// LSTM cell 1 of every group: z = [p | ctx] . W1x + p1[g]; the next group's fragments in a second buffer
-template <int GM, int MTG, class C1, class P1>
-__device__ __forceinline__ void pd_g_cell1_all(const PersistDecodeArgs& A, const float4 (&wx1)[3], int t, int tile, float* lds, C1 c1, P1 p1, PdShared* sh, int role, int zt) {
-    constexpr int RG = 16 * MTG;
-    const int par = t & 1, MT = A.MT;
-    pd_wait_flags_all(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, sh);       // (a chain's context flag follows its prenet flag)
-    if (sh->abort) return;
-    PD_STAMP(role, 2);
-    float4 xa0[3], xa1[3], xb0[3], xb1[3];
-    pd_g_xload<MTG, 0, 3, 3>(A.xa[par], MT, 0, xa0, xa1);
-#pragma unroll
-    for (int g = 0; g < GM; ++g) {
-        if (g < A.G) {
-            float4 (&x0)[3] = (g & 1) ? xb0 : xa0;
-            float4 (&x1)[3] = (g & 1) ? xb1 : xa1;
-            PD_PIN();
-            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-            pd_g_mma<MTG, 3, 0, 1, 3>(x0, x1, wx1, a0, a1);
-            // (group g - 1's h1 stores were left in flight: their acknowledgement arrived under this group's MFMAs; drained here, its
-            // arrival is signalled behind the reduction's first barrier -- the last group's at once, everybody waits for it.  The next
-            // group's fragments are requested BEHIND the drain -- in front of it the drain waited for them -- and land under the epilogue)
-            if (g > 0) pd_drain();
-            PD_PIN();
-            if (g + 1 < GM && g + 1 < A.G) {
-                if (g & 1) pd_g_xload<MTG, 0, 3, 3>(A.xa[par], MT, g + 1, xa0, xa1);
-                else pd_g_xload<MTG, 0, 3, 3>(A.xa[par], MT, g + 1, xb0, xb1);
-            }
-            PD_PIN();
-            pd_spill(lds, threadIdx.x >> 6, a0, a1);
-            const float z = pd_reduce_arrive<8>(lds, p1(g), g > 0 ? A.ctl + zt + PD_CNT3 + (g - 1) * (PD_NSH * 32) : nullptr);
-            pd_gates_store(z, c1(g), A.h1[par], tile + zt, A.B, MT, RG * g, RG);
-            if (g == A.G - 1) pd_arrive(A.ctl + zt + PD_CNT3 + g * (PD_NSH * 32));
-            PD_STAMP(role, 3 + 7 * g);
-        }
-    }
-}
-
-// LSTM cell 2 of every group: z = h1_t . W2x + p2[g]; REC1: then, from the same fragments, the layer-1 recurrent half for the next step,
-// the next group's fragments requested behind its MFMAs (else behind cell 2's own)
-// STREAM_H2 (chain workgroups): the layer-2 recurrent tile for the next phase is requested once the last group's cell-2 MFMAs have
-// released W2x's registers
-template <int GM, int MTG, bool REC1, bool TWOPASS, bool STREAM_H2, class C2, class P2, class P1>
-__device__ __forceinline__ void pd_g_cell2_all(const PersistDecodeArgs& A, const float4 (&wx2)[8], const float4 (&wh1)[8], float4 (&wh2)[8], int t, int tile, float* lds,
-                                               C2 c2, P2 p2, P1 p1, PdShared* sh, int role, int zt) {
-    constexpr int RG = 16 * MTG;
-    const int par = t & 1, MT = A.MT;
-    pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
-    if (sh->abort) return;
-    PD_STAMP(role, 4);
-    float4 x0[8], x1[8];
-    pd_g_xload<MTG, 0, 8, 8>(A.h1[par], MT, 0, x0, x1);
-    PD_PIN();
-    const float bias1 = A.b1h[tile * 16 + (threadIdx.x & 15)];
-#pragma unroll
-    for (int g = 0; g < GM; ++g) {
-        if (g < A.G) {
-            const int gn = min(g + 1, A.G - 1);
-            f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-            pd_g_mma8<MTG, false, !REC1>(x0, x1, wx2, a0, a1, b0, b1, A.h1[par], MT, gn);
-            // REC1: group g - 1's h2 stores stayed in flight under its recurrent half and this group's MFMAs -- which waited for every
-            // fragment re-requested in between, so nothing is left to wait for here -- and its arrival is signalled behind this
-            // reduction's first barrier; the last group's at once (everybody waits for it)
-            const bool deferred = REC1 && g > 0;
-            if (deferred) pd_drain();
-            pd_spill(lds, threadIdx.x >> 6, a0, a1);
-            const float z = pd_reduce_arrive<8>(lds, p2(g), deferred ? A.ctl + zt + PD_CNT4 + (g - 1) * (PD_NSH * 32) : nullptr);
-            pd_gates_store(z, c2(g), A.h2[par], tile + zt, A.B, MT, RG * g, RG);
-            if (!REC1 || g == A.G - 1) pd_arrive(A.ctl + zt + PD_CNT4 + g * (PD_NSH * 32));
-            PD_STAMP(role, 5 + 7 * g);
-            if (STREAM_H2 && g == A.G - 1 && t + 1 < A.steps) pd_load_tile<8>(A.w2h, tile, wh2);
-            if (REC1) {
-                a0 = f32x4{0, 0, 0, 0}; a1 = f32x4{0, 0, 0, 0};
-                pd_g_mma8<MTG, true, true>(x0, x1, wh1, a0, a1, b0, b1, A.h1[par], MT, gn);
-                p1(g) = pd_g_rec_sum<true, TWOPASS>(lds, bias1, a0, a1, b0, b1, nullptr, A.twopass != 0);
-                PD_STAMP(role, 6 + 7 * g);
-            }
-        }
-    }
-}
-
-// a recurrent half of every group from the state in memory: LAYER 1 -> p(g) = h1_t . W1h + b1 (projection role), 2 -> h2_t . W2h + b2
-// (tiles below co_tiles sum in the projection launch's co-workers' 8-wave order)
-template <int GM, int MTG, int LAYER, bool TWOPASS, bool WAIT, class P>
-__device__ __forceinline__ void pd_g_rec_all(const PersistDecodeArgs& A, const float4 (&wh)[8], int t, int tile, float* lds, P p, PdShared* sh, int role, int zt) {
-    const int MT = A.MT;
-    if (WAIT) {
-        pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
-        if (sh->abort) return;
-    }
-    PD_STAMP(role, 7);
-    const float* hb = LAYER == 1 ? A.h1[t & 1] : A.h2[t & 1];
-    const float bias = (LAYER == 1 ? A.b1h : A.b2h)[tile * 16 + (threadIdx.x & 15)];
-    // (the summation order is a property of the tile: the branch encloses the whole phase -- first fragment loads included -- so that
-    // the fragments carried from group to group belong to ONE arm: shared between the arms, the allocator gave every re-requested
-    // fragment a register of its own and spilled)
-    if (LAYER == 1 || tile >= A.co_tiles) {
-        float4 x0[8], x1[8];
-        pd_g_xload<MTG, 0, 8, 8>(hb, MT, 0, x0, x1);
-        PD_PIN();
-#pragma unroll
-        for (int g = 0; g < GM; ++g) {
-            if (g < A.G) {
-                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-                pd_g_mma8<MTG, true, true>(x0, x1, wh, a0, a1, b0, b1, hb, MT, min(g + 1, A.G - 1));
-                p(g) = pd_g_rec_sum<true, TWOPASS>(lds, bias, a0, a1, b0, b1, nullptr, A.twopass != 0);
-                PD_STAMP(role, 8 + 7 * g);
-            }
-        }
-    } else {
-        float4 x0[8], x1[8];
-        pd_g_xload<MTG, 0, 8, 8>(hb, MT, 0, x0, x1);
-        PD_PIN();
-#pragma unroll
-        for (int g = 0; g < GM; ++g) {
-            if (g < A.G) {
-                f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0};
-                pd_g_mma8<MTG, false, true>(x0, x1, wh, a0, a1, b0, b1, hb, MT, min(g + 1, A.G - 1));
-                p(g) = pd_g_rec_sum<false, TWOPASS>(lds, bias, a0, a1, b0, b1);
-                PD_STAMP(role, 8 + 7 * g);
-            }
-        }
-    }
-}
-
-// a tile's four GEMM halves for every group; CHAIN: utterance blockIdx.x's chain first, the tile's weights streamed -- each requested a
-// phase ahead of its use
-template <int GM, int MTG, bool CHAIN>
-__device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float* smem, PdShared* sh) {
-    float* lds = smem;
-    const int tile = blockIdx.x, b = blockIdx.x, tid = threadIdx.x, col = tid & 15;
-    constexpr int role = CHAIN ? 0 : 2;
-    PdW W;
-    PdG<GM> S;
-#pragma unroll
-    for (int g = 0; g < GM; ++g) { S.c1[g] = 0.f; S.c2[g] = 0.f; S.p1[g] = A.b1h[tile * 16 + col]; S.p2[g] = A.b2h[tile * 16 + col]; }
-    auto c1 = [&](int g) -> float& { return S.c1[g]; };
-    auto c2 = [&](int g) -> float& { return S.c2[g]; };
-    auto p1 = [&](int g) -> float& { return S.p1[g]; };
-    auto p2 = [&](int g) -> float& { return S.p2[g]; };
-    PdChainLds L{};
-    PdChainRegs R{};
-    if (CHAIN) {
-        L = pd_carve(smem, A.tvp, A.twopass ? 8 : 16);
-        R.Tv = A.tok_len ? max(1, min(A.Tv, (int)A.tok_len[b])) : A.Tv;
-        R.drop = A.drop_rate > 0.f;
-        R.hashed = R.drop && A.keep_hash != 0;
-        R.noisy = A.sigmoid_noise > 0.f;
-        R.seed = R.hashed ? *A.seed_ptr : 0ull;
-        R.bias1 = tid < PD_P ? A.b1[tid] : 0.f;
-        R.biasq = tid < PD_A ? A.bq[tid] : 0.f;
-        R.sbias = A.score_bias[0];
-        const float4* src = reinterpret_cast<const float4*>(A.pm + (size_t)b * A.Tv * PD_A);
-        for (int e = tid; e < A.tvp * PD_A / 4; e += PD_NT) {
-            const int row = e / (PD_A / 4), c4 = e % (PD_A / 4);
-            *reinterpret_cast<float4*>(L.tile + row * PD_LDV + 4 * c4) = row < R.Tv ? src[(size_t)row * (PD_A / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (tid < PD_A) L.vs[tid] = A.av[tid];
-        if (tid < A.tvp) L.pv[tid] = tid == 0 ? 1.f : 0.f;
-    } else {
-        pd_load_tile<3>(A.w1x, tile, W.x1); pd_load_tile<8>(A.w2x, tile, W.x2);
-        pd_load_tile<8>(A.w1h, tile, W.h1); pd_load_tile<8>(A.w2h, tile, W.h2);
-    }
-    __syncthreads();
-    // The chain needs the whole register file (all of prenet 1's weights in flight): the tile's per-group state -- cell states,
-    // recurrent halves -- waits in memory meanwhile (its own rows of `stash`, written and re-read by the same thread: L2 hits,
-    // requested back before the first flag wait).
-    for (int t = 0; t < A.steps; ++t) {
-        PD_STAMP(role, 0);
-        PD_ZT(zt);
-        float* st = A.stash + (size_t)blockIdx.x * (4 * GM * PD_NT) + tid + zt;
-        if (CHAIN) {
-#pragma unroll
-            for (int g = 0; g < GM; ++g) {
-                st[(4 * g + 0) * PD_NT] = S.c1[g]; st[(4 * g + 1) * PD_NT] = S.c2[g];
-                st[(4 * g + 2) * PD_NT] = S.p1[g]; st[(4 * g + 3) * PD_NT] = S.p2[g];
-            }
-            PD_PIN();
-            float unused = 0.f;
-            int bs = b;
-            asm volatile("" : "+s"(bs));
-            pd_chain<false>(A, L, R, t, bs, sh, unused, zt);
-            if (sh->abort) return;
-            PD_STAMP(role, 1);
-            PD_PIN();
-            pd_load_tile<3>(A.w1x, tile, W.x1);
-#pragma unroll
-            for (int g = 0; g < GM; ++g) {
-                S.c1[g] = st[(4 * g + 0) * PD_NT]; S.c2[g] = st[(4 * g + 1) * PD_NT];
-                S.p1[g] = st[(4 * g + 2) * PD_NT]; S.p2[g] = st[(4 * g + 3) * PD_NT];
-            }
-            pd_load_tile<8>(A.w2x, tile, W.x2); pd_load_tile<8>(A.w1h, tile, W.h1);        // (for the NEXT phase: they arrive during cell 1)
-        }
-        pd_g_cell1_all<GM, MTG>(A, W.x1, t, tile, lds, c1, p1, sh, role, zt);
-        if (sh->abort) return;
-        pd_g_cell2_all<GM, MTG, true, CHAIN, CHAIN>(A, W.x2, W.h1, W.h2, t, tile, lds, c2, p2, p1, sh, role, zt);
-        if (sh->abort) return;
-        if (t + 1 == A.steps) break;
-        pd_g_rec_all<GM, MTG, 2, CHAIN, true>(A, W.h2, t, tile, lds, p2, sh, role, zt);
-        if (sh->abort) return;
-    }
-}
-
-// a projection (tile, M-tile of the group) + the LSTM tile.  Resident: the layer-2 input half, the layer-1 recurrent half (fused into
-// cell 2 as in the tile roles: as a pass of its own over h1 behind the projections it made this role the last to finish every step,
-// and every other workgroup waited for its cell-1 arrivals: v1 of this kernel, 60 us per step at 128 rows) ;
-// W1x (24 KB) is streamed at the start of every step (it arrives while the workgroup waits for the chains), the projection tile in
-// front of the wait for the h2 arrivals, the layer-2 recurrent tile behind the projections; the per-group state (cell states, recurrent halves) lives in LDS behind the slabs -- this
-// role has no chain and the LDS to spare, and not the registers.
-template <int GM, int MTG>
-__device__ __forceinline__ void pd_g_run_proj(const PersistDecodeArgs& A, float* lds, PdShared* sh) {
-    const int tile = blockIdx.x, col = threadIdx.x & 15;
-    const int pi = tile - A.n_chain, ptile = pi % A.pj_tiles, pm = pi / A.pj_tiles;
-    PdW W;
-    pd_load_tile<8>(A.w2x, tile, W.x2); pd_load_tile<8>(A.w1h, tile, W.h1);
-    float* sl = lds + 16 * PD_SLAB + threadIdx.x;           // [4 GM][512]: c1, c2, p1, p2 of group g at rows 4 g ..
-#pragma unroll
-    for (int g = 0; g < GM; ++g) { sl[(4 * g + 0) * PD_NT] = 0.f; sl[(4 * g + 1) * PD_NT] = 0.f; sl[(4 * g + 2) * PD_NT] = A.b1h[tile * 16 + col]; sl[(4 * g + 3) * PD_NT] = A.b2h[tile * 16 + col]; }
-    auto c1 = [&](int g) -> float& { return sl[(4 * g + 0) * PD_NT]; };
-    auto c2 = [&](int g) -> float& { return sl[(4 * g + 1) * PD_NT]; };
-    auto p1 = [&](int g) -> float& { return sl[(4 * g + 2) * PD_NT]; };
-    auto p2 = [&](int g) -> float& { return sl[(4 * g + 3) * PD_NT]; };
-    for (int t = 0; t < A.steps; ++t) {
-        PD_STAMP(1, 0);
-        PD_ZT(zt);
-        pd_load_tile<3>(A.w1x, tile, W.x1);
-        pd_g_cell1_all<GM, MTG>(A, W.x1, t, tile, lds, c1, p1, sh, 1, zt);
-        if (sh->abort) return;
-        pd_g_cell2_all<GM, MTG, true, false, false>(A, W.x2, W.h1, W.h2, t, tile, lds, c2, p2, p1, sh, 1, zt);
-        if (sh->abort) return;
-        // every group's projection behind ONE wait for the h2 arrivals (the chains that need them start ~10 us later: their
-        // workgroups still have this step's recurrent halves to multiply); the projection tile (72 KB) arrives during that wait
-        float4 wpj[9];
-        pd_load_tile<9>(A.wp, ptile, wpj);
-        pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
-        if (sh->abort) return;
-#pragma unroll
-        for (int g = 0; g < GM; ++g)
-            if (g < A.G) pd_proj<true>(A, wpj, t, ptile, MTG * g + pm, lds, sh, g);
-        if (t + 1 == A.steps) break;
-        pd_load_tile<8>(A.w2h, tile, W.h2);
-        PD_PIN();
-        pd_g_rec_all<GM, MTG, 2, false, false>(A, W.h2, t, tile, lds, p2, sh, 1, zt);
-    }
-}
-
-template <int GM, int MTG>
-__global__ __launch_bounds__(PD_NT) void gt_persist_decode_g_kernel(PersistDecodeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ PdShared sh;
-    if (threadIdx.x == 0) sh.abort = 0;
-    __syncthreads();
-    const int tile = blockIdx.x;
-#ifndef PD_GONLY
-#define PD_GONLY -1         // (register-budget diagnosis: compile one role alone)
-#endif
-    if (tile < A.n_chain) { if (PD_GONLY < 0 || PD_GONLY == 0) pd_g_run_tile<GM, MTG, true>(A, smem, &sh); }
-    else if (tile < A.n_chain + A.pj_tiles * MTG) { if (PD_GONLY < 0 || PD_GONLY == 1) pd_g_run_proj<GM, MTG>(A, smem, &sh); }
-    else if (PD_GONLY < 0 || PD_GONLY == 2) pd_g_run_tile<GM, MTG, false>(A, smem, &sh);
-}
-
-// ====================================================================================================================== bf16
-// Mixed precision (Use_Mixed_Precision: bf16 GEMM operands, fp32 accumulation / state / epilogues; BASELINE configs[4]) on the
-// persistent launch: ONE group of up to 64 rows (four M-tiles).  On bf16 MFMA (v_mfma_f32_16x16x32_bf16) the step's GEMMs are a few
-// hundred nanoseconds; what a step costs is its dependent phases and their epilogues, so the batch is NOT cut into groups of 32 rows
-// (each with its own epilogues): a wave's fragments of four M-tiles are as many registers as two in fp32.  Roles as in the group
-// kernels: workgroup b < B runs utterance b's chain (fp32, as in the launch path) and its gate tile with streamed weights, the next
-// pj_tiles x MT own a projection (tile, M-tile), the rest are plain.  Activations travel ONLY as the bf16 mirrors the launch path's
-// multi-chunk bodies read (kernels.h gt_blk_off_h: the MFMA's A operand as is), rounded once (RNE) by their producer -- the same
-// values the launch path's consumers get, in the same k-block -> wave assignment and summation orders (lean_body.h
-// gt_lean_core_bf16 / gt_lean_mc on eight waves; the recurrent halves in the front launch's 16-wave or the projection launch's
-// 8-wave order): bitwise the launches.
-constexpr int PDH_MT = 4, PDH_BMAX = 16 * PDH_MT;
-struct PdWh { u32x4 x1[2], h1[4], x2[4], h2[4]; };
-constexpr int PDH_SLAB = PDH_MT * 16 * 17;
-
-template <int KPW32>
-__device__ __forceinline__ void pdh_load_tile(const float* wp, int tile, int nkb32, u32x4 (&dst)[KPW32]) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const u32x4* wl = reinterpret_cast<const u32x4*>(wp) + ((size_t)tile * nkb32 + wave) * 64 + lane;
-#pragma unroll
-    for (int i = 0; i < KPW32; ++i) dst[i] = wl[(size_t)((wave + i * PD_NW < nkb32) ? i : 0) * PD_NW * 64];      // (past the end: re-read, never multiplied)
-}
-// the wave's fragments of 32-k blocks kb_off + wave + 8 i (i < KPW32, those below nkb32) of a mirror, all PDH_MT M-tiles
-template <int KPW32>
-__device__ __forceinline__ void pdh_xload(const uint16_t* base, int MT, int nkb32, int kb_off, u32x4 (&x)[PDH_MT][KPW32]) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const auto rs = gt_rsrc(base, 0x7FFFF000u);
-#pragma unroll
-    for (int i = 0; i < KPW32; ++i) {
-        const int kb = kb_off + ((wave + i * PD_NW < nkb32) ? wave + i * PD_NW : wave);
-#pragma unroll
-        for (int mt = 0; mt < PDH_MT; ++mt) {
-            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (kb * MT + min(mt, MT - 1)) * 1024, 16);
-            __builtin_memcpy(&x[mt][i], &t, 16);
-        }
-    }
-}
-template <int KPW32, int OFF, int STRIDE>
-__device__ __forceinline__ void pdh_mma(const u32x4 (&x)[PDH_MT][KPW32], const u32x4 (&w)[KPW32], int nkb32, f32x4 (&acc)[PDH_MT]) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#pragma unroll
-    for (int i = OFF; i < KPW32; i += STRIDE) {
-        if (wave + i * PD_NW < nkb32) {
-            bf16x8 bw;
-            __builtin_memcpy(&bw, &w[i], 16);
-#pragma unroll
-            for (int mt = 0; mt < PDH_MT; ++mt) {
-                bf16x8 a;
-                __builtin_memcpy(&a, &x[mt][i], 16);
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[mt], 0, 0, 0);
-            }
-        }
-    }
-}
-__device__ __forceinline__ void pdh_spill(float* lds, int slab, const f32x4 (&acc)[PDH_MT]) {
-    float (*part)[PDH_MT * 16][17] = reinterpret_cast<float (*)[PDH_MT * 16][17]>(lds);
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 15, q = lane >> 4;
-#pragma unroll
-    for (int mt = 0; mt < PDH_MT; ++mt)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) part[slab][mt * 16 + q * 4 + v][r] = acc[mt][v];
-}
-// elements (row = tid >> 4, col) and (row + 32, col): base + the first NSLAB slabs in ascending order
-template <int NSLAB>
-__device__ __forceinline__ void pdh_reduce(float* lds, const float (&base)[2], float (&z)[2]) {
-    __syncthreads();
-    const float (*part)[PDH_MT * 16][17] = reinterpret_cast<const float (*)[PDH_MT * 16][17]>(lds);
-    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        float v = base[e];
-#pragma unroll
-        for (int w = 0; w < NSLAB; ++w) v += part[w][row + 32 * e][col];
-        z[e] = v;
-        asm volatile("" : "+v"(z[e]));      // (one element's reads at a time: with both elements' 32 reads in flight the allocator spilled)
-    }
-    __syncthreads();
-}
-// gates (pd_gates_store's arithmetic) of both elements; h leaves as the bf16 mirror only: 4 units = one 8-byte write-through store
-__device__ __forceinline__ void pdh_gates_store(const float (&z)[2], float (&c)[2], uint16_t* hh, int tile, int M, int MT) {
-    const int col = threadIdx.x & 15;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int row = (threadIdx.x >> 4) + 32 * e;
-        const float zf = __shfl_down(z[e], 4, 16), zg = __shfl_down(z[e], 8, 16), zo = __shfl_down(z[e], 12, 16);
-        float hv = 0.f;
-        if (col < 4 && row < M) {
-            const float gi = gt_sigmoid(z[e]), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
-            c[e] = __builtin_fmaf(gf, c[e], gi * gg);
-            hv = go * gt_tanh(c[e]);
-        }
-        const float h1v = __shfl_down(hv, 1, 16), h2v = __shfl_down(hv, 2, 16), h3v = __shfl_down(hv, 3, 16);
-        if (col == 0 && row < M) {
-            uint2 pk;
-            pk.x = (uint32_t)gt_bf16_bits(hv) | ((uint32_t)gt_bf16_bits(h1v) << 16);
-            pk.y = (uint32_t)gt_bf16_bits(h2v) | ((uint32_t)gt_bf16_bits(h3v) << 16);
-            pd_st2_sc1(reinterpret_cast<uint2*>(hh + gt_blk_off_h(row, tile * 4, MT)), pk);
-        }
-    }
-}
-// sums of a recurrent-half tile: 16-wave order (fragments 0, 2 -> a; 1, 3 -> b; 16 slabs, or two passes over 8) or 8-wave order
-template <bool ORDER16>
-__device__ __forceinline__ void pdh_rec(const u32x4 (&x)[PDH_MT][4], const u32x4 (&w)[4], float bias, float* lds, bool two, float (&p)[2]) {
-    const int wave = threadIdx.x >> 6;
-    const float b2[2] = {bias, bias};
-    if (ORDER16) {
-        f32x4 a[PDH_MT], b[PDH_MT];
-#pragma unroll
-        for (int mt = 0; mt < PDH_MT; ++mt) { a[mt] = f32x4{0, 0, 0, 0}; b[mt] = f32x4{0, 0, 0, 0}; }
-        pdh_mma<4, 0, 2>(x, w, 32, a);
-        pdh_mma<4, 1, 2>(x, w, 32, b);
-        if (two) {
-            float z1[2];
-            pdh_spill(lds, wave, a);
-            pdh_reduce<8>(lds, b2, z1);
-            pdh_spill(lds, wave, b);
-            pdh_reduce<8>(lds, z1, p);
-        } else {
-            pdh_spill(lds, wave, a);
-            pdh_spill(lds, wave + 8, b);
-            pdh_reduce<16>(lds, b2, p);
-        }
-    } else {
-        f32x4 a[PDH_MT];
-#pragma unroll
-        for (int mt = 0; mt < PDH_MT; ++mt) a[mt] = f32x4{0, 0, 0, 0};
-        pdh_mma<4, 0, 1>(x, w, 32, a);
-        pdh_spill(lds, wave, a);
-        pdh_reduce<8>(lds, b2, p);
-    }
-}
-struct PdHS { float c1[2], c2[2], p1[2], p2[2]; };
-
-// The chain workgroups' recurrent halves are computed by HELPER workgroups -- plain workgroup i helps chain tile i; at <= 64 rows there
-// are more plain workgroups than chains -- from the state fragments the helper holds anyway, and handed back through memory
-// (hpart [layer][tile][64 rows][16 columns], one tagged flag per layer and tile).  A chain workgroup's step is then chain -> cell 1 ->
-// cell 2 and straight on to the next chain, whose prenet-0 hand-off is what it waits for: the step's critical path no longer carries
-// its two recurrent halves (1.4 us each + the wait for the h2 arrivals between them), which the helpers multiply while they would
-// otherwise wait for the chains.
-constexpr int PDH_HP = PDH_MT * 16 * 16;     // floats of one handed-back tile
-__device__ __forceinline__ void pdh_publish(const float (&v)[2], float* dst, uint32_t* flag, uint32_t tag) {
-    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float v1 = __shfl_down(v[e], 1, 16), v2 = __shfl_down(v[e], 2, 16), v3 = __shfl_down(v[e], 3, 16);
-        if ((col & 3) == 0) pd_st4_sc1(dst + (row + 32 * e) * 16 + col, make_float4(v[e], v1, v2, v3));
-    }
-    pd_drain();
-    __syncthreads();
-    if (threadIdx.x == 0) pd_st1_sc1(flag, tag);
-}
-// a chain workgroup's wait for every context flag (<= 64 utterances: one per lane) AND, in the same polls, for its two helpers' flags
-__device__ __forceinline__ void pdh_wait_flags_helped(const PersistDecodeArgs& A, const uint32_t* f, uint32_t want, const uint32_t* fh1, const uint32_t* fh2, uint32_t want_h,
-                                                      PdShared* sh) {
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        const bool h0 = lane < A.B;
-        const uint32_t* p0 = f + (h0 ? lane : 0) * PD_FS;
-        const uint32_t* p1 = lane == 0 ? fh1 : fh2;
-        uint32_t spins = 0;
-        for (;;) {
-            uint32_t v0, v1;
-            asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(p0), "v"(p1) : "memory");
-            const bool ok = (!h0 || v0 >= want) && (lane > 1 || v1 >= want_h);
-            if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(ok))) == 64) break;
-            if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
-            if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
-        }
-    }
-    __syncthreads();
-}
-
-// HELPED (chain workgroups): the recurrent halves of this step arrive from the helpers; they are requested behind the flag wait and
-// land under the fragments and MFMAs
-template <bool HELPED>
-__device__ __forceinline__ void pdh_cell1(const PersistDecodeArgs& A, const u32x4 (&wx1)[2], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role, int zt) {
-    const int par = t & 1, MT = A.MT;
-    if (HELPED) pdh_wait_flags_helped(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, A.ctl + zt + PD_F_H + tile * 32, A.ctl + zt + PD_F_H + (PDH_BMAX + tile) * 32, (uint32_t)t, sh);
-    else pd_wait_flags_all(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, sh);
-    if (sh->abort) return;
-    PD_STAMP(role, 2);
-    if (HELPED && t > 0) {
-        const auto rh = gt_rsrc(A.hpart, 2u * PDH_BMAX * PDH_HP * 4u);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const uint32_t off = (uint32_t)((tile * PDH_HP + (threadIdx.x + zt) + 512 * e) * 4);
-            S.p1[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (int)off, 0, 16));
-            S.p2[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (int)off, PDH_BMAX * PDH_HP * 4, 16));
-        }
-    }
-    u32x4 x[PDH_MT][2];
-    pdh_xload<2>(A.xah[par], MT, PD_KBP / 2 + PD_KBC / 2, 0, x);
-    PD_PIN();
-    f32x4 a[PDH_MT];
-#pragma unroll
-    for (int mt = 0; mt < PDH_MT; ++mt) a[mt] = f32x4{0, 0, 0, 0};
-    pdh_mma<2, 0, 1>(x, wx1, PD_KBP / 2 + PD_KBC / 2, a);
-    pdh_spill(lds, threadIdx.x >> 6, a);
-    float z[2];
-    pdh_reduce<8>(lds, S.p1, z);
-    pdh_gates_store(z, S.c1, A.h1h[par], tile + zt, A.B, MT);
-    pd_arrive(A.ctl + zt + PD_CNT3);
-    PD_STAMP(role, 3);
-}
-// cell 2; the h1 fragments stay in `x` for the recurrent halves that follow (pdh_rec1)
-__device__ __forceinline__ void pdh_cell2(const PersistDecodeArgs& A, const u32x4 (&wx2)[4], u32x4 (&x)[PDH_MT][4], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role,
-                                          int zt) {
-    const int par = t & 1, MT = A.MT;
-    pd_wait_count(A, A.ctl + zt + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
-    if (sh->abort) return;
-    PD_STAMP(role, 4);
-    pdh_xload<4>(A.h1h[par], MT, PD_KBH / 2, 0, x);
-    PD_PIN();
-    f32x4 a[PDH_MT];
-#pragma unroll
-    for (int mt = 0; mt < PDH_MT; ++mt) a[mt] = f32x4{0, 0, 0, 0};
-    pdh_mma<4, 0, 1>(x, wx2, PD_KBH / 2, a);
-    pdh_spill(lds, threadIdx.x >> 6, a);
-    float z[2];
-    pdh_reduce<8>(lds, S.p2, z);
-    pdh_gates_store(z, S.c2, A.h2h[par], tile + zt, A.B, MT);
-    pd_arrive(A.ctl + zt + PD_CNT4);
-    PD_STAMP(role, 5);
-}
-// layer-1 recurrent half of tile `tl` for the next step from the fragments cell 2 left in `x` (own tile: into `p`; a chain tile's: published)
-__device__ __forceinline__ void pdh_rec1(const PersistDecodeArgs& A, const u32x4 (&x)[PDH_MT][4], const u32x4 (&wh1)[4], int tl, float* lds, bool two, float (&p)[2]) {
-    pdh_rec<true>(x, wh1, A.b1h[tl * 16 + (threadIdx.x & 15)], lds, two, p);
-}
-// layer-2 recurrent half for the next step: this workgroup's tile and, HELP, chain tile `help` (published)
-template <bool WAIT, bool HELP>
-__device__ __forceinline__ void pdh_rec2(const PersistDecodeArgs& A, u32x4 (&wh2)[4], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role, int zt, int help) {
-    if (HELP) pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, wh2);      // (a helper streams its own W2h: arrives during the wait)
-    if (WAIT) {
-        pd_wait_count(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
-        if (sh->abort) return;
-    }
-    PD_STAMP(role, 7);
-    const int col = threadIdx.x & 15;
-    // (the summation order is a property of the tile.  Each arm loads its own fragments: shared between the arms of a branch, the
-    // allocator gave up on packing them and spilled -- the group kernels' pd_g_rec_all met the same)
-    if (tile < A.co_tiles) {
-        u32x4 x[PDH_MT][4];
-        pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
-        PD_PIN();
-        pdh_rec<false>(x, wh2, A.b2h[tile * 16 + col], lds, false, S.p2);
-    } else {
-        u32x4 x[PDH_MT][4];
-        pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
-        PD_PIN();
-        pdh_rec<true>(x, wh2, A.b2h[tile * 16 + col], lds, false, S.p2);
-    }
-    PD_STAMP(role, 8);
-    if (HELP) {         // (behind the own half: the chain workgroup needs it at its next cell 2, a whole chain away)
-        pdh_load_tile<4>(A.w2h, help, PD_KBH / 2, wh2);
-        float v[2];
-        if (help < A.co_tiles) {
-            u32x4 x[PDH_MT][4];
-            pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
-            PD_PIN();
-            pdh_rec<false>(x, wh2, A.b2h[help * 16 + col], lds, false, v);
-        } else {
-            u32x4 x[PDH_MT][4];
-            pdh_xload<4>(A.h2h[t & 1], A.MT, PD_KBH / 2, 0, x);
-            PD_PIN();
-            pdh_rec<true>(x, wh2, A.b2h[help * 16 + col], lds, false, v);
-        }
-        pdh_publish(v, A.hpart + (size_t)(PDH_BMAX + help) * PDH_HP, A.ctl + zt + PD_F_H + (PDH_BMAX + help) * 32, (uint32_t)t + 1u);
-    }
-}
-// projection tile `ptile`, M-tile `pmt` from the mirrors of h2 (32-k blocks 0..31) and of the context (the last 4 of xa's 12)
-__device__ __forceinline__ void pdh_proj(const PersistDecodeArgs& A, const u32x4 (&wp)[5], int t, int ptile, int pmt, float* lds) {
-    const int par = t & 1, MT = A.MT;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const auto rh = gt_rsrc(A.h2h[par], 0x7FFFF000u);
-    const auto rx = gt_rsrc(A.xah[par], 0x7FFFF000u);
-    constexpr int NKB = PD_KBPJ / 2;
-    u32x4 x[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int kb = (wave + i * PD_NW < NKB) ? wave + i * PD_NW : wave;          // wave-uniform
-        const auto tv = kb < PD_KBH / 2 ? __builtin_amdgcn_raw_buffer_load_b128(rh, lane * 16, (kb * MT + pmt) * 1024, 16)
-                                        : __builtin_amdgcn_raw_buffer_load_b128(rx, lane * 16, ((kb - PD_KBH / 2 + PD_KBP / 2) * MT + pmt) * 1024, 16);
-        __builtin_memcpy(&x[i], &tv, 16);
-    }
-    PD_PIN();
-    f32x4 a0 = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        if (wave + i * PD_NW < NKB) {
-            bf16x8 av, bw;
-            __builtin_memcpy(&av, &x[i], 16);
-            __builtin_memcpy(&bw, &wp[i], 16);
-            a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bw, a0, 0, 0, 0);
-        }
-    }
-    const f32x4 zero = {0, 0, 0, 0};
-    pd_spill(lds, threadIdx.x >> 6, a0, zero);
-    const float v = pd_reduce<8>(lds, A.bp[ptile * 16 + (threadIdx.x & 15)]);
-    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
-    const int grow = pmt * 16 + row, gcol = ptile * 16 + col;
-    if (row < 16 && grow < A.B) {
-        if (gcol >= A.z_col0) {
-            if (gcol < A.z_col0 + PD_P) {
-                uint2 g;
-                g.x = __builtin_bit_cast(uint32_t, v); g.y = (uint32_t)t + 1u;
-                pd_st2_sc1(A.z0g + (size_t)grow * PD_P + (gcol - A.z_col0), g);
-            }
-        } else if (gcol < A.n_split) {
-            A.pre[(size_t)grow * A.ld_pre + (size_t)t * A.n_split + gcol] = v;
-        } else if (gcol < A.n_out) {
-            A.stop[(size_t)grow * A.steps + t] = v;
-        }
-    }
-}
-
-// CHAIN: utterance blockIdx.x's chain, then cell 1 and cell 2 of its tile with W1x / W2x streamed (its recurrent halves come from a
-// helper); else a plain workgroup: its tile's four halves with resident weights and, HELP, the recurrent halves of chain tile `help`
-template <bool CHAIN, bool HELP>
-__device__ __forceinline__ void pdh_run_tile(const PersistDecodeArgs& A, float* smem, PdShared* sh, int help) {
-    float* lds = smem;
-    const int tile = blockIdx.x, b = blockIdx.x, tid = threadIdx.x, col = tid & 15;
-    constexpr int role = CHAIN ? 0 : 2;
-    PdWh W;
-    PdHS S;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) { S.c1[e] = 0.f; S.c2[e] = 0.f; S.p1[e] = A.b1h[tile * 16 + col]; S.p2[e] = A.b2h[tile * 16 + col]; }
-    PdChainLds L{};
-    PdChainRegs R{};
-    if (CHAIN) {
-        L = pd_carve(smem, A.tvp, 8, PDH_SLAB);
-        R.Tv = A.tok_len ? max(1, min(A.Tv, (int)A.tok_len[b])) : A.Tv;
-        R.drop = A.drop_rate > 0.f;
-        R.hashed = R.drop && A.keep_hash != 0;
-        R.noisy = A.sigmoid_noise > 0.f;
-        R.seed = R.hashed ? *A.seed_ptr : 0ull;
-        R.bias1 = tid < PD_P ? A.b1[tid] : 0.f;
-        R.biasq = tid < PD_A ? A.bq[tid] : 0.f;
-        R.sbias = A.score_bias[0];
-        const float4* src = reinterpret_cast<const float4*>(A.pm + (size_t)b * A.Tv * PD_A);
-        for (int e = tid; e < A.tvp * PD_A / 4; e += PD_NT) {
-            const int row = e / (PD_A / 4), c4 = e % (PD_A / 4);
-            *reinterpret_cast<float4*>(L.tile + row * PD_LDV + 4 * c4) = row < R.Tv ? src[(size_t)row * (PD_A / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (tid < PD_A) L.vs[tid] = A.av[tid];
-        if (tid < A.tvp) L.pv[tid] = tid == 0 ? 1.f : 0.f;
-    } else {
-        // (a helper keeps the input halves resident and streams the recurrent tiles -- its own, then the chain tile's, through the same
-        // registers: four resident tiles and a streamed fifth did not fit beside the 64-row fragments)
-        pdh_load_tile<2>(A.w1x, tile, PD_KBP / 2 + PD_KBC / 2, W.x1); pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2);
-        if (!HELP) { pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1); pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, W.h2); }
-    }
-    __syncthreads();
-    for (int t = 0; t < A.steps; ++t) {
-        PD_STAMP(role, 0);
-        PD_ZT(zt);
-        if (CHAIN) {
-            float unused = 0.f;
-            int bs = b;
-            asm volatile("" : "+s"(bs));
-            pd_chain<false, true>(A, L, R, t, bs, sh, unused, zt);
-            if (sh->abort) return;
-            PD_STAMP(role, 1);
-            PD_PIN();
-            pdh_load_tile<2>(A.w1x, tile, PD_KBP / 2 + PD_KBC / 2, W.x1);
-            pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2);        // (arrives during cell 1)
-        }
-        pdh_cell1<CHAIN>(A, W.x1, t, tile, lds, S, sh, role, zt);
-        if (sh->abort) return;
-        if (HELP && t + 1 < A.steps) pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1);      // (streamed: arrives during the wait for h1)
-        u32x4 x[PDH_MT][4];
-        pdh_cell2(A, W.x2, x, t, tile, lds, S, sh, role, zt);
-        if (sh->abort) return;
-        if (CHAIN) continue;                          // (a chain workgroup goes straight on to the next chain)
-        if (t + 1 == A.steps) break;
-        pdh_rec1(A, x, W.h1, tile, lds, false, S.p1);
-        PD_STAMP(role, 6);
-        if (HELP) {         // (the chain workgroup needs it at its NEXT cell 1, a whole chain away: own half first)
-            pdh_load_tile<4>(A.w1h, help, PD_KBH / 2, W.h1);
-            float v[2];
-            pdh_rec1(A, x, W.h1, help, lds, false, v);
-            pdh_publish(v, A.hpart + (size_t)help * PDH_HP, A.ctl + zt + PD_F_H + help * 32, (uint32_t)t + 1u);
-        }
-        pdh_rec2<true, HELP>(A, W.h2, t, tile, lds, S, sh, role, zt, help);
-        if (sh->abort) return;
-    }
-}
-
-// a projection (tile, M-tile) + the LSTM tile, everything resident; the projection comes FIRST behind the h2 arrivals (the chains wait
-// for it), the recurrent halves of layer 1 (h1 re-read) and of layer 2 behind it
-__device__ __forceinline__ void pdh_run_proj(const PersistDecodeArgs& A, float* lds, PdShared* sh) {
-    const int tile = blockIdx.x, col = threadIdx.x & 15;
-    const int pi = tile - A.n_chain, ptile = pi % A.pj_tiles, pmt = pi / A.pj_tiles;
-    PdWh W;
-    pdh_load_tile<2>(A.w1x, tile, PD_KBP / 2 + PD_KBC / 2, W.x1); pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2);
-    pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1); pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, W.h2);
-    u32x4 wpj[5];
-    pdh_load_tile<5>(A.wp, ptile, PD_KBPJ / 2, wpj);
-    PdHS S;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) { S.c1[e] = 0.f; S.c2[e] = 0.f; S.p1[e] = A.b1h[tile * 16 + col]; S.p2[e] = A.b2h[tile * 16 + col]; }
-    for (int t = 0; t < A.steps; ++t) {
-        PD_STAMP(1, 0);
-        PD_ZT(zt);
-        pdh_cell1<false>(A, W.x1, t, tile, lds, S, sh, 1, zt);
-        if (sh->abort) return;
-        {
-            u32x4 x[PDH_MT][4];
-            pdh_cell2(A, W.x2, x, t, tile, lds, S, sh, 1, zt);
-            if (sh->abort) return;
-        }
-        pd_wait_count(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
-        if (sh->abort) return;
-        pdh_proj(A, wpj, t, ptile, pmt, lds);
-        PD_STAMP(1, 6);
-        if (t + 1 == A.steps) break;
-        {   // (the h1 fragments again: kept in registers across the projection they cost this role spills; nobody waits for this half)
-            u32x4 x[PDH_MT][4];
-            pdh_xload<4>(A.h1h[t & 1], A.MT, PD_KBH / 2, 0, x);
-            PD_PIN();
-            pdh_rec1(A, x, W.h1, tile, lds, false, S.p1);
-        }
-        pdh_rec2<false, false>(A, W.h2, t, tile, lds, S, sh, 1, zt, -1);
-    }
-}
-
-__global__ __launch_bounds__(PD_NT) void gt_persist_decode_h_kernel(PersistDecodeArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ PdShared sh;
-    if (threadIdx.x == 0) sh.abort = 0;
-    __syncthreads();
-    const int tile = blockIdx.x;
-    const int n_pj = A.pj_tiles * A.MT;
-#ifndef PD_HONLY
-#define PD_HONLY -1         // (register-budget diagnosis: compile one role alone)
-#endif
-    if (tile < A.n_chain) { if (PD_HONLY < 0 || PD_HONLY == 0) pdh_run_tile<true, false>(A, smem, &sh, -1); }
-    else if (tile < A.n_chain + n_pj) { if (PD_HONLY < 0 || PD_HONLY == 1) pdh_run_proj(A, smem, &sh); }
-    else if (tile - (A.n_chain + n_pj) < A.n_chain) {       // (helps chain tile `index among the plain`)
-        if (PD_HONLY < 0 || PD_HONLY == 2) pdh_run_tile<false, true>(A, smem, &sh, tile - (A.n_chain + n_pj));
-    } else if (PD_HONLY < 0 || PD_HONLY == 3) pdh_run_tile<false, false>(A, smem, &sh, -1);
-}
+#include "persist_groups.h"      // the group kernels (33..128 rows in fp32)
+#include "persist_bf16.h"        // the bf16 kernel (mixed precision, <= 64 rows)
 
 // z0 granules of step 0: the first frame is zero (Taco2.py:162-165), so prenet 0's pre-activations are its bias; + the control words
 __global__ void gt_persist_decode_init_kernel(uint2* z0g, const float* b0, uint32_t* ctl, int B) {
