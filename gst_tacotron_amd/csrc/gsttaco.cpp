@@ -108,7 +108,9 @@ struct gsttaco_ctx {
     // EXPERIMENTS round 3, item 2b)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool gst_fork = false;
+    int gst_fork = 0;            // GSTTACO_GST_FORK: 1 = forked inside the captured encoder graph, 2 = its own graph on the side stream beside the
+                                 // encoder's convolution graph, joined in front of the BiLSTM graph
+    int enc_part = 0;            // (mode 2) which part of the encoder segment is being enqueued: 0 all, 1 up to the hoisted GEMM, 2 the BiLSTM
     bool masks_lazy = false;     // the last decode did not write the keep-mask tensor (hashed decisions): gsttaco_debug_randomness regenerates it
 
     // weights on device
@@ -667,7 +669,8 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
     a.x = x; a.w = L.xw; a.shift = L.xb;
     a.out = L.z; a.ldo = 8 * H;
     a.B = B; a.T = Tn; a.Cin = L.C; a.N = 8 * H; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
-    HIPCHECK(c, launch_conv(c, a, s));
+    if (c->enc_part != 2) HIPCHECK(c, launch_conv(c, a, s));
+    if (c->enc_part == 1) return 0;
     // One persistent launch for the whole sequence, one (direction, 16 utterances) group per XCD (skinny_gemm.hip
     // gt_bilstm_persist_kernel; same arithmetic, bitwise the same outputs); GSTTACO_BILSTM_PERSIST=0 keeps the launch per step.
     if (L.ph && c->bilstm_persist && gt_bilstm_persist_supported(H, std::min(B, 64), c->n_cu)) {
@@ -713,6 +716,9 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
     const float* x = c->d_emb;
     const int32_t* tok = c->w_tokens;
     int cur = 0;
+    if (c->enc_part == 2) {         // (the convolutions ran in their own graph: their output is where n_enc_conv layers leave it)
+        if (g.n_enc_conv > 0) { x = c->w_act[(g.n_enc_conv - 1) & 1]; tok = nullptr; }
+    } else
     if (gst_Tref1 > 0) {
         HIPCHECK(c, hipEventRecord(c->ev_fork, s));
         HIPCHECK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
@@ -720,7 +726,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
         if (rg) return rg;
         HIPCHECK(c, hipEventRecord(c->ev_join, c->side_stream));
     }
-    for (int i = 0; i < g.n_enc_conv; ++i) {
+    for (int i = 0; i < g.n_enc_conv && c->enc_part != 2; ++i) {
         const ConvLayer& L = c->enc_conv[i];
         ConvGemmArgs a{};
         a.x = x; a.tokens = tok; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
@@ -734,8 +740,8 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
     }
     // BiLSTM: one launch per time step, both directions in grid.z; h is written straight into enc_out.
     const int H = g.enc_rnn, C = c->conv_c, EO = c->enc_out;
-    if (gst_Tref1 > 0) HIPCHECK(c, hipStreamWaitEvent(s, c->ev_join, 0));
-    HIPCHECK(c, gt_launch_zero(c->w_cenc, (size_t)2 * B * H, s));
+    if (gst_Tref1 > 0 && c->enc_part == 0) HIPCHECK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    if (c->enc_part != 2) HIPCHECK(c, gt_launch_zero(c->w_cenc, (size_t)2 * B * H, s));
     if (lean_bilstm_usable(c, c->enc_lean, B)) return enqueue_lean_bilstm(c, s, c->enc_lean, x, B, Tv, c->w_cenc, c->w_enc, tlen);
     for (int t = 0; t < Tv; ++t) {
         SkinnyArgs a[2];
@@ -1684,7 +1690,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->persist_decode = env_int("GSTTACO_PERSIST_DECODE", 1) != 0;
     c->persist_rows = env_int("GSTTACO_PERSIST_ROWS", 128);
     c->persist_split16 = env_int("GSTTACO_PERSIST_SPLIT16", 0) != 0 ? 1 : 0;
-    c->gst_fork = env_int("GSTTACO_GST_FORK", 0) != 0;
+    c->gst_fork = std::min(2, std::max(0, env_int("GSTTACO_GST_FORK", 0)));
     c->wino = env_int("GSTTACO_WINO", 4);
     if (c->wino != 0 && c->wino != 2) c->wino = 4;      // {0, 2, 4}; any other non-zero value (the old boolean's 1 included) means the default
     c->stamps = env_int("GSTTACO_STAMPS", 0) == 1;
@@ -2302,9 +2308,29 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
     // (run_cached, g_persist_event); the segment between them -- GST, value projection, the decode loop, the postnet: 95 % of the
     // call -- overlaps freely with other contexts' work.  The encoder / vocoder segments share their cached graphs with
     // gsttaco_encode / gsttaco_vocoder.
-    const bool fork = gst && c->gst_fork;
-    GraphKey kenc{fork ? 6 : 1, B, Tv, fork ? Tref1 : 0, 0, 0, 0, 0, masked};
+    const bool fork = gst && c->gst_fork != 0;
+    const bool lean_enc = lean_bilstm_usable(c, c->enc_lean, B);
+    if (fork && c->gst_fork == 2 && lean_enc) {
+        // three graphs: GST on the side stream beside the convolutions' graph, joined in front of the BiLSTM's
+        HIPCHECK(c, hipEventRecord(c->ev_fork, s));
+        HIPCHECK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        GraphKey kg{8, B, 0, Tref1, 0, 0, 0, 0, 0};
+        if ((rc = run_cached(c, c->side_stream, kg, [&](hipStream_t st) { return enqueue_gst(c, st, B, Tref1); }))) return rc;
+        HIPCHECK(c, hipEventRecord(c->ev_join, c->side_stream));
+        GraphKey k6{6, B, Tv, 0, 0, 0, 0, 0, masked}, k7{7, B, Tv, 0, 0, 0, 0, 0, masked};
+        c->enc_part = 1;
+        rc = run_cached(c, s, k6, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv, masked); });
+        c->enc_part = 0;
+        if (rc) return rc;
+        HIPCHECK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        c->enc_part = 2;
+        rc = run_cached(c, s, k7, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv, masked); }, true);
+        c->enc_part = 0;
+        if (rc) return rc;
+    } else {
+    GraphKey kenc{fork ? 9 : 1, B, Tv, fork ? Tref1 : 0, 0, 0, 0, 0, masked};
     if ((rc = run_cached(c, s, kenc, [&](hipStream_t st) { return enqueue_encoder(c, st, B, Tv, masked, fork ? Tref1 : 0); }, true))) return rc;
+    }
     GraphKey key{0, B, Tv, Tref1, steps, mask != nullptr, noise != nullptr, c->prof_every, masked};
     rc = run_cached(c, s, key, [&](hipStream_t st) {
         int r2 = 0;
