@@ -273,3 +273,21 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE is 4" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_prices_the_decode_step_at_the_surveys_bytes():
+    """bench.py's roofline arithmetic is SURVEY.md section 8(d)'s, not its own: 57.88 MB of decoder weights + 3.2 MB of activation rows =
+    61.1 MB per decode step at configs[1], 5.9 ms ideal for the whole Inference_Step; bf16 weights halve the weight share; what a
+    persistent launch MUST move is far less (weights once per launch)."""
+    import bench
+    from gst_tacotron_amd import synthetic
+    from gst_tacotron_amd.hparams import Dims, load_hp, load_token_dict
+    hp = load_hp(synthetic.config_hp("cfg2"))
+    d = Dims(hp, vocab=len(load_token_dict(hp)))
+    total, w, a = bench.survey_step_bytes(d, 32, 128, False)
+    assert w == 4 * (86528 + 32896 + 129 + 5771264 + 8392704 + 1152 * 161 + 161)      # SURVEY 8(d)'s own sum (prenet, query, v + bias, LSTM 1, LSTM 2, projection)
+    assert abs(w / 1e6 - 57.88) < 0.01 and abs(a / 1e6 - 3.2) < 0.05 and abs(total / 1e6 - 61.1) < 0.05
+    assert bench.survey_step_bytes(d, 32, 128, True)[1] * 2 == w
+    assert abs(bench.ideal_ms(d, 32, 128, 256, False, 500) - 5.9) < 0.05
+    comp = bench.persistent_compulsory_bytes(d, 32, 128, False, 500)
+    assert w < comp < 500 * total / 50
