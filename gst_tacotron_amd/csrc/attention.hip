@@ -22,11 +22,11 @@
 size_t gt_attn_lds_bytes(int Tv, int A, int loc_f, int loc_k, int* rows_lds) {
     int rows = Tv < 256 ? Tv : 256;
     // keep the tile (+ the LSA location features of its rows) <= 96 KiB
-    while ((size_t)rows * (A + 1 + loc_f) * 4 > 96 * 1024 && rows > 16) rows /= 2;
+    while ((size_t)rows * (A + 1 + loc_f + 1) * 4 > 96 * 1024 && rows > 16) rows /= 2;
     if (rows_lds) *rows_lds = rows;
     // tile + q + v + score/p + prev + align + partials (+ LSA: location features, dense and conv weights, biases)
     size_t fl = (size_t)rows * (A + 1) + 2 * (size_t)A + 3 * (size_t)Tv + 4 * 256 + 64;
-    if (loc_f > 0) fl += (size_t)rows * loc_f + (size_t)loc_f * A + (size_t)loc_k * loc_f + loc_f + 2 * (size_t)A;
+    if (loc_f > 0) fl += (size_t)rows * (loc_f + 1) + (size_t)loc_f * A + (size_t)loc_k * loc_f + loc_f + 2 * (size_t)A;
     return fl * sizeof(float);
 }
 
@@ -55,8 +55,12 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
     // LSA extension scratch
     const bool lsa = P.type == GSTTACO_ATT_LSA;
     const int LF = lsa ? P.loc_f : 0, LK = lsa ? P.loc_k : 0;
-    float* lfeat = partial + 4 * 256;                // [rows_lds][LF]  conv(state)+bias
-    float* ldw = lfeat + (size_t)rows_lds * LF;      // [LF][A]
+    // (row stride LF + 1: in the score pass a lane is a memory ROW and reads its row's features one after the other -- at a stride of
+    // 32 floats every lane of a wave hit the same LDS bank, a 64-way conflict on each of 64 x 32 reads per thread: the step-wise LSA
+    // extension ran at 325 us per decode step, 165 ms per Inference_Step at the headline shape, tools/lsa_time.py)
+    const int LFS = LF + 1;
+    float* lfeat = partial + 4 * 256;                // [rows_lds][LF + 1]  conv(state)+bias
+    float* ldw = lfeat + (size_t)rows_lds * LFS;     // [LF][A]
     float* lcw = ldw + (size_t)LF * A;               // [LK][LF]
     float* lcb = lcw + (size_t)LK * LF;              // [LF]
     float* labias = lcb + LF;                        // [A]  location-dense bias + additive bias
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
                     const int ts = t + j - lpad;
                     if (ts >= 0 && ts < Tv) acc += pv[ts] * lcw[j * LF + f];
                 }
-                lfeat[i] = acc;
+                lfeat[rr * LFS + f] = acc;
             }
             __syncthreads();
         }
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
             const int abeg = part * arange, aend = min(A, abeg + arange);
             if (lsa) {
                 // score = sum_a tanh(q + key + Dense(loc) + bias)   (Layers.py:364, 407; no v vector, scale 1)
-                const float* lf = lfeat + (size_t)row * LF;
+                const float* lf = lfeat + (size_t)row * LFS;
                 for (int a = abeg; a < aend; ++a) {
                     float loc = labias[a];
                     for (int f = 0; f < LF; ++f) loc += lf[f] * ldw[f * A + a];
