@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgsttaco.so")
-SOURCES = ["gsttaco.cpp", "skinny_gemm.hip", "gemm_conv.hip", "attention.hip", "dec_front.hip", "persist_decode.hip", "gst.hip", "audio.hip"]
+SOURCES = ["gsttaco.cpp", "skinny_gemm.hip", "gemm_conv.hip", "attention.hip", "dec_front.hip", "dec_front_lsa.hip", "persist_decode.hip", "gst.hip", "audio.hip"]
 FLAGS_STAMP = os.path.join(LIBDIR, ".flags")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

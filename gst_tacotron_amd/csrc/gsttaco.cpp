@@ -175,6 +175,7 @@ struct gsttaco_ctx {
     float* w_z0 = nullptr;
     float *val_enc_w = nullptr, *val_bias = nullptr, *att_v = nullptr, *att_sb = nullptr;
     float *loc_cw = nullptr, *loc_cb = nullptr, *loc_dw = nullptr, *loc_db = nullptr, *att_bias = nullptr;   // LSA extension
+    float* loc_pack = nullptr;          // the same as the fused front end's LDS image (kernels.h LsaPack)
     float* w_lsa_state = nullptr;
 
     // CBHG vocoder
@@ -861,11 +862,17 @@ FrontSched plan_front_jobs(const gsttaco_ctx* c, int jobs, int chunks, int n_wor
     return best;
 }
 
+// the fused front end (dec_front.hip; dec_front_lsa.hip for the LSA extension, whose operands share its LDS) takes this shape
+static bool front_fits(const gsttaco_ctx* c, int Tv) {
+    const gsttaco_config& g = c->cfg;
+    const bool lsa = g.att_type == GSTTACO_ATT_LSA;
+    return gt_dec_front_supported(g.mel_dim, c->P0, c->P1, c->att, Tv, lsa ? g.loc_filters : 0, lsa ? g.loc_kernel : 0);
+}
+
 // throughput mode at the reference's dropout rate on a fused front end: nobody reads the keep-mask tensor (see enqueue_decode)
 bool masks_unused(const gsttaco_ctx* c, int Tv, bool injected) {
     const gsttaco_config& g = c->cfg;
-    return !injected && g.prenet_rate == 0.5f && c->keep_hash && c->fused_front && g.att_type != GSTTACO_ATT_LSA &&
-           gt_dec_front_supported(g.mel_dim, c->P0, c->P1, c->att, Tv);
+    return !injected && g.prenet_rate == 0.5f && c->keep_hash && c->fused_front && front_fits(c, Tv);
 }
 
 int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool has_mask, bool has_noise, bool masked) {
@@ -902,7 +909,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     // each CU's load pipe, which is what bounds those launches (EXPERIMENTS round 4), and no conversion per consumer.  Only when
     // every producer and consumer of the step is one that knows about mirrors (lean paths below).
     const bool mirror = B > 32 && c->w_xa_h != nullptr && c->fused_front && c->split_rec && c->lean && c->keep_x_weights &&
-                        g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv) &&
+                        front_fits(c, Tv) &&
                         gt_lstm_x_supported(c->lstm_x[0].nkb) && gt_lstm_x_supported(c->lstm_x[1].nkb) && c->lstm_h[0].nkb == 64 && c->lstm_h[1].nkb == 64;
     if (mirror && !persist_base) {
         HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(c->w_h1_h[1]), (size_t)MT * 16 * H1 / 2, s));
@@ -912,7 +919,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     // both LSTM cells in one launch (skinny_gemm.hip gt_lstm12_kernel): fp32 lean shapes, batch <= 32, one live context
     // (batch <= 32: fp32; above: the multi-chunk form, fp32 or bf16)
     const bool fuse_base = c->fuse12_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->lstm_x[0].bf16 == c->lstm_x[1].bf16 &&
-                           g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv);
+                           front_fits(c, Tv);
     const bool fuse12_small = fuse_base && !c->lstm_x[0].bf16 && gt_lstm12_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->fuse12_slots[0]);
     const bool fuse12_mc = fuse_base && gt_lstm12_mc_supported(c->lstm_x[0].nkb, c->lstm_x[1].nkb, H1, H2, B, c->fuse12_slots[c->lstm_x[0].bf16 ? 2 : 1]);
     const bool fuse12 = fuse12_small || fuse12_mc;
@@ -999,8 +1006,9 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         const float* mask0 = has_mask ? c->w_masks + (size_t)t * mask_step : nullptr;
         const float* mask1 = has_mask ? c->w_masks + (size_t)t * mask_step + (size_t)B * P0 : nullptr;
         const bool prof = c->prof_every > 0 && (t % c->prof_every) == 0;
-        // the fused front end implements BMA/SMA; the LSA extension runs on the four-kernel path
-        const bool fused = c->fused_front && g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(mel, P0, P1, att, Tv);
+        // (the four-kernel path below: GSTTACO_FUSED_FRONT=0, or a shape the fused kernel's LDS does not hold)
+        const bool lsa = g.att_type == GSTTACO_ATT_LSA;
+        const bool fused = c->fused_front && front_fits(c, Tv);
         const bool split = fused && c->split_rec;
         const bool use_z0 = split && c->proj_z.wp != nullptr;        // prenet-0 rides in the projection launch
         float* xa_t = c->w_xa;
@@ -1020,12 +1028,18 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             f.drop_rate = g.prenet_rate; f.drop_scale = drop_scale; f.seed_ptr = c->w_seed; f.rng_step = (uint32_t)t;
             f.pm = c->w_pm; f.v = c->att_v; f.score_bias = c->att_sb;
             f.prev = t == 0 ? nullptr : c->w_align + (size_t)(t - 1) * Tv; f.ldprev = (int64_t)steps * Tv;
-            f.noise = has_noise ? c->w_noise + (size_t)t * B * Tv : nullptr; f.ldnoise = Tv;
+            if (lsa) {      // the state buffer (zeroed above) in place of the previous alignment; softmax, no noise
+                f.prev = c->w_lsa_state; f.ldprev = Tv;
+                f.loc_pack = c->loc_pack;
+                f.lsa_state = c->w_lsa_state; f.loc_k = g.loc_kernel; f.loc_f = g.loc_filters;
+                f.lsa_cumulate = g.lsa_cumulate; f.lsa_smoothing = g.lsa_smoothing;
+            }
+            f.noise = (has_noise && !lsa) ? c->w_noise + (size_t)t * B * Tv : nullptr; f.ldnoise = Tv;
             f.align = c->w_align + (size_t)t * Tv; f.ldalign = (int64_t)steps * Tv;
             f.xa = xa_t; f.MT = MT;
             f.xah = mirror ? c->w_xa_h : nullptr;
             f.B = B; f.Tv = Tv; f.mel = mel; f.P0 = P0; f.P1 = P1; f.A = att; f.type = g.att_type;
-            f.sigmoid_noise = g.sigmoid_noise;
+            f.sigmoid_noise = lsa ? 0.f : g.sigmoid_noise;
             f.tok_len = tlen;
             f.dbg = (c->stamps && t == steps / 2) ? c->w_dbg : nullptr;
             f.lean_front = c->front_mode >= 2 ? 1 : 0;
@@ -1871,6 +1885,21 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
             if ((rc = up(&c->loc_dw, "decoder.attention.location_dense.kernel"))) return rc;
             if ((rc = up(&c->loc_db, "decoder.attention.location_dense.bias"))) return rc;
             if ((rc = up(&c->att_bias, "decoder.attention.bias"))) return rc;
+            {   // the same five tensors as the fused front end's LDS image (kernels.h LsaPack)
+                const HostTensor &cw = T(c, "decoder.attention.location_conv.kernel"), &cb = T(c, "decoder.attention.location_conv.bias");
+                const HostTensor &dw = T(c, "decoder.attention.location_dense.kernel"), &db = T(c, "decoder.attention.location_dense.bias");
+                const HostTensor& ab = T(c, "decoder.attention.bias");
+                const int LF = g.loc_filters, LK = g.loc_kernel, A = c->att;
+                const LsaPack lp = gt_lsa_pack(A, LF, LK);
+                std::vector<float> img((size_t)lp.total, 0.f);
+                for (int f = 0; f < LF; ++f)
+                    for (int a = 0; a < A; ++a) img[(size_t)f * lp.LDWS + a] = dw.data[(size_t)f * A + a];
+                for (int j = 0; j < LK; ++j)
+                    for (int f = 0; f < LF; ++f) img[lp.off_cw + (size_t)j * lp.LCS + f] = cw.data[(size_t)j * LF + f];
+                for (int f = 0; f < LF; ++f) img[lp.off_cb + f] = cb.data[f];
+                for (int a = 0; a < A; ++a) img[lp.off_ab + a] = db.data[a] + ab.data[a];
+                if ((rc = upload(c, &c->loc_pack, img.data(), img.size()))) return rc;
+            }
         } else {
             const HostTensor& av = T(c, "decoder.attention.v");
             if ((rc = upload(c, &c->att_v, av.data.data(), av.data.size()))) return rc;
@@ -2490,8 +2519,7 @@ int gsttaco_debug_raise_handoff_error(gsttaco_ctx* c, uint32_t bits) {
 
 int gsttaco_decode_plan(const gsttaco_ctx* c, int Tv, int32_t plan[3]) {
     if (!c || !plan || Tv < 1) return GSTTACO_E_INVALID;
-    const gsttaco_config& g = c->cfg;
-    const bool fused = c->fused_front && g.att_type != GSTTACO_ATT_LSA && gt_dec_front_supported(g.mel_dim, c->P0, c->P1, c->att, Tv);
+    const bool fused = c->fused_front && front_fits(c, Tv);
     const bool split = fused && c->split_rec;
     plan[0] = fused ? 1 : 0;
     plan[1] = (split && c->proj_z.wp != nullptr) ? 1 : 0;

@@ -289,8 +289,33 @@ struct DecFrontArgs {
                                     // the prenet-1 / query weights that the (hashed) keep decisions zero are not requested
     int lean_front;                 // 1: the lean utterance path (front_lean.h) where its preconditions hold; 0: the general kernel
     uint16_t* xah;                  // bf16 mirror of xa (gt_blk_off_h), written beside it, or NULL
+    // type == GSTTACO_ATT_LSA (dec_front_lsa.hip; the four-kernel path's AttnStepArgs fields of the same names): `prev` is then the
+    // state buffer itself (ldprev = Tv), read at the start of the step and rewritten at its end
+    const float* loc_pack;                  // the LSA weights as the kernel's LDS image (LsaPack below), 16-byte aligned
+    float* lsa_state;                       // [B, Tv] cumulative (or previous) alignment
+    int loc_k, loc_f, lsa_cumulate, lsa_smoothing;
 };
-bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv);
+// LDS image of the LSA weights on the fused front end, built once on the host (gsttaco.cpp) and copied per step with 16-byte loads:
+//   dw  [LFp][LDWS]  location Dense kernel [F, A], rows zero-padded to the MFMA k granule (4)
+//   cw  [LKp][LCS]   location Conv1D kernel [K, 1, F] as [K][F], taps padded to 4, filters to the MFMA n granule (16)
+//   cb  [LFc]        Conv1D bias (zero beyond F)
+//   ab  [A]          Dense bias + the additive attention bias
+// Row strides LDWS = A + 8 and LCS = LFc + 8 floats put the four k rows of a B fragment on different banks; LFS = LFc + 4 is the row
+// stride of the location-feature tile the kernel writes behind the memory tile.
+struct LsaPack { int LFc, LFp, LKp, LFS, LDWS, LCS, off_cw, off_cb, off_ab, total; };
+inline __host__ __device__ LsaPack gt_lsa_pack(int A, int LF, int LK) {
+    LsaPack p;
+    p.LFc = (LF + 15) & ~15; p.LFp = (LF + 3) & ~3; p.LKp = (LK + 3) & ~3;
+    p.LFS = p.LFc + 4; p.LDWS = A + 8; p.LCS = p.LFc + 8;
+    p.off_cw = p.LFp * p.LDWS; p.off_cb = p.off_cw + p.LKp * p.LCS; p.off_ab = p.off_cb + p.LFc;
+    p.total = (p.off_ab + A + 3) & ~3;
+    return p;
+}
+// (loc_f > 0: the LSA form, whose operands share the LDS with the processed-memory tile)
+bool gt_dec_front_supported(int mel, int P0, int P1, int A, int Tv, int loc_f = 0, int loc_k = 0);
+// dec_front_lsa.hip: the LSA instantiations of the general kernel (shape = 0..4 for A = 16, 32, 64, 128, 256)
+hipError_t gt_front_lsa_init();
+void gt_front_lsa_launch(int shape, bool z0, int lean, bool exact, dim3 grid, size_t lds, hipStream_t s, const DecFrontArgs& a);
 hipError_t gt_dec_front_init();
 hipError_t gt_launch_dec_front(const DecFrontArgs& a, hipStream_t stream);
 

@@ -636,11 +636,14 @@ def test_masked_mode_ragged_batch(att):
     assert np.abs(un[0].cpu().numpy() - ref_un[0]).max() <= TOL
 
 
-def test_lsa_extension_full_dims_and_masked():
+@pytest.mark.parametrize("front", ["2", "0"], ids=["fused-front", "four-kernel"])
+def test_lsa_extension_full_dims_and_masked(monkeypatch, front):
     """Step-wise location-sensitive attention (extension A13) at full dimensions, k=31 / 32 filters, with and without
-    the smoothing normalisation, unmasked and masked."""
+    the smoothing normalisation, unmasked and masked (140 positions: two passes of the fused kernel's 128-row tile) -- on the fused
+    front end (dec_front_lsa.hip: the two location GEMMs on the fp32 matrix pipe) and on the four-kernel path (attention.hip)."""
     import torch
     from oracle import oracle_np
+    monkeypatch.setenv("GSTTACO_FUSED_FRONT", front)
     B, Tv, Tref, steps = 3, 140, 64, 5
     lens = np.array([140, 60, 101], np.int32)
     for smoothing in (False, True):
@@ -651,6 +654,7 @@ def test_lsa_extension_full_dims_and_masked():
         w = weights.synthetic_weights(hp, seed=0)
         tokens, _ = synthetic.make_tokens(np.random.default_rng(42), B, Tv, lengths=lens)
         m = _model(hp, w, B, Tv, Tref + 1)
+        assert m.decode_plan(Tv)[0] is (front != "0")
         for tl in (None, lens):
             out = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps, masked=tl is not None)
             torch.cuda.synchronize()
@@ -658,6 +662,38 @@ def test_lsa_extension_full_dims_and_masked():
             assert np.abs(out[0].cpu().numpy() - ref[0]).max() <= TOL
             assert np.abs(out[3].cpu().numpy() - ref[3]).max() <= TOL
             assert np.allclose(out[3].cpu().numpy().sum(-1), 1.0, atol=1e-5)
+        del m
+
+
+@pytest.mark.parametrize("filters,kernel,att,fits", [(32, 31, 128, True), (20, 9, 128, True), (8, 7, 64, True), (40, 15, 128, True),
+                                                     (64, 63, 128, False)])
+def test_lsa_fused_front_matches_the_four_kernel_path(monkeypatch, filters, kernel, att, fits):
+    """The LSA extension's two implementations against each other in throughput mode (device-generated dropout), at filter counts and
+    kernel sizes that are not multiples of the matrix instruction's granules, 24 utterances x 96 positions x 40 steps: the location
+    sums are the same fmaf chains in the same order, so the outputs differ only through the order of the score's sum over channels.
+    (Last case: operands that do not fit the fused kernel's LDS beside the memory tile stay on the four-kernel path.)"""
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    B, Tv, Tref, steps = 24, 96, 64, 40
+    hp = synthetic.config_hp("cfg2")
+    hp["Tacotron2"]["Decoder"]["Attention"] = {"Type": "LSA", "Size": att, "Conv": {"Filters": filters, "Kernel_Size": kernel}}
+    w = weights.synthetic_weights(hp, seed=3)
+    rng = np.random.default_rng(5)
+    tokens, _ = synthetic.make_tokens(rng, B, Tv)
+    mels, ml = synthetic.make_ref_mels(rng, B, Tref)
+    outs = []
+    for front in ("2", "0"):
+        monkeypatch.setenv("GSTTACO_FUSED_FRONT", front)
+        m = _model(hp, w, B, Tv, Tref + 1)
+        assert m.decode_plan(Tv)[0] is (front != "0" and fits)
+        o = m.Inference_Step(tokens, None, None, mels, ml, seed=11, steps=steps)
+        torch.cuda.synchronize()
+        outs.append([x.cpu().numpy() for x in (o[0], o[3])])
+        del m
+    assert np.isfinite(outs[0][0]).all()
+    assert np.abs(outs[0][0] - outs[1][0]).max() <= TOL
+    assert np.abs(outs[0][1] - outs[1][1]).max() <= TOL
+    assert np.allclose(outs[0][1].sum(-1), 1.0, atol=1e-5)
 
 
 def test_config3_batch128_variable_length_with_padding_masks():

@@ -32,4 +32,6 @@ def run(att, env):
 
 run("SMA", {})
 run("SMA", {"GSTTACO_PERSIST_DECODE": "0"})
+run("SMA", {"GSTTACO_PERSIST_DECODE": "0", "GSTTACO_FUSED_FRONT": "1"})      # the general utterance kernel (LSA's), not the lean one
 run("LSA", {})
+run("LSA", {"GSTTACO_FUSED_FRONT": "0"})                                    # the four-kernel path (attention.hip)

@@ -9,6 +9,8 @@ hp, inputs = synthetic.config_inputs("cfg2", batch=32)
 if os.environ.get("STAMPS_NO_RANDOM") == "1":
     hp["Tacotron2"]["Decoder"]["Prenet"]["Dropout_Rate"] = 0.0
     hp["Tacotron2"]["Decoder"]["Attention"]["Sigmoid_Noise"] = 0.0
+if os.environ.get("STAMPS_LSA") == "1":      # the LSA extension on the fused front end (dec_front_lsa.hip); launch path
+    hp["Tacotron2"]["Decoder"]["Attention"] = {"Type": "LSA", "Size": 128, "Conv": {"Filters": 32, "Kernel_Size": 31}, "Smoothing": False}
 w = weights.synthetic_weights(hp, seed=0)
 m = GST_Tacotron(hyper_parameters=hp, max_batch=32, max_tokens=128, max_ref_frames=257)
 m.Restore(weights=w)
