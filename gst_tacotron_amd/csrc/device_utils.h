@@ -12,6 +12,47 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #define GT_WAVE 64
 
+// Cross-lane moves inside a 16-lane row on the VALU (DPP) -- no LDS round trip.  hipcc compiles every __shfl_* to ds_bpermute_b32
+// (~100 cycles through the LDS crossbar, waited for with lgkmcnt): six dependent ones summed a hand-off's counter shards inside every
+// poll, two rounds of three sat in every LSTM epilogue and three in the attention score (EXPERIMENTS round 5, item 8).
+template <int CTRL>
+__device__ __forceinline__ float gt_dpp(float x) {      // lanes without a source keep their own value
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t gt_dpp_u32(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xF, 0xF, false);
+}
+// (integer form of gt_row_sum below: arrival-counter shards)
+template <int L>
+__device__ __forceinline__ uint32_t gt_row_sum_u32(uint32_t s) {
+    static_assert(L == 4 || L == 8 || L == 16, "a power of two inside a 16-lane row");
+    s += gt_dpp_u32<0xB1>(s);
+    s += gt_dpp_u32<0x4E>(s);
+    if (L >= 8) s += gt_dpp_u32<0x141>(s);
+    if (L >= 16) s += gt_dpp_u32<0x140>(s);
+    return s;
+}
+// the value of lane i + N of the same 16-lane row (row_shl:N) = __shfl_down(x, N, 16)
+template <int N>
+__device__ __forceinline__ float gt_row_down(float x) {
+    static_assert(N >= 1 && N <= 15, "row_shl:1..15");
+    return gt_dpp<0x100 + N>(x);
+}
+// sum over aligned groups of L = 4 / 8 / 16 lanes, every lane of the group holding the total: the same additions as the xor butterfly
+// `for (d = 1; d < L; d <<= 1) s += __shfl_xor(s, d)` -- after the two quad steps the four lanes of a quad hold identical bits, so
+// adding the mirror lane's value (row_half_mirror, row_mirror) is adding the xor partner's
+template <int L>
+__device__ __forceinline__ float gt_row_sum(float s) {
+    static_assert(L == 4 || L == 8 || L == 16, "a power of two inside a 16-lane row");
+    s += gt_dpp<0xB1>(s);                   // quad_perm [1,0,3,2]
+    s += gt_dpp<0x4E>(s);                   // quad_perm [2,3,0,1]
+    if (L >= 8) s += gt_dpp<0x141>(s);      // row_half_mirror
+    if (L >= 16) s += gt_dpp<0x140>(s);     // row_mirror
+    return s;
+}
+
 // tanh(x) = 1 - 2/(exp(2x)+1) on one v_exp_f32 + one v_rcp_f32 (5 VALU ops).  No clamp is needed: exp(2x) -> inf
 // gives rcp -> 0 -> +1, exp(2x) -> 0 gives -1, never NaN.  abs error <= ~2e-7 (covered by the parity tests).
 __device__ __forceinline__ float gt_tanh(float x) {

@@ -482,8 +482,7 @@ __global__ __launch_bounds__(FT) void gt_dec_front_kernel(DecFrontArgs P) {
             s2 = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, gt_tanh2(f32x2{q4.z, q4.w} + f32x2{m4.z, m4.w}), s2);
         }
         float s = s2.x + s2.y;
-#pragma unroll
-        for (int d = 1; d < L; d <<= 1) s += __shfl_xor(s, d, 64);
+        s = gt_row_sum<L>(s);
         if (li == 0 && t < Tv) sc[t] = s + sbias;
     }
     __syncthreads();

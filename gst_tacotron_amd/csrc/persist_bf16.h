@@ -92,14 +92,14 @@ __device__ __forceinline__ void pdh_gates_store(const float (&z)[2], float (&c)[
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int row = (threadIdx.x >> 4) + 32 * e;
-        const float zf = __shfl_down(z[e], 4, 16), zg = __shfl_down(z[e], 8, 16), zo = __shfl_down(z[e], 12, 16);
+        const float zf = gt_row_down<4>(z[e]), zg = gt_row_down<8>(z[e]), zo = gt_row_down<12>(z[e]);
         float hv = 0.f;
         if (col < 4 && row < M) {
             const float gi = gt_sigmoid(z[e]), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
             c[e] = __builtin_fmaf(gf, c[e], gi * gg);
             hv = go * gt_tanh(c[e]);
         }
-        const float h1v = __shfl_down(hv, 1, 16), h2v = __shfl_down(hv, 2, 16), h3v = __shfl_down(hv, 3, 16);
+        const float h1v = gt_row_down<1>(hv), h2v = gt_row_down<2>(hv), h3v = gt_row_down<3>(hv);
         if (col == 0 && row < M) {
             uint2 pk;
             pk.x = (uint32_t)gt_bf16_bits(hv) | ((uint32_t)gt_bf16_bits(h1v) << 16);
@@ -152,7 +152,7 @@ __device__ __forceinline__ void pdh_publish(const float (&v)[2], float* dst, uin
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const float v1 = __shfl_down(v[e], 1, 16), v2 = __shfl_down(v[e], 2, 16), v3 = __shfl_down(v[e], 3, 16);
+        const float v1 = gt_row_down<1>(v[e]), v2 = gt_row_down<2>(v[e]), v3 = gt_row_down<3>(v[e]);
         if ((col & 3) == 0) pd_st4_sc1(dst + (row + 32 * e) * 16 + col, make_float4(v[e], v1, v2, v3));
     }
     pd_drain();
@@ -216,7 +216,7 @@ __device__ __forceinline__ void pdh_cell1(const PersistDecodeArgs& A, const u32x
 __device__ __forceinline__ void pdh_cell2(const PersistDecodeArgs& A, const u32x4 (&wx2)[4], u32x4 (&x)[PDH_MT][4], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role,
                                           int zt) {
     const int par = t & 1, MT = A.MT;
-    pd_wait_count(A, A.ctl + zt + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+    pd_wait_count(A, A.ctl + zt + PD_CNT3, PD_WANT(A, t), sh);
     if (sh->abort) return;
     PD_STAMP(role, 4);
     pdh_xload<4>(A.h1h[par], MT, PD_KBH / 2, 0, x);
@@ -241,7 +241,7 @@ template <bool WAIT, bool HELP>
 __device__ __forceinline__ void pdh_rec2(const PersistDecodeArgs& A, u32x4 (&wh2)[4], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role, int zt, int help) {
     if (HELP) pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, wh2, zt);  // (a helper streams its own W2h: arrives during the wait)
     if (WAIT) {
-        pd_wait_count(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        pd_wait_count(A, A.ctl + zt + PD_CNT4, PD_WANT(A, t), sh);
         if (sh->abort) return;
     }
     PD_STAMP(role, 7);
@@ -419,7 +419,7 @@ __device__ __forceinline__ void pdh_run_proj(const PersistDecodeArgs& A, float* 
             pdh_cell2(A, W.x2, x, t, tile, lds, S, sh, 1, zt);
             if (sh->abort) return;
         }
-        pd_wait_count(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        pd_wait_count(A, A.ctl + zt + PD_CNT4, PD_WANT(A, t), sh);
         if (sh->abort) return;
         pdh_proj(A, wpj, t, ptile, pmt, lds);
         PD_STAMP(1, 6);

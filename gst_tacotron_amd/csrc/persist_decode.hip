@@ -50,6 +50,13 @@ constexpr uint32_t PD_SPIN_MAX = 1u << 20;
                        // A/B, profiles/r04_ab.txt) -- a poll is one read in flight and a round trip long: the pause only delays the next one
 #endif
 #define PD_SLEEP() do { if (PD_SLEEP_N > 0) __builtin_amdgcn_s_sleep(PD_SLEEP_N); } while (0)
+// `zt`: a per-step opaque zero added into every per-thread global address of a body.  Without it the step loop's invariant
+// addresses -- flags, counter shards and state rows of every group and parity: dozens of 64-bit pairs at four groups -- are hoisted
+// out of the loop and live across the chain, which needs the whole register file: they spill, and a scratch reload waits for vmcnt(0).
+#define PD_ZT(zt) int zt = 0; asm volatile("" : "+v"(zt))
+#ifndef PD_X2_EARLY
+#define PD_X2_EARLY 1   // the chain role requests W2x inside cell 1 (0: behind the h1 wait, with the h1 fragments: same-box A/B 19.8 against 19.4 us per step)
+#endif
 #ifndef PD_NSH
 #define PD_NSH 64      // shards of an arrival counter (a 128-byte line each): arrivals per line = 256 / PD_NSH, lines per poll = PD_NSH.  The 256
                        // arrival atomics of an all-to-all are served one after the other per line: same-box A/B (profiles/r04_ab.txt) 8 shards
@@ -113,27 +120,30 @@ __device__ __forceinline__ void pd_wait_flags(const PersistDecodeArgs& A, const 
     }
     __syncthreads();
 }
-// sum of the PD_NSH counter shards >= want
-__device__ __forceinline__ void pd_wait_count(const PersistDecodeArgs& A, const uint32_t* c, uint32_t want, PdShared* sh) {
+// every one of the PD_NSH counter shards >= want.  Every workgroup arrives once per step on shard blockIdx.x % PD_NSH, so each shard's
+// expected value is known (PD_WANT) and no cross-lane sum is needed: the poll is a load, a compare and a ballot (the sum was six
+// dependent ds_bpermute round trips, ~0.2 us, inside every poll of every hand-off).
+static_assert(PD_NWG % PD_NSH == 0 && PD_NSH % 64 == 0, "whole workgroups per shard, whole shards per lane");
+#define PD_WANT(A, t) ((uint32_t)((t) + 1) * (uint32_t)(PD_NWG / PD_NSH) + (uint32_t)(A).expect_extra)
+// `flag` (or NULL): one more word that must show `fwant` -- it rides in the same poll (a poll of its own in front of this one was a
+// serial round trip of ~0.8 us even when long satisfied)
+__device__ __forceinline__ void pd_wait_count(const PersistDecodeArgs& A, const uint32_t* c, uint32_t want, PdShared* sh, const uint32_t* flag = nullptr,
+                                              uint32_t fwant = 0u) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         uint32_t spins = 0;
         for (;;) {
-            uint32_t v;
-            if constexpr (PD_NSH <= 64) {
-                v = lane < PD_NSH ? pd_ld_sc1(c + lane * 32) : 0u;
-            } else {                                    // several shards per lane: all requested, then one wait
-                uint32_t u[PD_NSH > 64 ? PD_NSH / 64 : 1];
+            uint32_t u[PD_NSH / 64];                    // (several shards per lane: all requested, then one wait)
+            uint32_t uf = fwant;
 #pragma unroll
-                for (int k = 0; k < PD_NSH / 64; ++k) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(u[k]) : "v"(c + (lane + 64 * k) * 32) : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                v = 0u;
+            for (int k = 0; k < PD_NSH / 64; ++k) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(u[k]) : "v"(c + (lane + 64 * k) * 32) : "memory");
+            if (flag) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(uf) : "v"(flag) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(uf));
+            bool ok = uf >= fwant;
 #pragma unroll
-                for (int k = 0; k < PD_NSH / 64; ++k) { asm volatile("" : "+v"(u[k])); v += u[k]; }
-            }
-#pragma unroll
-            for (int d = 1; d < (PD_NSH < 64 ? PD_NSH : 64); d <<= 1) v += __shfl_xor(v, d, 64);
-            if (__builtin_amdgcn_readfirstlane(v) >= want) break;
+            for (int k = 0; k < PD_NSH / 64; ++k) { asm volatile("" : "+v"(u[k])); ok = ok && u[k] >= want; }
+            if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(ok))) == 64) break;
             if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
             if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
             PD_SLEEP();
@@ -212,7 +222,9 @@ __device__ __forceinline__ void pd_spill(float* lds, int slab, const f32x4& a0, 
     for (int v = 0; v < 4; ++v) { part[slab][q * 4 + v][r] = a0[v]; part[slab][16 + q * 4 + v][r] = a1[v]; }
 }
 // element (row = tid >> 4, col = tid & 15) = base + sum over the first `nslab` slabs (ascending)
-template <int NSLAB>
+// TRAIL = false: without the closing barrier -- for the caller whose next spill into the slabs lies behind another workgroup barrier
+// anyway (an arrival, a wait): the epilogue's stores then leave one barrier earlier
+template <int NSLAB, bool TRAIL = true>
 __device__ __forceinline__ float pd_reduce(float* lds, float base) {
     __syncthreads();
     const float (*part)[32][17] = reinterpret_cast<const float (*)[32][17]>(lds);
@@ -220,7 +232,7 @@ __device__ __forceinline__ float pd_reduce(float* lds, float base) {
     float z = base;
 #pragma unroll
     for (int w = 0; w < NSLAB; ++w) z += part[w][row][col];
-    __syncthreads();            // the slabs are re-used by the next reduction
+    if (TRAIL) __syncthreads();            // the slabs are re-used by the next reduction
     return z;
 }
 // the same, and one lane signals an arrival counter behind the first barrier (`cnt` != NULL): the DEFERRED arrival of an earlier
@@ -286,7 +298,7 @@ __device__ __forceinline__ float pd_g_rec_tile(const float4 (&x0)[8], const floa
 // h of the tile's 4 units leaves as ONE 16-byte write-through store per row (rows >= M are never stored)
 __device__ __forceinline__ void pd_gates_store(float z, float& c, float* hdst, int tile, int M, int MT, int row0 = 0, int rows = 32) {
     const int lrow = threadIdx.x >> 4, row = row0 + lrow, col = threadIdx.x & 15;       // (a group: rows row0 .. row0 + rows - 1)
-    const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+    const float zf = gt_row_down<4>(z), zg = gt_row_down<8>(z), zo = gt_row_down<12>(z);
     float hv = 0.f;
     if (lrow >= rows) return;               // (16-row groups: the slab's upper half is unused; whole 16-lane segments leave together)
     if (col < 4 && row < M) {
@@ -294,7 +306,7 @@ __device__ __forceinline__ void pd_gates_store(float z, float& c, float* hdst, i
         c = __builtin_fmaf(gf, c, gi * gg);
         hv = go * gt_tanh(c);
     }
-    const float h1v = __shfl_down(hv, 1, 16), h2v = __shfl_down(hv, 2, 16), h3v = __shfl_down(hv, 3, 16);
+    const float h1v = gt_row_down<1>(hv), h2v = gt_row_down<2>(hv), h3v = gt_row_down<3>(hv);
     if (col == 0 && row < M) pd_st4_sc1(hdst + gt_blk_off(row, tile * 4, MT), make_float4(hv, h1v, h2v, h3v));
 }
 template <int KPW>
@@ -308,7 +320,7 @@ __device__ __forceinline__ void pd_load_tile(const float* wp, int tile, float4 (
 // a [32][16] tile of recurrent-half sums (thread = element) for another workgroup: 16-byte write-through stores, drained, one flag
 __device__ __forceinline__ void pd_publish_part(float v, float* dst, uint32_t* flag, uint32_t tag) {
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
-    const float v1 = __shfl_down(v, 1, 16), v2 = __shfl_down(v, 2, 16), v3 = __shfl_down(v, 3, 16);
+    const float v1 = gt_row_down<1>(v), v2 = gt_row_down<2>(v), v3 = gt_row_down<3>(v);
     if ((col & 3) == 0) pd_st4_sc1(dst + row * 16 + col, make_float4(v, v1, v2, v3));
     pd_drain();
     __syncthreads();
@@ -321,7 +333,7 @@ struct PdW { float4 x1[3], h1[8], x2[8], h2[8]; };
 // LSTM cell 1: z = [p | ctx] . W1x + part1 (= h1_{t-1} . W1h + b1).  split: the prenet part is multiplied as soon as the chains
 // have published it, the context part when it arrives (same accumulator, same k-block order as gt_lstm_x_kernel<8, 3>).
 __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int t, int tile, float* lds, float& c1v, float p1v, PdShared* sh, bool split,
-                                        bool stream_x1 = false, int role = 2) {
+                                        bool stream_x1 = false, int role = 2, bool stream_x2 = false) {
     const int par = t & 1, MT = A.MT;
     if (stream_x1) pd_load_tile<3>(A.w1x, tile, W.x1);          // (the chain role: arrives while the other chains finish)
     const float* xa = A.xa[par];
@@ -346,11 +358,16 @@ __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int
         if (sh->abort) return;
         PD_STAMP(role, 3);
         pd_xload<0, 3, 3>(xa, MT, x0, x1);
+        // (the chain role: cell 2's input half, behind this cell's fragments -- requested at cell 2's entry, the poll of the h1 arrivals
+        // queued behind its 64 KB, loads returning in order, and this role, which everybody waits for, saw the hand-off ~1 us late)
+        // (the tile index through an opaque register: its load addresses are otherwise hoisted out of the step loop, live across the
+        // chain, and the allocator -- at 250 of 256 registers there -- spills three dozen other loop invariants)
+        if (stream_x2) { int tz = tile; asm volatile("" : "+s"(tz)); pd_load_tile<8>(A.w2x, tz, W.x2); }
         PD_PIN();
         pd_mma<3, 0, 1, 3>(x0, x1, W.x1, a0, a1);
     }
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
-    const float z = pd_reduce<8>(lds, p1v);
+    const float z = pd_reduce<8, false>(lds, p1v);          // (pd_arrive's barrier below closes the slabs)
     pd_gates_store(z, c1v, A.h1[par], tile, A.B, MT);
     PD_STAMP(role, 4);
     pd_arrive(A.ctl + PD_CNT3);
@@ -358,24 +375,37 @@ __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int
 
 // LSTM cell 2: z = h1_t . W2x + part2; then, from the same fragments, recurrent halves of cell 1 for the NEXT step: a chain
 // workgroup's (help_tile >= 0, published for it) and this workgroup's own (with_rec1)
-__device__ __forceinline__ void pd_cell2(const PersistDecodeArgs& A, PdW& W, int t, int tile, float* lds, float& c2v, float p2v, float& p1_next, bool with_rec1,
-                                        PdShared* sh, int help_tile, bool stream_h1, bool stream_x2, int role = 2) {
+// helped_p2 >= 0 (chain role, t > 0): this tile's layer-2 recurrent half comes from its helper -- the helper's flag rides in the poll
+// of the h1 arrivals, the sums (slot helped_p2 of hpart) are requested with the h1 fragments
+__device__ __forceinline__ void pd_cell2(const PersistDecodeArgs& A, PdW& W, int t, int tile, float* lds, float& c2v, float& p2v, float& p1_next, bool with_rec1,
+                                        PdShared* sh, int help_tile, bool stream_h1, bool stream_x2, int role = 2, int helped_p2 = -1) {
     const int par = t & 1, MT = A.MT;
-    if (stream_x2) pd_load_tile<8>(A.w2x, tile, W.x2);          // (the chain role: these registers belong to the chain's operands until here)
+    // (the chain role streams W2x: these registers belong to the chain's operands until cell 1.  Requested BEHIND the wait, with the
+    // h1 fragments: in front of it the poll queued behind its 64 KB -- loads return in order -- and this role, which everybody waits
+    // for, saw the hand-off ~1 us after the others)
     float4 wu[8];
     if (help_tile >= 0) pd_load_tile<8>(A.w1h, help_tile, wu);  // (a chain workgroup's W1h tile, streamed: arrives during the wait)
     if (stream_h1) pd_load_tile<8>(A.w1h, tile, W.h1);          // (layer-2 helpers keep W2h resident and stream their own W1h)
-    pd_wait_count(A, A.ctl + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+    pd_wait_count(A, A.ctl + PD_CNT3, PD_WANT(A, t), sh, helped_p2 >= 0 ? A.ctl + PD_F_H + helped_p2 * 32 : nullptr, (uint32_t)t);
     if (sh->abort) return;
     PD_STAMP(role, 5);
     float4 x0[8], x1[8];
+    if (stream_x2) pd_load_tile<8>(A.w2x, tile, W.x2);
     pd_xload<0, 8, 8>(A.h1[par], MT, x0, x1);
+    if (helped_p2 >= 0) {
+        const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
+        const float4 d2 = gt_bload4_sc1(rh, (uint32_t)((helped_p2 * 512 + ((int)threadIdx.x & ~3)) * 4), 0u);
+        const int e = threadIdx.x & 3;
+        p2v = e == 0 ? d2.x : e == 1 ? d2.y : e == 2 ? d2.z : d2.w;
+    }
     PD_PIN();
+    PD_STAMP(role, 21);         // (fragments requested)
     f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
     pd_mma<8, 0, 1, 8>(x0, x1, W.x2, a0, a1);
     PD_STAMP(role, 6);
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
-    const float z = pd_reduce<8>(lds, p2v);
+    const float z = pd_reduce<8, false>(lds, p2v);
+    PD_STAMP(role, 22);         // (reduced)
     pd_gates_store(z, c2v, A.h2[par], tile, A.B, MT);
     PD_STAMP(role, 7);
     pd_arrive(A.ctl + PD_CNT4);
@@ -417,7 +447,7 @@ template <bool GK = false>     // GK: called by a group kernel (its stamp slots)
 __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4 (&wp)[9], int t, int ptile, int pmt, float* lds, PdShared* sh, int g = 0) {
     const int par = t & 1, MT = A.MT;
     if (!GK) {          // (a group kernel has waited for every group's arrivals at once)
-        pd_wait_count(A, A.ctl + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        pd_wait_count(A, A.ctl + PD_CNT4, PD_WANT(A, t), sh);
         if (sh->abort) return;
     }
     if (!GK) PD_STAMP(1, 9);
@@ -443,7 +473,8 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
     }
     if (!GK) PD_STAMP(1, 10);
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
-    const float v = pd_reduce<8>(lds, A.bp[ptile * 16 + (threadIdx.x & 15)]);
+    // (one-group kernel: the projection role's next spill -- the next step's cell 1 -- lies behind that phase's flag wait and its barrier)
+    const float v = GK ? pd_reduce<8>(lds, A.bp[ptile * 16 + (threadIdx.x & 15)]) : pd_reduce<8, false>(lds, A.bp[ptile * 16 + (threadIdx.x & 15)]);
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
     const int grow = pmt * 16 + row, gcol = ptile * 16 + col;
     if (row < 16 && grow < A.B) {
@@ -552,6 +583,16 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
     PD_STAMP(0, 13);
     // ---- S1: this utterance's row of prenet-0 pre-activations (granules tagged with the step they are for)
     if (tid < PD_P) {
+        // (the keep decisions and everything else that does not need the granule: in FRONT of the poll, while the projection of the
+        // previous step is still on its way -- behind it they were ~100 instructions on the step's critical path)
+        if (R.hashed) {
+            k0 = gt_drop_keep(R.seed, (uint32_t)t, 0u, (uint32_t)b, (uint32_t)tid, (uint32_t)PD_P, A.drop_rate);
+            k1 = gt_drop_keep(R.seed, (uint32_t)t, 1u, (uint32_t)b, (uint32_t)tid, (uint32_t)PD_P, A.drop_rate);
+        }
+        if (R.drop) { k0 *= A.drop_scale; k1 *= A.drop_scale; }
+        else { k0 = 1.f; k1 = 1.f; }
+        L.ks1[tid] = k1;
+        asm volatile("" : "+v"(k0) : : "memory");
         uint2 g = pd_ld2_sc1(A.z0g + (size_t)b * PD_P + tid);
         uint32_t spins = 0;
         while (__builtin_amdgcn_readfirstlane(__popcll(__ballot(g.y == (uint32_t)t))) != 64) {
@@ -559,14 +600,7 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
             if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
             g = pd_ld2_sc1(A.z0g + (size_t)b * PD_P + tid);
         }
-        if (R.hashed) {
-            k0 = gt_drop_keep(R.seed, (uint32_t)t, 0u, (uint32_t)b, (uint32_t)tid, (uint32_t)PD_P, A.drop_rate);
-            k1 = gt_drop_keep(R.seed, (uint32_t)t, 1u, (uint32_t)b, (uint32_t)tid, (uint32_t)PD_P, A.drop_rate);
-        }
-        if (R.drop) { k0 *= A.drop_scale; k1 *= A.drop_scale; }
-        else { k0 = 1.f; k1 = 1.f; }
         L.y0[tid] = fmaxf(__builtin_bit_cast(float, g.x), 0.f) * k0;
-        L.ks1[tid] = k1;
     }
     if (tid < Tv) L.nz[tid] = A.sigmoid_noise * nzv;
     __syncthreads();
@@ -637,8 +671,9 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
             pd_st2_sc1(reinterpret_cast<uint2*>(A.xah[par] + gt_blk_off_h(b, 4 * tid, MT)), pk);
         } else
         pd_st4_sc1(xa + gt_blk_off(b, 4 * tid, MT), *reinterpret_cast<const float4*>(L.y1 + 4 * tid));
-        pd_drain();
-        if (tid == 0) pd_st1_sc1(A.ctl + PD_F_P + b * PD_FS, (uint32_t)t + 1u);
+        // (drained and flagged BEHIND the query projection's barrier below: waiting for the write acknowledgement here held the other
+        // seven waves at that barrier for ~0.7 us of every step, and nobody is short of the prenet part -- the LSTM-1 workgroups that
+        // multiply it early wait for the context anyway)
     }
     if (HELPED && t > 0 && tid >= PD_NT - 64) {        // the last wave, meanwhile: this tile's layer-1 recurrent half from its helper must show step t
         const int l2 = tid & 63;
@@ -672,6 +707,10 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
         *reinterpret_cast<float4*>(L.partial + kpb * PD_A + 4 * cgq) = acc;
     }
     __syncthreads();
+    if (tid < 64) {                                 // S2p's flag: the prenet stores were acknowledged under the projection above
+        pd_drain();
+        if (tid == 0) pd_st1_sc1(A.ctl + PD_F_P + b * PD_FS, (uint32_t)t + 1u);
+    }
     if (sh->abort) return;
     if (HELPED && t > 0) {                          // (behind the barrier the flag poll joined: the helper's sums, consumed by cell 1)
         const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
@@ -698,8 +737,7 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
             s2 = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, gt_tanh2(f32x2{q4.z, q4.w} + f32x2{m4.z, m4.w}), s2);
         }
         float s = s2.x + s2.y;
-#pragma unroll
-        for (int d = 1; d < 8; d <<= 1) s += __shfl_xor(s, d, 64);
+        s = gt_row_sum<8>(s);
         if (li == 0 && row < Tv) L.sc[row] = s + R.sbias;
     }
     __syncthreads();
@@ -846,8 +884,9 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
             for (int k = 0; k < 8; ++k) if (t == ts[k]) A.dbg[24 + k] = __builtin_amdgcn_s_memrealtime();
         }
         if (live) {
-            if (A.tvp == 128) pd_chain<true, false, true>(A, L, R, t, b, sh, p1v);
-            else pd_chain<true>(A, L, R, t, b, sh, p1v);
+            PD_ZT(zt);
+            if (A.tvp == 128) pd_chain<true, false, true>(A, L, R, t, b, sh, p1v, zt);
+            else pd_chain<true>(A, L, R, t, b, sh, p1v, zt);
             if (sh->abort) return;
         } else if (t > 0) {                                     // no chain to hide it behind: fetch the layer-1 half directly
             pd_wait_flags(A, A.ctl + PD_F_H + tile * 32, 1, (uint32_t)t, sh);
@@ -857,18 +896,11 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
             const int e = tid & 3;
             p1v = e == 0 ? d1.x : e == 1 ? d1.y : e == 2 ? d1.z : d1.w;
         }
-        pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, false, true, 0);
+        pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, false, true, 0, PD_X2_EARLY != 0);
         if (sh->abort) return;
-        if (t > 0) {        // the layer-2 half from its helper, in the shadow of the wait for h1 (one flag, then one 16-byte load per thread)
-            pd_wait_flags(A, A.ctl + PD_F_H + (32 + tile) * 32, 1, (uint32_t)t, sh);
-            if (sh->abort) return;
-            const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
-            const float4 d2 = gt_bload4_sc1(rh, (uint32_t)(((32 + tile) * 512 + (tid & ~3)) * 4), 0u);
-            const int e = tid & 3;
-            p2v = e == 0 ? d2.x : e == 1 ? d2.y : e == 2 ? d2.z : d2.w;
-        }
         float unused = 0.f;
-        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, true, 0);
+        // (the layer-2 half from its helper: flag and sums ride with the h1 arrivals' poll and fragments)
+        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, PD_X2_EARLY == 0, 0, t > 0 ? 32 + tile : -1);
         if (sh->abort) return;
     }
 }
@@ -923,7 +955,7 @@ __device__ __forceinline__ void pd_run_plain(const PersistDecodeArgs& A, float* 
         if (sh->abort) return;
         if (t + 1 == A.steps) break;
         if (HELP == 1) pd_load_tile<8>(A.w2h, tile, W.h2);      // (streamed: arrives during the wait)
-        pd_wait_count(A, A.ctl + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        pd_wait_count(A, A.ctl + PD_CNT4, PD_WANT(A, t), sh);
         if (sh->abort) return;
         PD_STAMP(2, 13);
         p2v = pd_rec2(A, t, A.h2[par], W.h2, tile, HELP == 2 ? help_tile : -1, lds);        // for step t + 1

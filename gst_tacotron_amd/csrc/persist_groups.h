@@ -19,10 +19,6 @@
 // the rest are plain.  Control: per-group arrival counters, per-utterance flags as before.
 template <int GM> struct PdG { float c1[GM], c2[GM], p1[GM], p2[GM]; };
 
-// `zt`: a per-step opaque zero added into every per-thread global address of these bodies.  Without it the step loop's invariant
-// addresses -- flags, counter shards and state rows of every group and parity: dozens of 64-bit pairs at four groups -- are hoisted
-// out of the loop and live across the chain, which needs the whole register file: they spill, and a scratch reload waits for vmcnt(0).
-#define PD_ZT(zt) int zt = 0; asm volatile("" : "+v"(zt))
 
 // ---- one wait for ALL groups: the context flags of every utterance (two per lane: B <= 128) ...
 __device__ __forceinline__ void pd_wait_flags_all(const PersistDecodeArgs& A, const uint32_t* f, uint32_t want, PdShared* sh) {
@@ -58,18 +54,10 @@ __device__ __forceinline__ void pd_wait_count_all(const PersistDecodeArgs& A, co
                 if (g < A.G) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(u[g]) : "v"(c + g * (PD_NSH * 32) + lane * 32) : "memory");
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bool ok = true;
+            bool ok = true;                 // (per shard: pd_wait_count)
 #pragma unroll
-            for (int g = 0; g < GM; ++g) {
-                if (g < A.G) {
-                    asm volatile("" : "+v"(u[g]));
-                    uint32_t v = u[g];
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
-                    ok = ok && __builtin_amdgcn_readfirstlane(v) >= want;
-                }
-            }
-            if (ok) break;
+            for (int g = 0; g < GM; ++g) { asm volatile("" : "+v"(u[g])); ok = ok && u[g] >= want; }
+            if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(ok))) == 64) break;
             if (++spins > PD_SPIN_MAX) { if (lane == 0) pd_give_up(A, sh, true); break; }
             if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(pd_ld_sc1(A.err)) != 0u) { if (lane == 0) pd_give_up(A, sh, false); break; }
         }
@@ -173,7 +161,7 @@ __device__ __forceinline__ void pd_g_cell2_all(const PersistDecodeArgs& A, const
                                                C2 c2, P2 p2, P1 p1, PdShared* sh, int role, int zt) {
     constexpr int RG = 16 * MTG;
     const int par = t & 1, MT = A.MT;
-    pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT3, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+    pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT3, PD_WANT(A, t), sh);
     if (sh->abort) return;
     PD_STAMP(role, 4);
     float4 x0[8], x1[8];
@@ -213,7 +201,7 @@ template <int GM, int MTG, int LAYER, bool TWOPASS, bool WAIT, class P>
 __device__ __forceinline__ void pd_g_rec_all(const PersistDecodeArgs& A, const float4 (&wh)[8], int t, int tile, float* lds, P p, PdShared* sh, int role, int zt) {
     const int MT = A.MT;
     if (WAIT) {
-        pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, PD_WANT(A, t), sh);
         if (sh->abort) return;
     }
     PD_STAMP(role, 7);
@@ -360,7 +348,7 @@ __device__ __forceinline__ void pd_g_run_proj(const PersistDecodeArgs& A, float*
         // workgroups still have this step's recurrent halves to multiply); the projection tile (72 KB) arrives during that wait
         float4 wpj[9];
         pd_load_tile<9>(A.wp, ptile, wpj);
-        pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, (uint32_t)(t + 1) * PD_NWG + (uint32_t)A.expect_extra, sh);
+        pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, PD_WANT(A, t), sh);
         if (sh->abort) return;
 #pragma unroll
         for (int g = 0; g < GM; ++g)

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(NW * 64) void gt_lstm_x_kernel(LstmXArgs A) {
         float z = pin[i];
 #pragma unroll
         for (int w = 0; w < NW; ++w) z += part[w][row][col];
-        const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+        const float zf = gt_row_down<4>(z), zg = gt_row_down<8>(z), zo = gt_row_down<12>(z);
         const int grow = m0 + row, unit = tile * 4 + col;
         if (col < 4 && grow < A.M && unit < A.H) {
             if (A.row_len && A.t_index >= A.row_len[grow]) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(512) void gt_lstm12_kernel(Lstm12Args P) {
         float z = pin;
 #pragma unroll
         for (int w = 0; w < NW; ++w) z += part[w][row][col];
-        const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+        const float zf = gt_row_down<4>(z), zg = gt_row_down<8>(z), zo = gt_row_down<12>(z);
         if (col < 4 && row < A.M && unit < A.H) {
             const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
             const float c2 = __builtin_fmaf(gf, c_prev, gi * gg);
@@ -239,8 +239,7 @@ __global__ __launch_bounds__(512) void gt_lstm12_kernel(Lstm12Args P) {
         uint32_t spins = 0;
         for (;;) {
             uint32_t v = lane < GT_L12_NSH ? gt_ldu_sc1(P.arrive + lane * 32) : 0u;
-#pragma unroll
-            for (int d = 1; d < GT_L12_NSH; d <<= 1) v += __shfl_xor(v, d, 64);
+            v = gt_row_sum_u32<GT_L12_NSH>(v);
             if (__builtin_amdgcn_readfirstlane(v) >= P.expect) break;
             ++spins;
             if (spins > (1u << 18)) { if (lane == 0) { atomicOr(P.err, 1u); s_abort = 1; } break; }
@@ -284,7 +283,7 @@ __global__ __launch_bounds__(512) void gt_lstm12_kernel(Lstm12Args P) {
     float z = pin;
 #pragma unroll
     for (int w = 0; w < NW; ++w) z += part[w][row][col];
-    const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+    const float zf = gt_row_down<4>(z), zg = gt_row_down<8>(z), zo = gt_row_down<12>(z);
     if (col < 4 && row < A.M && unit < A.H) {
         const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);
         const float c2 = __builtin_fmaf(gf, c_prev, gi * gg);
@@ -331,7 +330,7 @@ __device__ __forceinline__ void gt_lstm_x_mc_body(const LstmXArgs& A, const int 
             float z = pin[j];
 #pragma unroll
             for (int w = 0; w < NW; ++w) z += part[j][w][row][col];
-            const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+            const float zf = gt_row_down<4>(z), zg = gt_row_down<8>(z), zo = gt_row_down<12>(z);
             const int unit = (tile0 + j) * 4 + col;
             if (j < ntile && col < 4 && grow < A.M && unit < A.H) {
                 float hv = 0.f;                                     // masked mode: a step that does not exist for this utterance writes 0
@@ -405,8 +404,7 @@ __global__ __launch_bounds__(512) void gt_lstm12_mc_kernel(Lstm12Args P) {
         uint32_t spins = 0;
         for (;;) {
             uint32_t v = lane < GT_L12_NSH ? gt_ldu_sc1(P.arrive + lane * 32) : 0u;
-#pragma unroll
-            for (int d = 1; d < GT_L12_NSH; d <<= 1) v += __shfl_xor(v, d, 64);
+            v = gt_row_sum_u32<GT_L12_NSH>(v);
             if (__builtin_amdgcn_readfirstlane(v) >= P.expect) break;
             ++spins;
             if (spins > (1u << 18)) { if (lane == 0) { atomicOr(P.err, 1u); s_abort = 1; } break; }
@@ -652,7 +650,7 @@ __global__ __launch_bounds__(NW * 64) void gt_bilstm_lean_kernel(BiLstmArgs A) {
         float z = pin[i];
 #pragma unroll
         for (int w = 0; w < NW; ++w) z += part[w][row][col];
-        const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+        const float zf = gt_row_down<4>(z), zg = gt_row_down<8>(z), zo = gt_row_down<12>(z);
         const int grow = m0 + row, unit = tile * 4 + col;
         if (col < 4 && grow < A.M && unit < A.H) {
             float hv = 0.f;
@@ -824,7 +822,7 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
         float z = cur;
 #pragma unroll
         for (int w = 0; w < NW; ++w) z += part[w][j_own][row][col];
-        const float zf = __shfl_down(z, 4, 16), zg = __shfl_down(z, 8, 16), zo = __shfl_down(z, 12, 16);
+        const float zf = gt_row_down<4>(z), zg = gt_row_down<8>(z), zo = gt_row_down<12>(z);
         float hv = 0.f;
         if (owner && real && tt < n_valid) {
             const float gi = gt_sigmoid(z), gf = gt_sigmoid(zf), gg = gt_tanh(zg), go = gt_sigmoid(zo);

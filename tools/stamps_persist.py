@@ -30,8 +30,9 @@ legend = {0: "step start", 1: "prenet flags seen", 2: "prenet part multiplied", 
           6: "cell 2 MFMAs done", 7: "h2 stored", 8: "h2 arrival counted", 9: "h2 arrivals seen (projection)", 10: "projection MFMAs done",
           11: "projection published", 12: "recurrent half 1 done", 13: "h2 arrivals seen (recurrent half)", 14: "recurrent half 2 done",
           16: "prenet published", 13 + 100: "", 17: "query done", 18: "scores done", 19: "alignment done", 20: "context published",
-          23: "prenet-1 sums stored", 15: "prenet-1 barrier passed"}
+          23: "prenet-1 sums stored", 15: "prenet-1 barrier passed", 21: "cell 2 fragments requested", 22: "cell 2 sums reduced"}
 chain_legend = dict(legend); chain_legend.update({13: "weights requested", 14: "z0 arrived, y0 in LDS"})
+legend.update({21: "cell 2 fragments requested", 22: "cell 2 sums reduced"})
 for r in range(3):
     t0 = buf[r * 32]
     st = sorted((buf[r * 32 + i], i) for i in range(1, 24 if r == 0 else 32) if buf[r * 32 + i])
