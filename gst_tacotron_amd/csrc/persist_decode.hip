@@ -579,6 +579,17 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
         k0 = m[(size_t)b * PD_P + tid];
         k1 = m[(size_t)A.B * PD_P + (size_t)b * PD_P + tid];
     }
+    // (which query rows this thread requests below -- launch-path thread = (4 output columns cgq, k-part kp of 8 rows), this thread
+    // plays kp = tid / 32 and 16 + tid / 32 -- derived here, in front of the poll, with the other keep decisions)
+    const int cgq = tid & 31, kpa = tid >> 5, kpb = 16 + (tid >> 5);
+    uint32_t qba = 0xFFu, qbb = 0xFFu;
+    if (R.hashed) {
+        qba = (gt_keep_word(R.seed, (uint32_t)t, 1u, (uint32_t)b, (uint32_t)kpa >> 2) >> ((8 * kpa) & 31)) & 0xFFu;
+        qbb = (gt_keep_word(R.seed, (uint32_t)t, 1u, (uint32_t)b, (uint32_t)kpb >> 2) >> ((8 * kpb) & 31)) & 0xFFu;
+    }
+    // (a row is requested when either half of the wave keeps it: the two halves are different k-parts)
+    const uint32_t ua = (uint32_t)__builtin_amdgcn_readlane((int)qba, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qba, 32);
+    const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)qbb, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qbb, 32);
     PD_PIN();
     PD_STAMP(0, 13);
     // ---- S1: this utterance's row of prenet-0 pre-activations (granules tagged with the step they are for)
@@ -607,14 +618,9 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
     if (sh->abort) return;
     PD_STAMP(0, 14);
     // ---- prenet layer 1 (Taco2.py:262-283): two launch-path threads' 16-row sums each.  The query weights (Steps.py:122) are
-    // requested into the first half's registers as soon as it is consumed: launch-path thread = (4 output columns cgq, k-part kp of
-    // 8 rows), this thread plays kp = tid / 32 and 16 + tid / 32; rows whose input (mask 1) is dropped are not requested.
-    const int cgq = tid & 31, kpa = tid >> 5, kpb = 16 + (tid >> 5);
-    uint32_t qba = 0xFFu, qbb = 0xFFu;
-    if (R.hashed) {
-        qba = (gt_keep_word(R.seed, (uint32_t)t, 1u, (uint32_t)b, (uint32_t)kpa >> 2) >> ((8 * kpa) & 31)) & 0xFFu;
-        qbb = (gt_keep_word(R.seed, (uint32_t)t, 1u, (uint32_t)b, (uint32_t)kpb >> 2) >> ((8 * kpb) & 31)) & 0xFFu;
-    }
+    // requested into the first half's registers: row i's request right behind the multiply-add that consumed register i, so the 16
+    // requests of a wave -- a CU's address pipe takes ~16 cycles for each -- go out under the first half's arithmetic instead of
+    // as a burst between the halves; rows whose input (mask 1) is dropped are not requested.
     float4 (&qa)[16] = ra;
     {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -624,23 +630,16 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             gt_fma4(acc, x[i], ra[i]);
-        }
-        PD_PIN4(acc);
-        *reinterpret_cast<float4*>(L.partial + wave * PD_P + 4 * lane) = acc;
-        {   // (a row is requested when either half of the wave keeps it: the two halves are different k-parts)
-            const uint32_t ua = (uint32_t)__builtin_amdgcn_readlane((int)qba, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qba, 32);
-            const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)qbb, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qbb, 32);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                qa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            PD_PIN4(acc);
+            qa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < 8) {
                 if ((ua >> i) & 1u) qa[i] = gt_bload4(rsWq, ((qba >> i) & 1u) ? (uint32_t)cgq * 16u : GT_OOB, (uint32_t)((8 * kpa + i) * PD_A * 4));
+            } else {
+                if ((ub >> (i - 8)) & 1u) qa[i] = gt_bload4(rsWq, ((qbb >> (i - 8)) & 1u) ? (uint32_t)cgq * 16u : GT_OOB, (uint32_t)((8 * kpb + i - 8) * PD_A * 4));
             }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                qa[8 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if ((ub >> i) & 1u) qa[8 + i] = gt_bload4(rsWq, ((qbb >> i) & 1u) ? (uint32_t)cgq * 16u : GT_OOB, (uint32_t)((8 * kpb + i) * PD_A * 4));
-            }
+            PD_PIN();
         }
+        *reinterpret_cast<float4*>(L.partial + wave * PD_P + 4 * lane) = acc;
         PD_PIN();
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -722,17 +721,24 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
     __syncthreads();
     PD_STAMP(0, 17);
     // ---- scores (Steps.py:126-152): 8 lanes per memory row, 4 x 16-byte pieces each; rows tid / 8, 64 + tid / 8, ... (tvp / 64 passes)
+    // (the thread's four pieces of the query and of v are the same for every row it plays: read once -- re-read per row they were
+    // two thirds of the pass's LDS bytes, 128 KB of 192, on a pass that is LDS- and transcendental-bound)
     const int npass = TV128 ? 2 : A.tvp >> 6;
+    float4 qr[4], wr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        qr[j] = *reinterpret_cast<const float4*>(L.qs + 4 * ((tid & 7) + 8 * j));
+        wr[j] = *reinterpret_cast<const float4*>(L.vs + 4 * ((tid & 7) + 8 * j));
+    }
 #pragma unroll 1
     for (int hh = 0; hh < npass; ++hh) {
         const int row = hh * 64 + (tid >> 3), li = tid & 7;
         f32x2 s2 = {0.f, 0.f};
-#pragma unroll 2
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int a0 = 4 * (li + 8 * j);
             const float4 m4 = *reinterpret_cast<const float4*>(L.tile + row * PD_LDV + a0);
-            const float4 q4 = *reinterpret_cast<const float4*>(L.qs + a0);
-            const float4 w4 = *reinterpret_cast<const float4*>(L.vs + a0);
+            const float4 q4 = qr[j], w4 = wr[j];
             s2 = __builtin_elementwise_fma(f32x2{w4.x, w4.y}, gt_tanh2(f32x2{q4.x, q4.y} + f32x2{m4.x, m4.y}), s2);
             s2 = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, gt_tanh2(f32x2{q4.z, q4.w} + f32x2{m4.z, m4.w}), s2);
         }
@@ -743,13 +749,18 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
     __syncthreads();
     PD_STAMP(0, 18);
     // ---- noise + sigmoid + alignment: SMA (Steps.py:215-229) or BMA (Steps.py:168-199)
+    // alp (TV128): the alignment once more in the context pass's order -- row group cp's sixteen rows cp, cp + 8, .. side by side -- so that
+    // pass reads them as four 16-byte words instead of sixteen broadcast reads (a third of its LDS instructions); rows >= Tv: zeros.
+    // In the slabs behind the context's row-group sums: free between the query's reduction and the cells' first spill.
+    float* alp = L.red + 8 * PD_A;
     if (A.att_type == GSTTACO_ATT_SMA) {
         if (tid < Tv) {
             const int tt = tid;
             float v = L.pv[tt] * gt_sigmoid(L.sc[tt] + (R.noisy ? L.nz[tt] : 0.f));
             if (tt > 0) v = __builtin_fmaf(L.pv[tt - 1], 1.f - gt_sigmoid(L.sc[tt - 1] + (R.noisy ? L.nz[tt - 1] : 0.f)), v);
             L.al[tt] = v;
-        }
+            if (TV128) alp[(tt & 7) * 16 + (tt >> 3)] = v;
+        } else if (TV128 && tid < 128) alp[(tid & 7) * 16 + (tid >> 3)] = 0.f;
     } else {
         if (tid < Tv) {
             float s = L.sc[tid];
@@ -774,8 +785,10 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
             for (int tt = t0; tt < t1; ++tt) {
                 base += L.pv[tt] / fminf(fmaxf(L.al[tt], 1e-10f), 1.f);
                 L.al[tt] = L.sc[tt] * L.al[tt] * base;
+                if (TV128) alp[(tt & 7) * 16 + (tt >> 3)] = L.al[tt];
             }
         }
+        if (TV128 && tid >= Tv && tid < 128) alp[(tid & 7) * 16 + (tid >> 3)] = 0.f;
     }
     __syncthreads();
     PD_STAMP(0, 19);
@@ -790,6 +803,22 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
         for (int hh = 0; hh < 2; ++hh) {
             const int cp = hh * 4 + (tid >> 7);
             float cacc = 0.f;
+            if (TV128) {
+                // the same multiply-adds in the same order (p0: rows cp, cp + 16, ..; p1: rows cp + 8, cp + 24, ..); rows >= Tv add an
+                // exact zero (their alignment and their memory row are zero) where the general form skips them
+                const float4* ap = reinterpret_cast<const float4*>(alp + cp * 16);
+                const float* tl = L.tile + cp * PD_LDV + ca;
+                float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const float4 a4 = ap[k4];
+                    p0 = __builtin_fmaf(a4.x, tl[(32 * k4) * PD_LDV], p0);
+                    p1 = __builtin_fmaf(a4.y, tl[(32 * k4 + 8) * PD_LDV], p1);
+                    p0 = __builtin_fmaf(a4.z, tl[(32 * k4 + 16) * PD_LDV], p0);
+                    p1 = __builtin_fmaf(a4.w, tl[(32 * k4 + 24) * PD_LDV], p1);
+                }
+                cacc += p0 + p1;
+            } else
             for (int c = nchunks - 1; c >= 0; --c) {
                 const int nr = min(128, Tv - 128 * c);
                 const float* alc = L.al + 128 * c;
