@@ -187,7 +187,7 @@ __device__ __forceinline__ void pdh_cell1(const PersistDecodeArgs& A, const u32x
     const int par = t & 1, MT = A.MT;
     if (HELPED) pdh_wait_flags_helped(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, A.ctl + zt + PD_F_H + tile * 32, A.ctl + zt + PD_F_H + (PDH_BMAX + tile) * 32, (uint32_t)t, sh);
     else pd_wait_flags_all(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, sh);
-    if (sh->abort) return;
+    PD_PHASE_ABORT(sh);
     PD_STAMP(role, 2);
     if (HELPED && t > 0) {
         const auto rh = gt_rsrc(A.hpart, 2u * PDH_BMAX * PDH_HP * 4u);
@@ -217,7 +217,7 @@ __device__ __forceinline__ void pdh_cell2(const PersistDecodeArgs& A, const u32x
                                           int zt) {
     const int par = t & 1, MT = A.MT;
     pd_wait_count(A, A.ctl + zt + PD_CNT3, PD_WANT(A, t), sh);
-    if (sh->abort) return;
+    PD_PHASE_ABORT(sh);
     PD_STAMP(role, 4);
     pdh_xload<4>(A.h1h[par], MT, PD_KBH / 2, 0, x);
     PD_PIN();
@@ -242,7 +242,7 @@ __device__ __forceinline__ void pdh_rec2(const PersistDecodeArgs& A, u32x4 (&wh2
     if (HELP) pdh_load_tile<4>(A.w2h, tile, PD_KBH / 2, wh2, zt);  // (a helper streams its own W2h: arrives during the wait)
     if (WAIT) {
         pd_wait_count(A, A.ctl + zt + PD_CNT4, PD_WANT(A, t), sh);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
     }
     PD_STAMP(role, 7);
     const int col = threadIdx.x & 15;
@@ -362,25 +362,26 @@ __device__ __forceinline__ void pdh_run_tile(const PersistDecodeArgs& A, float* 
     }
     __syncthreads();
     for (int t = 0; t < A.steps; ++t) {
+        if (sh->abort) return;          // (the one abort check of the step: PD_PHASE_ABORT)
         PD_STAMP(role, 0);
         PD_ZT(zt);
         if (CHAIN) {
-            float unused = 0.f;
+            float4 unused4;
             int bs = b;
             asm volatile("" : "+s"(bs));
-            pd_chain<false, true>(A, L, R, t, bs, sh, unused, zt);
-            if (sh->abort) return;
+            pd_chain<false, true>(A, L, R, t, bs, sh, unused4, zt);
+            PD_PHASE_ABORT(sh);
             PD_STAMP(role, 1);
             PD_PIN();
             pdh_load_tile<2>(A.w1x, tile, PD_KBP / 2 + PD_KBC / 2, W.x1, zt);
             pdh_load_tile<4>(A.w2x, tile, PD_KBH / 2, W.x2, zt);    // (arrives during cell 1)
         }
         pdh_cell1<CHAIN>(A, W.x1, t, tile, lds, S, sh, role, zt);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         if (HELP && t + 1 < A.steps) pdh_load_tile<4>(A.w1h, tile, PD_KBH / 2, W.h1, zt);  // (streamed: arrives during the wait for h1)
         u32x4 x[PDH_MT][4];
         pdh_cell2(A, W.x2, x, t, tile, lds, S, sh, role, zt);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         if (CHAIN) continue;                          // (a chain workgroup goes straight on to the next chain)
         if (t + 1 == A.steps) break;
         pdh_rec1(A, x, W.h1, tile, lds, false, S.p1);
@@ -392,7 +393,7 @@ __device__ __forceinline__ void pdh_run_tile(const PersistDecodeArgs& A, float* 
             pdh_publish(v, A.hpart + (size_t)help * PDH_HP + zt, A.ctl + zt + PD_F_H + help * 32, (uint32_t)t + 1u);
         }
         pdh_rec2<true, HELP>(A, W.h2, t, tile, lds, S, sh, role, zt, help);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
     }
 }
 
@@ -410,17 +411,18 @@ __device__ __forceinline__ void pdh_run_proj(const PersistDecodeArgs& A, float* 
 #pragma unroll
     for (int e = 0; e < 2; ++e) { S.c1[e] = 0.f; S.c2[e] = 0.f; S.p1[e] = A.b1h[tile * 16 + col]; S.p2[e] = A.b2h[tile * 16 + col]; }
     for (int t = 0; t < A.steps; ++t) {
+        if (sh->abort) return;          // (the one abort check of the step: PD_PHASE_ABORT)
         PD_STAMP(1, 0);
         PD_ZT(zt);
         pdh_cell1<false>(A, W.x1, t, tile, lds, S, sh, 1, zt);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         {
             u32x4 x[PDH_MT][4];
             pdh_cell2(A, W.x2, x, t, tile, lds, S, sh, 1, zt);
-            if (sh->abort) return;
+            PD_PHASE_ABORT(sh);
         }
         pd_wait_count(A, A.ctl + zt + PD_CNT4, PD_WANT(A, t), sh);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         pdh_proj(A, wpj, t, ptile, pmt, lds);
         PD_STAMP(1, 6);
         if (t + 1 == A.steps) break;

@@ -90,6 +90,11 @@ __device__ __forceinline__ void pd_drain() { asm volatile("s_waitcnt vmcnt(0)" :
 #define PD_PIN4(a) do { asm volatile("" : "+v"((a).x), "+v"((a).y), "+v"((a).z), "+v"((a).w) : : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 struct PdShared { int abort; };
+// After a give-up (a bounded wait ran out, or found the launch's error word raised) the workgroup leaves at the top of its NEXT step:
+// one LDS read of the flag per step instead of one behind every wait -- each was a read, a wait for it and a branch, ~60 ns, four or
+// five of them on the step's critical path.  Until then the remaining phases of the step run on whatever the failed wait left
+// (no address and no loop bound depends on data), and each of their waits gives up on the error word after 64 polls.
+#define PD_PHASE_ABORT(sh) do { } while (0)
 
 // diagnostic phase stamps (GSTTACO_STAMPS=1, tools/stamps_persist.py): thread 0 of workgroups 0 (chain), 32 (projection) and 255 (plain) at
 // the middle step, slot = role * 32 + index (100 MHz ticks)
@@ -341,21 +346,21 @@ __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int
     float4 x0[3], x1[3];
     if (split) {
         pd_wait_flags<PD_FS>(A, A.ctl + PD_F_P, A.B, (uint32_t)t + 1u, sh);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         PD_STAMP(role, 1);
         pd_xload<0, 2, 3>(xa, MT, x0, x1);
         PD_PIN();
         pd_mma<2, 0, 1, 3>(x0, x1, W.x1, a0, a1);
         PD_STAMP(role, 2);
         pd_wait_flags<PD_FS>(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         PD_STAMP(role, 3);
         pd_xload<2, 3, 3>(xa, MT, x0, x1);
         PD_PIN();
         pd_mma<1, 2, 1, 3>(x0, x1, W.x1, a0, a1);
     } else {
         pd_wait_flags<PD_FS>(A, A.ctl + PD_F_C, A.B, (uint32_t)t + 1u, sh);      // (a chain's context flag is set after its prenet flag)
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         PD_STAMP(role, 3);
         pd_xload<0, 3, 3>(xa, MT, x0, x1);
         // (the chain role: cell 2's input half, behind this cell's fragments -- requested at cell 2's entry, the poll of the h1 arrivals
@@ -378,7 +383,7 @@ __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int
 // helped_p2 >= 0 (chain role, t > 0): this tile's layer-2 recurrent half comes from its helper -- the helper's flag rides in the poll
 // of the h1 arrivals, the sums (slot helped_p2 of hpart) are requested with the h1 fragments
 __device__ __forceinline__ void pd_cell2(const PersistDecodeArgs& A, PdW& W, int t, int tile, float* lds, float& c2v, float& p2v, float& p1_next, bool with_rec1,
-                                        PdShared* sh, int help_tile, bool stream_h1, bool stream_x2, int role = 2, int helped_p2 = -1) {
+                                        PdShared* sh, int help_tile, bool stream_h1, bool stream_x2, int role = 2, int helped_p2 = -1, bool helped_role = false) {
     const int par = t & 1, MT = A.MT;
     // (the chain role streams W2x: these registers belong to the chain's operands until cell 1.  Requested BEHIND the wait, with the
     // h1 fragments: in front of it the poll queued behind its 64 KB -- loads return in order -- and this role, which everybody waits
@@ -387,22 +392,28 @@ __device__ __forceinline__ void pd_cell2(const PersistDecodeArgs& A, PdW& W, int
     if (help_tile >= 0) pd_load_tile<8>(A.w1h, help_tile, wu);  // (a chain workgroup's W1h tile, streamed: arrives during the wait)
     if (stream_h1) pd_load_tile<8>(A.w1h, tile, W.h1);          // (layer-2 helpers keep W2h resident and stream their own W1h)
     pd_wait_count(A, A.ctl + PD_CNT3, PD_WANT(A, t), sh, helped_p2 >= 0 ? A.ctl + PD_F_H + helped_p2 * 32 : nullptr, (uint32_t)t);
-    if (sh->abort) return;
+    PD_PHASE_ABORT(sh);
     PD_STAMP(role, 5);
     float4 x0[8], x1[8];
     if (stream_x2) pd_load_tile<8>(A.w2x, tile, W.x2);
     pd_xload<0, 8, 8>(A.h1[par], MT, x0, x1);
-    if (helped_p2 >= 0) {
+    // (the helper's sums: requested with the fragments -- out of range when there are none: no branch around the request -- and looked
+    // at BEHIND the MFMAs: a use right here, or inside a branch, is a wait for every fragment before the first MFMA instead of a
+    // counted wait per fragment)
+    float4 d2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (helped_role) {
         const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
-        const float4 d2 = gt_bload4_sc1(rh, (uint32_t)((helped_p2 * 512 + ((int)threadIdx.x & ~3)) * 4), 0u);
-        const int e = threadIdx.x & 3;
-        p2v = e == 0 ? d2.x : e == 1 ? d2.y : e == 2 ? d2.z : d2.w;
+        d2 = gt_bload4_sc1(rh, helped_p2 >= 0 ? (uint32_t)((helped_p2 * 512 + ((int)threadIdx.x & ~3)) * 4) : GT_OOB, 0u);
     }
     PD_PIN();
     PD_STAMP(role, 21);         // (fragments requested)
     f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
     pd_mma<8, 0, 1, 8>(x0, x1, W.x2, a0, a1);
     PD_STAMP(role, 6);
+    if (helped_role && helped_p2 >= 0) {
+        const int e = threadIdx.x & 3;
+        p2v = e == 0 ? d2.x : e == 1 ? d2.y : e == 2 ? d2.z : d2.w;
+    }
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
     const float z = pd_reduce<8, false>(lds, p2v);
     PD_STAMP(role, 22);         // (reduced)
@@ -448,7 +459,7 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
     const int par = t & 1, MT = A.MT;
     if (!GK) {          // (a group kernel has waited for every group's arrivals at once)
         pd_wait_count(A, A.ctl + PD_CNT4, PD_WANT(A, t), sh);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
     }
     if (!GK) PD_STAMP(1, 9);
     const int lane = threadIdx.x & 63;
@@ -565,7 +576,7 @@ __device__ __forceinline__ void pd_chain_issue(const PersistDecodeArgs& A, const
 // TV128: at most 128 tokens (the headline shape: two score passes, one context chunk -- as compile-time constants they are worth
 // ~0.2 us per step, same-box A/B profiles/r05_ab.txt)
 template <bool HELPED, bool MIRROR, bool TV128 = false>
-__device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v, int zt,
+__device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float4& hraw, int zt,
                                               float4 (&ra)[16], float4 (&rb)[16]) {
     const int tid = threadIdx.x + zt, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -590,6 +601,7 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
     // (a row is requested when either half of the wave keeps it: the two halves are different k-parts)
     const uint32_t ua = (uint32_t)__builtin_amdgcn_readlane((int)qba, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qba, 32);
     const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)qbb, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qbb, 32);
+    if (tid < Tv) L.nz[tid] = A.sigmoid_noise * nzv;        // (in front of the poll too: behind it, a kernel-argument reload sat on the critical path)
     PD_PIN();
     PD_STAMP(0, 13);
     // ---- S1: this utterance's row of prenet-0 pre-activations (granules tagged with the step they are for)
@@ -613,9 +625,8 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
         }
         L.y0[tid] = fmaxf(__builtin_bit_cast(float, g.x), 0.f) * k0;
     }
-    if (tid < Tv) L.nz[tid] = A.sigmoid_noise * nzv;
     __syncthreads();
-    if (sh->abort) return;
+    PD_PHASE_ABORT(sh);
     PD_STAMP(0, 14);
     // ---- prenet layer 1 (Taco2.py:262-283): two launch-path threads' 16-row sums each.  The query weights (Steps.py:122) are
     // requested into the first half's registers: row i's request right behind the multiply-add that consumed register i, so the 16
@@ -710,12 +721,11 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
         pd_drain();
         if (tid == 0) pd_st1_sc1(A.ctl + PD_F_P + b * PD_FS, (uint32_t)t + 1u);
     }
-    if (sh->abort) return;
-    if (HELPED && t > 0) {                          // (behind the barrier the flag poll joined: the helper's sums, consumed by cell 1)
+    PD_PHASE_ABORT(sh);
+    if (HELPED) {       // (behind the barrier the flag poll joined: the helper's sums, consumed by cell 1.  Requested without a branch
+                        // -- out of range at step 0 -- and handed out raw: a use in here is a full memory wait inside the chain)
         const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
-        const float4 d1 = gt_bload4_sc1(rh, (uint32_t)((b * 512 + (tid & ~3)) * 4), 0u);
-        const int e = tid & 3;
-        p1v = e == 0 ? d1.x : e == 1 ? d1.y : e == 2 ? d1.z : d1.w;
+        hraw = gt_bload4_sc1(rh, t > 0 ? (uint32_t)((b * 512 + (tid & ~3)) * 4) : GT_OOB, 0u);
     }
     if (tid < PD_A) L.qs[tid] = reduce_partial(L.partial, 32, PD_A, tid) + R.biasq;
     __syncthreads();
@@ -865,10 +875,11 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
 // zt: 0, or a per-step opaque zero (the group kernels: nothing of the chain's address arithmetic may be hoisted out of the step loop)
 // MIRROR (mixed precision): the prenet output and the context leave as the bf16 mirror (kernels.h gt_blk_off_h) only
 template <bool HELPED, bool MIRROR = false, bool TV128 = false>
-__device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float& p1v, int zt = 0) {
+// HELPED: `hraw` returns the four sums around this thread's element of the helper's layer-1 half (step > 0; element tid % 4 is its own)
+__device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float4& hraw, int zt = 0) {
     float4 ra[16], rb[16];
     pd_chain_issue(A, R, t, b, zt, ra, rb);
-    pd_chain_rest<HELPED, MIRROR, TV128>(A, L, R, t, b, sh, p1v, zt, ra, rb);
+    pd_chain_rest<HELPED, MIRROR, TV128>(A, L, R, t, b, sh, hraw, zt, ra, rb);
 }
 
 // ====================================================================================================================== roles
@@ -905,6 +916,7 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
     }
     __syncthreads();
     for (int t = 0; t < A.steps; ++t) {
+        if (sh->abort) return;          // (the one abort check of the step: PD_PHASE_ABORT)
         PD_STAMP(0, 0);
         // (diagnostic: when this workgroup's steps 0, 1, 2, 8, 64, half, 3/4 and last begin -- slots 24..31 of the chain role)
         if (A.dbg && threadIdx.x == 0 && blockIdx.x == 0) {
@@ -914,23 +926,25 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
         }
         if (live) {
             PD_ZT(zt);
-            if (A.tvp == 128) pd_chain<true, false, true>(A, L, R, t, b, sh, p1v, zt);
-            else pd_chain<true>(A, L, R, t, b, sh, p1v, zt);
-            if (sh->abort) return;
+            float4 hraw;
+            if (A.tvp == 128) pd_chain<true, false, true>(A, L, R, t, b, sh, hraw, zt);
+            else pd_chain<true>(A, L, R, t, b, sh, hraw, zt);
+            PD_PHASE_ABORT(sh);
+            if (t > 0) { const int e = tid & 3; p1v = e == 0 ? hraw.x : e == 1 ? hraw.y : e == 2 ? hraw.z : hraw.w; }
         } else if (t > 0) {                                     // no chain to hide it behind: fetch the layer-1 half directly
             pd_wait_flags(A, A.ctl + PD_F_H + tile * 32, 1, (uint32_t)t, sh);
-            if (sh->abort) return;
+            PD_PHASE_ABORT(sh);
             const auto rh = gt_rsrc(A.hpart, 2u * 32u * 512u * 4u);
             const float4 d1 = gt_bload4_sc1(rh, (uint32_t)((tile * 512 + (tid & ~3)) * 4), 0u);
             const int e = tid & 3;
             p1v = e == 0 ? d1.x : e == 1 ? d1.y : e == 2 ? d1.z : d1.w;
         }
         pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, false, true, 0, PD_X2_EARLY != 0);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         float unused = 0.f;
         // (the layer-2 half from its helper: flag and sums ride with the h1 arrivals' poll and fragments)
-        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, PD_X2_EARLY == 0, 0, t > 0 ? 32 + tile : -1);
-        if (sh->abort) return;
+        pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, PD_X2_EARLY == 0, 0, t > 0 ? 32 + tile : -1, true);
+        PD_PHASE_ABORT(sh);
     }
 }
 
@@ -945,15 +959,16 @@ __device__ __forceinline__ void pd_run_proj(const PersistDecodeArgs& A, float* l
     pd_load_tile<9>(A.wp, ptile, wpj);
     float c1v = 0.f, c2v = 0.f, p1v = A.b1h[tile * 16 + col], p2v = A.b2h[tile * 16 + col];
     for (int t = 0; t < A.steps; ++t) {
+        if (sh->abort) return;          // (the one abort check of the step: PD_PHASE_ABORT)
         const int par = t & 1;
         PD_STAMP(1, 0);
         pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, true, false, 1);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         float unused = 0.f;
         pd_cell2(A, W, t, tile, lds, c2v, p2v, unused, false, sh, -1, false, false, 1);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         pd_proj(A, wpj, t, ptile, pmt, lds, sh);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         if (t + 1 == A.steps) break;
         pd_load_tile<8>(A.w1h, tile, W.h1);
         PD_PIN();
@@ -975,17 +990,18 @@ __device__ __forceinline__ void pd_run_plain(const PersistDecodeArgs& A, float* 
     if (HELP != 1) pd_load_tile<8>(A.w2h, tile, W.h2);
     float c1v = 0.f, c2v = 0.f, p1v = A.b1h[tile * 16 + col], p2v = A.b2h[tile * 16 + col];
     for (int t = 0; t < A.steps; ++t) {
+        if (sh->abort) return;          // (the one abort check of the step: PD_PHASE_ABORT)
         const int par = t & 1;
         PD_STAMP(2, 0);
         pd_cell1(A, W, t, tile, lds, c1v, p1v, sh, true);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         pd_cell2(A, W, t, tile, lds, c2v, p2v, p1v, true, sh, HELP == 1 ? help_tile : -1, HELP == 2, false);
         PD_STAMP(2, 12);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         if (t + 1 == A.steps) break;
         if (HELP == 1) pd_load_tile<8>(A.w2h, tile, W.h2);      // (streamed: arrives during the wait)
         pd_wait_count(A, A.ctl + PD_CNT4, PD_WANT(A, t), sh);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         PD_STAMP(2, 13);
         p2v = pd_rec2(A, t, A.h2[par], W.h2, tile, HELP == 2 ? help_tile : -1, lds);        // for step t + 1
         PD_STAMP(2, 14);

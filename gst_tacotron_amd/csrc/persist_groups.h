@@ -121,7 +121,7 @@ __device__ __forceinline__ void pd_g_cell1_all(const PersistDecodeArgs& A, const
     constexpr int RG = 16 * MTG;
     const int par = t & 1, MT = A.MT;
     pd_wait_flags_all(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, sh);       // (a chain's context flag follows its prenet flag)
-    if (sh->abort) return;
+    PD_PHASE_ABORT(sh);
     PD_STAMP(role, 2);
     float4 xa0[3], xa1[3], xb0[3], xb1[3];
     pd_g_xload<MTG, 0, 3, 3>(A.xa[par], MT, 0, xa0, xa1);
@@ -162,7 +162,7 @@ __device__ __forceinline__ void pd_g_cell2_all(const PersistDecodeArgs& A, const
     constexpr int RG = 16 * MTG;
     const int par = t & 1, MT = A.MT;
     pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT3, PD_WANT(A, t), sh);
-    if (sh->abort) return;
+    PD_PHASE_ABORT(sh);
     PD_STAMP(role, 4);
     float4 x0[8], x1[8];
     pd_g_xload<MTG, 0, 8, 8>(A.h1[par], MT, 0, x0, x1);
@@ -202,7 +202,7 @@ __device__ __forceinline__ void pd_g_rec_all(const PersistDecodeArgs& A, const f
     const int MT = A.MT;
     if (WAIT) {
         pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, PD_WANT(A, t), sh);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
     }
     PD_STAMP(role, 7);
     const float* hb = LAYER == 1 ? A.h1[t & 1] : A.h2[t & 1];
@@ -282,6 +282,7 @@ __device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float*
     // recurrent halves -- waits in memory meanwhile (its own rows of `stash`, written and re-read by the same thread: L2 hits,
     // requested back before the first flag wait).
     for (int t = 0; t < A.steps; ++t) {
+        if (sh->abort) return;          // (the one abort check of the step: PD_PHASE_ABORT)
         PD_STAMP(role, 0);
         PD_ZT(zt);
         float* st = A.stash + (size_t)blockIdx.x * (4 * GM * PD_NT) + tid + zt;
@@ -292,11 +293,11 @@ __device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float*
                 st[(4 * g + 2) * PD_NT] = S.p1[g]; st[(4 * g + 3) * PD_NT] = S.p2[g];
             }
             PD_PIN();
-            float unused = 0.f;
+            float4 unused4;
             int bs = b;
             asm volatile("" : "+s"(bs));
-            pd_chain<false>(A, L, R, t, bs, sh, unused, zt);
-            if (sh->abort) return;
+            pd_chain<false>(A, L, R, t, bs, sh, unused4, zt);
+            PD_PHASE_ABORT(sh);
             PD_STAMP(role, 1);
             PD_PIN();
             pd_load_tile<3>(A.w1x, tile, W.x1);
@@ -308,12 +309,12 @@ __device__ __forceinline__ void pd_g_run_tile(const PersistDecodeArgs& A, float*
             pd_load_tile<8>(A.w2x, tile, W.x2); pd_load_tile<8>(A.w1h, tile, W.h1);        // (for the NEXT phase: they arrive during cell 1)
         }
         pd_g_cell1_all<GM, MTG>(A, W.x1, t, tile, lds, c1, p1, sh, role, zt);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         pd_g_cell2_all<GM, MTG, true, CHAIN, CHAIN>(A, W.x2, W.h1, W.h2, t, tile, lds, c2, p2, p1, sh, role, zt);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         if (t + 1 == A.steps) break;
         pd_g_rec_all<GM, MTG, 2, CHAIN, true>(A, W.h2, t, tile, lds, p2, sh, role, zt);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
     }
 }
 
@@ -337,19 +338,20 @@ __device__ __forceinline__ void pd_g_run_proj(const PersistDecodeArgs& A, float*
     auto p1 = [&](int g) -> float& { return sl[(4 * g + 2) * PD_NT]; };
     auto p2 = [&](int g) -> float& { return sl[(4 * g + 3) * PD_NT]; };
     for (int t = 0; t < A.steps; ++t) {
+        if (sh->abort) return;          // (the one abort check of the step: PD_PHASE_ABORT)
         PD_STAMP(1, 0);
         PD_ZT(zt);
         pd_load_tile<3>(A.w1x, tile, W.x1);
         pd_g_cell1_all<GM, MTG>(A, W.x1, t, tile, lds, c1, p1, sh, 1, zt);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         pd_g_cell2_all<GM, MTG, true, false, false>(A, W.x2, W.h1, W.h2, t, tile, lds, c2, p2, p1, sh, 1, zt);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
         // every group's projection behind ONE wait for the h2 arrivals (the chains that need them start ~10 us later: their
         // workgroups still have this step's recurrent halves to multiply); the projection tile (72 KB) arrives during that wait
         float4 wpj[9];
         pd_load_tile<9>(A.wp, ptile, wpj);
         pd_wait_count_all<GM>(A, A.ctl + zt + PD_CNT4, PD_WANT(A, t), sh);
-        if (sh->abort) return;
+        PD_PHASE_ABORT(sh);
 #pragma unroll
         for (int g = 0; g < GM; ++g)
             if (g < A.G) pd_proj<true>(A, wpj, t, ptile, MTG * g + pm, lds, sh, g);
