@@ -95,6 +95,16 @@ struct PdShared { int abort; };
 // five of them on the step's critical path.  Until then the remaining phases of the step run on whatever the failed wait left
 // (no address and no loop bound depends on data), and each of their waits gives up on the error word after 64 polls.
 #define PD_PHASE_ABORT(sh) do { } while (0)
+// a pointer argument into scalar registers NOW: placed in front of a wait, for what is dereferenced right behind it -- kernel
+// arguments the compiler does not keep in registers are otherwise re-read (s_load + wait, ~0.1-0.2 us) between the hand-off and the
+// first fragment request
+#define PD_HOLD(p)                                                                                      \
+    do {                                                                                                \
+        const uint64_t u_ = reinterpret_cast<uint64_t>(p);                                              \
+        uint32_t lo_ = __builtin_amdgcn_readfirstlane((uint32_t)u_), hi_ = __builtin_amdgcn_readfirstlane((uint32_t)(u_ >> 32)); \
+        asm volatile("" : "+s"(lo_), "+s"(hi_));                                                        \
+        p = reinterpret_cast<decltype(p)>(((uint64_t)hi_ << 32) | lo_);                                 \
+    } while (0)
 
 // diagnostic phase stamps (GSTTACO_STAMPS=1, tools/stamps_persist.py): thread 0 of workgroups 0 (chain), 32 (projection) and 255 (plain) at
 // the middle step, slot = role * 32 + index (100 MHz ticks)
@@ -342,6 +352,8 @@ __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int
     const int par = t & 1, MT = A.MT;
     if (stream_x1) pd_load_tile<3>(A.w1x, tile, W.x1);          // (the chain role: arrives while the other chains finish)
     const float* xa = A.xa[par];
+    float* h1d = A.h1[par];
+    PD_HOLD(xa); PD_HOLD(h1d);
     f32x4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
     float4 x0[3], x1[3];
     if (split) {
@@ -373,7 +385,7 @@ __device__ __forceinline__ void pd_cell1(const PersistDecodeArgs& A, PdW& W, int
     }
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
     const float z = pd_reduce<8, false>(lds, p1v);          // (pd_arrive's barrier below closes the slabs)
-    pd_gates_store(z, c1v, A.h1[par], tile, A.B, MT);
+    pd_gates_store(z, c1v, h1d, tile, A.B, MT);
     PD_STAMP(role, 4);
     pd_arrive(A.ctl + PD_CNT3);
 }
@@ -391,12 +403,15 @@ __device__ __forceinline__ void pd_cell2(const PersistDecodeArgs& A, PdW& W, int
     float4 wu[8];
     if (help_tile >= 0) pd_load_tile<8>(A.w1h, help_tile, wu);  // (a chain workgroup's W1h tile, streamed: arrives during the wait)
     if (stream_h1) pd_load_tile<8>(A.w1h, tile, W.h1);          // (layer-2 helpers keep W2h resident and stream their own W1h)
+    const float* h1p = A.h1[par];
+    float* h2d = A.h2[par];
+    PD_HOLD(h1p); PD_HOLD(h2d);
     pd_wait_count(A, A.ctl + PD_CNT3, PD_WANT(A, t), sh, helped_p2 >= 0 ? A.ctl + PD_F_H + helped_p2 * 32 : nullptr, (uint32_t)t);
     PD_PHASE_ABORT(sh);
     PD_STAMP(role, 5);
     float4 x0[8], x1[8];
     if (stream_x2) pd_load_tile<8>(A.w2x, tile, W.x2);
-    pd_xload<0, 8, 8>(A.h1[par], MT, x0, x1);
+    pd_xload<0, 8, 8>(h1p, MT, x0, x1);
     // (the helper's sums: requested with the fragments -- out of range when there are none: no branch around the request -- and looked
     // at BEHIND the MFMAs: a use right here, or inside a branch, is a wait for every fragment before the first MFMA instead of a
     // counted wait per fragment)
@@ -417,7 +432,7 @@ __device__ __forceinline__ void pd_cell2(const PersistDecodeArgs& A, PdW& W, int
     pd_spill(lds, threadIdx.x >> 6, a0, a1);
     const float z = pd_reduce<8, false>(lds, p2v);
     PD_STAMP(role, 22);         // (reduced)
-    pd_gates_store(z, c2v, A.h2[par], tile, A.B, MT);
+    pd_gates_store(z, c2v, h2d, tile, A.B, MT);
     PD_STAMP(role, 7);
     pd_arrive(A.ctl + PD_CNT4);
     PD_STAMP(role, 8);
@@ -457,6 +472,10 @@ __device__ __forceinline__ float pd_rec1_mem(const PersistDecodeArgs& A, const f
 template <bool GK = false>     // GK: called by a group kernel (its stamp slots)
 __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4 (&wp)[9], int t, int ptile, int pmt, float* lds, PdShared* sh, int g = 0) {
     const int par = t & 1, MT = A.MT;
+    const float* h2p = A.h2[par];
+    const float* xap = A.xa[par];
+    uint2* z0g = A.z0g;
+    PD_HOLD(h2p); PD_HOLD(xap); PD_HOLD(z0g);
     if (!GK) {          // (a group kernel has waited for every group's arrivals at once)
         pd_wait_count(A, A.ctl + PD_CNT4, PD_WANT(A, t), sh);
         PD_PHASE_ABORT(sh);
@@ -464,8 +483,8 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
     if (!GK) PD_STAMP(1, 9);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const auto rh = gt_rsrc(A.h2[par], 0x7FFFF000u);
-    const auto rx = gt_rsrc(A.xa[par], 0x7FFFF000u);
+    const auto rh = gt_rsrc(h2p, 0x7FFFF000u);
+    const auto rx = gt_rsrc(xap, 0x7FFFF000u);
     float4 x[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -493,7 +512,7 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
             if (gcol < A.z_col0 + PD_P) {
                 uint2 g;
                 g.x = __builtin_bit_cast(uint32_t, v); g.y = (uint32_t)t + 1u;
-                pd_st2_sc1(A.z0g + (size_t)grow * PD_P + (gcol - A.z_col0), g);
+                pd_st2_sc1(z0g + (size_t)grow * PD_P + (gcol - A.z_col0), g);
             }
         } else if (gcol < A.n_split) {
             A.pre[(size_t)grow * A.ld_pre + (size_t)t * A.n_split + gcol] = v;
