@@ -185,30 +185,40 @@ __device__ __forceinline__ void pdh_wait_flags_helped(const PersistDecodeArgs& A
 template <bool HELPED>
 __device__ __forceinline__ void pdh_cell1(const PersistDecodeArgs& A, const u32x4 (&wx1)[2], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role, int zt) {
     const int par = t & 1, MT = A.MT;
+    const uint16_t* xahp = A.xah[par];
+    uint16_t* h1hd = A.h1h[par];
+    PD_HOLD(xahp); PD_HOLD(h1hd);           // (persist_decode.hip PD_HOLD: no kernel-argument reload behind the wait)
     if (HELPED) pdh_wait_flags_helped(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, A.ctl + zt + PD_F_H + tile * 32, A.ctl + zt + PD_F_H + (PDH_BMAX + tile) * 32, (uint32_t)t, sh);
     else pd_wait_flags_all(A, A.ctl + zt + PD_F_C, (uint32_t)t + 1u, sh);
     PD_PHASE_ABORT(sh);
     PD_STAMP(role, 2);
-    if (HELPED && t > 0) {
+    // (the helpers' sums: requested without a branch -- out of range at step 0 -- and assigned BEHIND the MFMAs: a use inside a branch
+    // right here is a wait for them, and for every fragment request that follows in program order, before the first MFMA)
+    float hp1[2] = {0.f, 0.f}, hp2[2] = {0.f, 0.f};
+    if (HELPED) {
         const auto rh = gt_rsrc(A.hpart, 2u * PDH_BMAX * PDH_HP * 4u);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const uint32_t off = (uint32_t)((tile * PDH_HP + (threadIdx.x + zt) + 512 * e) * 4);
-            S.p1[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (int)off, 0, 16));
-            S.p2[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (int)off, PDH_BMAX * PDH_HP * 4, 16));
+            const uint32_t off = t > 0 ? (uint32_t)((tile * PDH_HP + (threadIdx.x + zt) + 512 * e) * 4) : GT_OOB;
+            hp1[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (int)off, 0, 16));
+            hp2[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rh, (int)off, PDH_BMAX * PDH_HP * 4, 16));
         }
     }
     u32x4 x[PDH_MT][2];
-    pdh_xload<2>(A.xah[par], MT, PD_KBP / 2 + PD_KBC / 2, 0, x);
+    pdh_xload<2>(xahp, MT, PD_KBP / 2 + PD_KBC / 2, 0, x);
     PD_PIN();
     f32x4 a[PDH_MT];
 #pragma unroll
     for (int mt = 0; mt < PDH_MT; ++mt) a[mt] = f32x4{0, 0, 0, 0};
     pdh_mma<2, 0, 1>(x, wx1, PD_KBP / 2 + PD_KBC / 2, a);
+    if (HELPED && t > 0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { S.p1[e] = hp1[e]; S.p2[e] = hp2[e]; }
+    }
     pdh_spill(lds, threadIdx.x >> 6, a);
     float z[2];
     pdh_reduce<8>(lds, S.p1, z);
-    pdh_gates_store(z, S.c1, A.h1h[par], tile + zt, A.B, MT);
+    pdh_gates_store(z, S.c1, h1hd, tile + zt, A.B, MT);
     pd_arrive(A.ctl + zt + PD_CNT3);
     PD_STAMP(role, 3);
 }
@@ -216,10 +226,13 @@ __device__ __forceinline__ void pdh_cell1(const PersistDecodeArgs& A, const u32x
 __device__ __forceinline__ void pdh_cell2(const PersistDecodeArgs& A, const u32x4 (&wx2)[4], u32x4 (&x)[PDH_MT][4], int t, int tile, float* lds, PdHS& S, PdShared* sh, int role,
                                           int zt) {
     const int par = t & 1, MT = A.MT;
+    const uint16_t* h1hp = A.h1h[par];
+    uint16_t* h2hd = A.h2h[par];
+    PD_HOLD(h1hp); PD_HOLD(h2hd);
     pd_wait_count(A, A.ctl + zt + PD_CNT3, PD_WANT(A, t), sh);
     PD_PHASE_ABORT(sh);
     PD_STAMP(role, 4);
-    pdh_xload<4>(A.h1h[par], MT, PD_KBH / 2, 0, x);
+    pdh_xload<4>(h1hp, MT, PD_KBH / 2, 0, x);
     PD_PIN();
     f32x4 a[PDH_MT];
 #pragma unroll
@@ -228,7 +241,7 @@ __device__ __forceinline__ void pdh_cell2(const PersistDecodeArgs& A, const u32x
     pdh_spill(lds, threadIdx.x >> 6, a);
     float z[2];
     pdh_reduce<8>(lds, S.p2, z);
-    pdh_gates_store(z, S.c2, A.h2h[par], tile + zt, A.B, MT);
+    pdh_gates_store(z, S.c2, h2hd, tile + zt, A.B, MT);
     pd_arrive(A.ctl + zt + PD_CNT4);
     PD_STAMP(role, 5);
 }
@@ -278,12 +291,14 @@ __device__ __forceinline__ void pdh_rec2(const PersistDecodeArgs& A, u32x4 (&wh2
     }
 }
 // projection tile `ptile`, M-tile `pmt` from the mirrors of h2 (32-k blocks 0..31) and of the context (the last 4 of xa's 12)
-__device__ __forceinline__ void pdh_proj(const PersistDecodeArgs& A, const u32x4 (&wp)[5], int t, int ptile, int pmt, float* lds) {
-    const int par = t & 1, MT = A.MT;
+// (h2hp / xahp / z0g: this step's mirrors and the granule buffer, held in scalar registers by the caller in front of its wait)
+__device__ __forceinline__ void pdh_proj(const PersistDecodeArgs& A, const u32x4 (&wp)[5], int t, int ptile, int pmt, float* lds, const uint16_t* h2hp, const uint16_t* xahp,
+                                         uint2* z0g) {
+    const int MT = A.MT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const auto rh = gt_rsrc(A.h2h[par], 0x7FFFF000u);
-    const auto rx = gt_rsrc(A.xah[par], 0x7FFFF000u);
+    const auto rh = gt_rsrc(h2hp, 0x7FFFF000u);
+    const auto rx = gt_rsrc(xahp, 0x7FFFF000u);
     constexpr int NKB = PD_KBPJ / 2;
     u32x4 x[5];
 #pragma unroll
@@ -314,7 +329,7 @@ __device__ __forceinline__ void pdh_proj(const PersistDecodeArgs& A, const u32x4
             if (gcol < A.z_col0 + PD_P) {
                 uint2 g;
                 g.x = __builtin_bit_cast(uint32_t, v); g.y = (uint32_t)t + 1u;
-                pd_st2_sc1(A.z0g + (size_t)grow * PD_P + (gcol - A.z_col0), g);
+                pd_st2_sc1(z0g + (size_t)grow * PD_P + (gcol - A.z_col0), g);
             }
         } else if (gcol < A.n_split) {
             A.pre[(size_t)grow * A.ld_pre + (size_t)t * A.n_split + gcol] = v;
@@ -421,9 +436,13 @@ __device__ __forceinline__ void pdh_run_proj(const PersistDecodeArgs& A, float* 
             pdh_cell2(A, W.x2, x, t, tile, lds, S, sh, 1, zt);
             PD_PHASE_ABORT(sh);
         }
+        const uint16_t* h2hp = A.h2h[t & 1];
+        const uint16_t* xahp = A.xah[t & 1];
+        uint2* z0g = A.z0g;
+        PD_HOLD(h2hp); PD_HOLD(xahp); PD_HOLD(z0g);
         pd_wait_count(A, A.ctl + zt + PD_CNT4, PD_WANT(A, t), sh);
         PD_PHASE_ABORT(sh);
-        pdh_proj(A, wpj, t, ptile, pmt, lds);
+        pdh_proj(A, wpj, t, ptile, pmt, lds, h2hp, xahp, z0g);
         PD_STAMP(1, 6);
         if (t + 1 == A.steps) break;
         {   // (the h1 fragments again: kept in registers across the projection they cost this role spills; nobody waits for this half)
