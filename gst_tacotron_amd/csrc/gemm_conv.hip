@@ -409,9 +409,29 @@ __global__ __launch_bounds__(256) void gt_conv_gemm_bf16_kernel(ConvGemmArgs A) 
 // (tap, slice) step moves per 2048 MFMA-cycles.  Both LDS operands are double-buffered: one barrier per step, the next
 // step's weights and the next slice's rows are in flight under the MFMAs.  Same operand roundings and the same fp32
 // accumulation as gt_conv_gemm_bf16_kernel (the order of the K terms differs: tap-major inside a slice).
+// Weight slabs (round 5): straight from memory into LDS (buffer_load ... lds: no staging registers, no ds_write, no VALU between the
+// request and the MFMAs).  A DMA instruction writes its 64 lanes' 16 bytes side by side, so the slab is UNPADDED -- 128 bytes per
+// column -- and swizzled instead: 16-byte chunk c of column r sits at chunk position c ^ (r % 8), which the DMA gets for free (a
+// lane chooses what it FETCHES: lane l of an instruction fills position l % 8 of column r0 + l / 8 with chunk (l % 8) ^ (l / 8)) and
+// the fragment reads undo (eight consecutive columns at one logical chunk hit eight different positions = all 32 banks).
+#ifndef GT_C5_DMA
+#define GT_C5_DMA 1
+#endif
 constexpr int C5_BM = 256, C5_BK = 64, C5_LD = C5_BK + 8, C5_AR = C5_BM + 4;
+constexpr int C5_LDB = GT_C5_DMA ? C5_BK : C5_LD;         // elements per column of the weight slab in LDS
 template <int RN>       // 32-column tiles per wave: the workgroup tile is 256 frames x (2 * RN * 32) channels
-constexpr int c5_lds_bytes() { return 2 * (C5_AR + 2 * RN * 32) * C5_LD * 2; }
+constexpr int c5_lds_bytes() { return 2 * (C5_AR * C5_LD + 2 * RN * 32 * C5_LDB) * 2; }
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+// 16 bytes per lane from a buffer straight into LDS: lane l's data lands at lds_addr + 16 l (lds_addr wave-uniform).  Inline asm, not
+// __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler orders every later LDS read of the kernel behind a DMA it knows of (a
+// vmcnt(0) in front of each).  The caller waits (s_waitcnt vmcnt(0)) and synchronises before the data is read.  (The compiler's own
+// counted waits stay safe: loads complete in order, an unknown one behind a known one only makes its wait longer.)
+__device__ __forceinline__ void gt_lds_dma16(__amdgpu_buffer_rsrc_t rs, const uint32_t lds_addr, const uint32_t voff, const uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 
 // XB / OB: the input / output activations are stored as bf16 (compile-time: as run-time flags both forms' registers were live at once)
 template <int RN, bool XB = false, bool OB = false>
@@ -421,7 +441,7 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
     constexpr int B_U4 = BN * (C5_BK / 8) / 512;                 // 16-byte pieces (8 k of one column) per thread per step
     extern __shared__ __attribute__((aligned(16))) __bf16 c5_lds[];
     __bf16* As = c5_lds;                                         // [2][C5_AR][C5_LD]
-    __bf16* Bs = c5_lds + 2 * C5_AR * C5_LD;                     // [2][BN][C5_LD]
+    __bf16* Bs = c5_lds + 2 * C5_AR * C5_LD;                     // [2][BN][C5_LDB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves: 64 frames x (RN * 32) channels each
@@ -462,7 +482,19 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
     const uint32_t abase = (uint32_t)((((int64_t)b * A.T + t0 + row0) * A.Cin + (tid & 15) * 4) * AE);
     float4 ra[XB ? 1 : A_H0];
     uint2 rh[XB ? A_H0 : 1];
-    u32x4 rb[B_U4];
+    u32x4 rb[GT_C5_DMA ? 1 : B_U4];
+    // weight slab DMA: BN / 8 instructions of 8 columns x 128 bytes per step, dealt to the 8 waves; lane l: column l / 8 of the eight,
+    // logical chunk (l % 8) ^ (l / 8) -> position l % 8
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wt), 0, 0x7FFFF000, 0x00020000);
+    const uint32_t lds_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Bs;
+    const uint32_t wvoff = (uint32_t)(((lane >> 3) * A.ldk + (((lane & 7) ^ (lane >> 3)) * 8)) * 2);
+    auto dma_b = [&](const int buf, const int tap, const int k0) {
+#pragma unroll
+        for (int i = 0; i < BN / 64; ++i) {
+            const int r0 = (__builtin_amdgcn_readfirstlane(wave) * (BN / 64) + i) * 8;
+            gt_lds_dma16(rs_w, lds_b + (uint32_t)((buf * BN + r0) * C5_LDB * 2), wvoff, (uint32_t)((((size_t)(n0 + r0)) * A.ldk + tap * A.Cin + k0) * 2));
+        }
+    };
     auto load_a = [&](const int k0, const int half) {
 #pragma unroll
         for (int i = 0; i < A_H0; ++i) {
@@ -497,6 +529,7 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
         }
     };
     auto load_b = [&](const int tap, const int k0) {
+        if (GT_C5_DMA) return;
 #pragma unroll
         for (int i = 0; i < B_U4; ++i) {
             const int f = tid + i * 512;
@@ -504,6 +537,7 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
         }
     };
     auto store_b = [&](const int buf) {
+        if (GT_C5_DMA) return;
 #pragma unroll
         for (int i = 0; i < B_U4; ++i) {
             const int f = tid + i * 512;
@@ -518,6 +552,7 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
     store_a(0, 1);
     load_b(0, 0);
     store_b(0);
+    if (GT_C5_DMA) { dma_b(0, 0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     __syncthreads();
     const int kh = lane >> 5, l31 = lane & 31;
     for (int s = 0; s < nsteps; ++s) {
@@ -527,16 +562,19 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
         // the other A buffer was last read in the previous slice)
         const int sn = min(s + 1, nsteps - 1);
         load_b(sn % 5, (sn / 5) * C5_BK);
+        // (DMA: into the other slab, last read in step s - 1 -- every wave is past that step's barrier)
+        if (GT_C5_DMA) dma_b((s + 1) & 1, sn % 5, (sn / 5) * C5_BK);
         if (tap == 0 || tap == 2) load_a(min(sl + 1, nslices - 1) * C5_BK, tap >> 1);
         const __bf16* Ab = As + ((sl & 1) * C5_AR + wm * 64 + l31 + tap) * C5_LD + kh * 8;
-        const __bf16* Bb = Bs + ((s & 1) * BN + wn * RN * 32 + l31) * C5_LD + kh * 8;
+        const __bf16* Bb = Bs + ((s & 1) * BN + wn * RN * 32 + l31) * C5_LDB + (GT_C5_DMA ? 0 : kh * 8);
 #pragma unroll
         for (int ks = 0; ks < C5_BK / 16; ++ks) {
             bf16x8 av[RM], bv[RN];
 #pragma unroll
             for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * C5_LD + ks * 16);
 #pragma unroll
-            for (int j = 0; j < RN; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * C5_LD + ks * 16);
+            for (int j = 0; j < RN; ++j)        // (DMA: chunk 2 ks + kh of column .. + l31 sits at position (2 ks + kh) ^ (l31 % 8): j * 32 keeps the column's low bits)
+                bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * C5_LDB + (GT_C5_DMA ? (((2 * ks + kh) ^ (l31 & 7)) * 8) : ks * 16));
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -544,6 +582,7 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
         }
         store_b((s + 1) & 1);           // (after the last step: written, never read)
         if (tap == 1 || tap == 3) store_a((sl + 1) & 1, tap >> 1);
+        if (GT_C5_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the next slab has landed -- requested a step's MFMAs ago)
         __syncthreads();
     }
 
