@@ -893,8 +893,10 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     const bool persist_bf16 = n_bf16 == 5 && c->w_xa_h && c->w_xa2_h && c->w_h1_h[0] && c->w_h2_h[0];
     const bool persist_base = c->persist_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->front_mode >= 2 &&
                               (n_bf16 == 0 || persist_bf16) && c->proj_z.wp != nullptr && c->proj.nkb >= 32 &&
-                              c->worker_tiles == 2 && c->co_worker_tiles == 1 && g.att_type != GSTTACO_ATT_LSA &&
-                              gt_dec_front_supported(mel, P0, P1, att, Tv) && c->lstm_x[0].nkb == 24 && c->lstm_x[1].nkb == 64 && c->lstm_h[0].nkb == 64 &&
+                              c->worker_tiles == 2 && c->co_worker_tiles == 1 &&
+                              // (the LSA extension: the one-group fp32 kernel's LSA chain, up to 128 tokens -- else the launch path)
+                              (g.att_type != GSTTACO_ATT_LSA || (n_bf16 == 0 && c->loc_pack && gt_persist_decode_lsa_fits(B, Tv, g.loc_filters, g.loc_kernel))) &&
+                              front_fits(c, Tv) && c->lstm_x[0].nkb == 24 && c->lstm_x[1].nkb == 64 && c->lstm_h[0].nkb == 64 &&
                               c->lstm_h[1].nkb == 64 && B <= c->persist_rows && (B <= 16 || !c->persist_split16 || c->w_stash) && (B <= 32 || c->w_stash) &&
                               gt_persist_decode_supported(mel, r, P0, P1, att, H1, H2, B, Tv, c->proj_z.ntiles, c->proj_z.nkb, c->persist_slots, c->persist_split16,
                                                           persist_bf16 ? 1 : 0);
@@ -963,7 +965,8 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
         // (randomness: hashed keep decisions, or the masks / noise in the buffers -- injected, or generated above -- always one of them)
         const bool hashed = !injected_mask && g.prenet_rate == 0.5f && c->keep_hash;
         if (persist_base) {
-            if (!((g.prenet_rate == 0.f || hashed || has_mask) && (g.sigmoid_noise == 0.f || has_noise)))
+            const bool lsa_p = g.att_type == GSTTACO_ATT_LSA;        // (LSA: softmax, no sigmoid noise)
+            if (!((g.prenet_rate == 0.f || hashed || has_mask) && (g.sigmoid_noise == 0.f || has_noise || lsa_p)))
                 return fail(c, GSTTACO_E_INVALID, "internal: the persistent decode launch was chosen without its randomness");
             PersistDecodeArgs a{};
             a.w1x = c->lstm_x[0].wp; a.w1h = c->lstm_h[0].wp; a.b1h = c->lstm_h[0].bias;
@@ -972,11 +975,12 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             a.n_out = c->proj_out; a.n_split = mel * r; a.z_col0 = c->z_col0;
             a.W1 = c->pw1; a.b1 = c->pb1; a.Wq = c->pwq; a.bq = c->pbq; a.av = c->att_v; a.score_bias = c->att_sb;
             a.pm = c->w_pm;
-            a.noise = (g.sigmoid_noise > 0.f) ? c->w_noise : nullptr;
+            a.noise = (g.sigmoid_noise > 0.f && !lsa_p) ? c->w_noise : nullptr;
             a.masks = (g.prenet_rate > 0.f && !hashed) ? c->w_masks : nullptr;
             a.seed_ptr = c->w_seed; a.tok_len = tlen;
-            a.drop_rate = g.prenet_rate; a.drop_scale = drop_scale; a.sigmoid_noise = g.sigmoid_noise;
+            a.drop_rate = g.prenet_rate; a.drop_scale = drop_scale; a.sigmoid_noise = lsa_p ? 0.f : g.sigmoid_noise;
             a.keep_hash = hashed ? 1 : 0; a.att_type = g.att_type;
+            a.loc_pack = c->loc_pack; a.loc_f = g.loc_filters; a.loc_k = g.loc_kernel; a.lsa_cumulate = g.lsa_cumulate; a.lsa_smoothing = g.lsa_smoothing;
             a.xa[0] = c->w_xa; a.xa[1] = c->w_xa2;
             a.h1[0] = c->w_h1[0]; a.h1[1] = c->w_h1[1]; a.h2[0] = c->w_h2[0]; a.h2[1] = c->w_h2[1];
             a.stash = c->w_stash;

@@ -334,6 +334,10 @@ struct PersistDecodeArgs {
     const int32_t* tok_len;                            // masked-mode extension (A12) or NULL
     float drop_rate, drop_scale, sigmoid_noise;
     int keep_hash, att_type;
+    // att_type == GSTTACO_ATT_LSA (the one-group kernel, up to 128 tokens): the location weights as the LDS image the fused front end
+    // uses (LsaPack above; resident in the chain workgroups' LDS for the whole launch) -- the state lives in their LDS
+    const float* loc_pack;
+    int loc_f, loc_k, lsa_cumulate, lsa_smoothing;
     // state / workspace
     float* xa[2];                                      // blocked [24][MT][256], ping-pong by step parity
     float* h1[2]; float* h2[2];                        // blocked [64][MT][256]
@@ -357,6 +361,7 @@ struct PersistDecodeArgs {
 size_t gt_persist_decode_ctl_words();
 bool gt_persist_decode_supported(int mel, int r, int P0, int P1, int A, int H1, int H2, int B, int Tv, int pj_tiles, int pj_nkb, int slots, int split16, int bf16);
 int gt_persist_decode_max_batch();
+bool gt_persist_decode_lsa_fits(int B, int Tv, int loc_f, int loc_k);       // the LSA chain: one group, <= 128 tokens, operands beside the memory tile
 hipError_t gt_persist_decode_init();                   // opt in to > 64 KiB dynamic LDS; once, outside stream capture
 int gt_persist_decode_blocks_per_cu();
 hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a, const float* b0, int split16, hipStream_t stream);

@@ -527,6 +527,7 @@ __device__ __forceinline__ void pd_proj(const PersistDecodeArgs& A, const float4
 // ---- the per-utterance chain (front_lean.h's arithmetic; every thread plays launch-path threads tid and tid + 512)
 struct PdChainLds {
     float *y0, *y1, *qs, *vs, *sc, *nz, *pv, *al, *ks1, *partial, *red, *tile;
+    float *lfeat, *lpack;       // LSA (one-group kernel, tvp = 128): location features [128][LFS] and the weight image (kernels.h LsaPack) behind the tile
 };
 // LDS of a chain workgroup (floats): [8 reduction slabs of its LSTM tile | small vectors | the utterance's processed memory, tvp rows].
 // The chain's GEMV partials (16 x 256) and the context's row-group sums (8 x 128) ALIAS the slabs: the chain is over (a barrier
@@ -549,10 +550,13 @@ __device__ __forceinline__ PdChainLds pd_carve(float* smem, int tvp, int nslab =
     L.partial = smem; L.red = smem;
     L.y0 = smem + nslab * slab_floats; L.y1 = L.y0 + PD_P; L.qs = L.y1 + PD_P; L.vs = L.qs + PD_A; L.sc = L.vs + PD_A; L.nz = L.sc + tvp; L.pv = L.nz + tvp;
     L.al = L.pv + tvp; L.ks1 = L.al + tvp; L.tile = L.ks1 + PD_P;
+    L.lfeat = L.tile + tvp * PD_LDV; L.lpack = L.lfeat;        // (pd_lsa_carve)
     return L;
 }
 
 struct PdChainRegs { float bias1, biasq, sbias; int Tv; uint64_t seed; bool hashed, drop, noisy; };
+// the LSA chain's LDS behind the 128-row tile: location features of the tile's rows + the weight image
+__host__ __device__ inline int pd_lsa_floats(int loc_f, int loc_k) { const LsaPack lp = gt_lsa_pack(PD_A, loc_f, loc_k); return 128 * lp.LFS + lp.total; }
 
 // ---- ALL of prenet-1's weights for step t, requested before the projection's hand-off is even looked at (the bf16 kernel: a phase
 // earlier still, in front of the recurrent half of the step before).  Launch-path wave kp (of 16) owns rows 16 kp .. 16 kp + 15,
@@ -594,7 +598,10 @@ __device__ __forceinline__ void pd_chain_issue(const PersistDecodeArgs& A, const
 // the chain behind its weight requests (pd_chain_issue)
 // TV128: at most 128 tokens (the headline shape: two score passes, one context chunk -- as compile-time constants they are worth
 // ~0.2 us per step, same-box A/B profiles/r05_ab.txt)
-template <bool HELPED, bool MIRROR, bool TV128 = false>
+// LSA (with TV128, tvp = 128; the one-group kernel): the step-wise location-sensitive extension in the chain -- dec_front_lsa.hip's two
+// MFMA products on 8 waves instead of 16, each score row's two channel halves summed as the 16-wave kernel's two waves sum them
+// (bitwise that kernel); the weight image stays in LDS for the whole launch, the cumulative alignment lives in L.pv
+template <bool HELPED, bool MIRROR, bool TV128 = false, bool LSA = false>
 __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float4& hraw, int zt,
                                               float4 (&ra)[16], float4 (&rb)[16]) {
     const int tid = threadIdx.x + zt, lane = tid & 63;
@@ -753,14 +760,72 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
     // (the thread's four pieces of the query and of v are the same for every row it plays: read once -- re-read per row they were
     // two thirds of the pass's LDS bytes, 128 KB of 192, on a pass that is LDS- and transcendental-bound)
     const int npass = TV128 ? 2 : A.tvp >> 6;
+    if (LSA) {
+        // (dec_front_lsa.hip / front_body.h, whose comments say why: location features = a Toeplitz product of the state, location term
+        // = a second product, both on v_mfma_f32_16x16x4_f32 -- a k-ordered fmaf chain, so a tile's sums do not depend on which wave
+        // computes it -- then score = sum_a tanh(q + key + loc + bias))
+        const LsaPack lp = gt_lsa_pack(PD_A, A.loc_f, A.loc_k);
+        const int LK = A.loc_k, LFS = lp.LFS, LDWS = lp.LDWS, LCS = lp.LCS;
+        const float* ldw = L.lpack;
+        const float* lcw = L.lpack + lp.off_cw;
+        const float* lcbs = L.lpack + lp.off_cb;
+        const float* labias = L.lpack + lp.off_ab;
+        const int l15 = lane & 15, lq = lane >> 4, lpad = (LK - 1) / 2;
+        const int NF = lp.LFc >> 4;
+        for (int it = wave; it < 8 * NF; it += PD_NW) {
+            const int m = it / NF, n = it - m * NF;
+            const float cb = lcbs[16 * n + l15];
+            f32x4 acc = {cb, cb, cb, cb};
+#pragma unroll 2
+            for (int ks = 0; ks < (lp.LKp >> 2); ++ks) {
+                const int j = 4 * ks + lq, ts = 16 * m + l15 + j - lpad;
+                const float xv = (j < LK && ts >= 0 && ts < Tv) ? L.pv[ts] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, lcw[j * LCS + 16 * n + l15], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) L.lfeat[(16 * m + 4 * lq + i) * LFS + 16 * n + l15] = acc[i];
+        }
+        __syncthreads();
+        {   // wave = 16-row tile; its two halves of the channels are the 16-wave kernel's two waves of that tile: summed separately, then added
+            const int m = wave;
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int wn = 0; wn < 2; ++wn) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { const float lb = labias[16 * (wn * 4 + g) + l15]; acc[g] = f32x4{lb, lb, lb, lb}; }
+                const float* lfr = L.lfeat + (16 * m + l15) * LFS + lq;
+                const float* lwr = ldw + lq * LDWS + 16 * wn * 4 + l15;
+#pragma unroll 2
+                for (int ks = 0; ks < (lp.LFp >> 2); ++ks) {
+                    const float fa = lfr[4 * ks];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, lwr[4 * ks * LDWS + 16 * g], acc[g], 0, 0, 0);
+                }
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int a = 16 * (wn * 4 + g) + l15;
+                    const float qa = L.qs[a];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) e[i] += gt_tanh(qa + L.tile[(16 * m + 4 * lq + i) * PD_LDV + a] + acc[g][i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[i] += gt_row_sum<16>(e[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (l15 == 0 && 16 * m + 4 * lq + i < Tv) L.sc[16 * m + 4 * lq + i] = z[i];
+        }
+    }
     float4 qr[4], wr[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4 && !LSA; ++j) {
         qr[j] = *reinterpret_cast<const float4*>(L.qs + 4 * ((tid & 7) + 8 * j));
         wr[j] = *reinterpret_cast<const float4*>(L.vs + 4 * ((tid & 7) + 8 * j));
     }
 #pragma unroll 1
-    for (int hh = 0; hh < npass; ++hh) {
+    for (int hh = 0; hh < (LSA ? 0 : npass); ++hh) {
         const int row = hh * 64 + (tid >> 3), li = tid & 7;
         f32x2 s2 = {0.f, 0.f};
 #pragma unroll
@@ -782,7 +847,29 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
     // pass reads them as four 16-byte words instead of sixteen broadcast reads (a third of its LDS instructions); rows >= Tv: zeros.
     // In the slabs behind the context's row-group sums: free between the query's reduction and the cells' first spill.
     float* alp = L.red + 8 * PD_A;
-    if (A.att_type == GSTTACO_ATT_SMA) {
+    if (LSA) {
+        // softmax (or the smoothing normalisation, Layers.py:426-444) over the Tv positions: one wave, a serial run per lane (front_body.h)
+        if (tid < 64) {
+            const int per = (Tv + 63) / 64;
+            const int t0 = lane * per, t1 = min(Tv, t0 + per);
+            float mx = -INFINITY;
+            for (int tt = t0; tt < t1; ++tt) mx = fmaxf(mx, L.sc[tt]);
+            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            float sum = 0.f;
+            for (int tt = t0; tt < t1; ++tt) {
+                const float e = A.lsa_smoothing ? 1.f / (1.f + expf(-L.sc[tt])) : expf(L.sc[tt] - mx);
+                L.al[tt] = e;
+                sum += e;
+            }
+            for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            const float inv = 1.f / sum;
+            for (int tt = t0; tt < t1; ++tt) {
+                L.al[tt] *= inv;
+                if (TV128) alp[(tt & 7) * 16 + (tt >> 3)] = L.al[tt];
+            }
+        }
+        if (TV128 && tid >= Tv && tid < 128) alp[(tid & 7) * 16 + (tid >> 3)] = 0.f;
+    } else if (A.att_type == GSTTACO_ATT_SMA) {
         if (tid < Tv) {
             const int tt = tid;
             float v = L.pv[tt] * gt_sigmoid(L.sc[tt] + (R.noisy ? L.nz[tt] : 0.f));
@@ -865,7 +952,8 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
         }
     }
     __syncthreads();
-    if (tid < Tv) L.pv[tid] = L.al[tid];                    // (the next step's "previous alignment"; every read of pv is behind barriers)
+    // (the next step's "previous alignment" -- LSA: the running sum of the alignments, or the last one; every read of pv is behind barriers)
+    if (tid < Tv) L.pv[tid] = (LSA && A.lsa_cumulate) ? L.pv[tid] + L.al[tid] : L.al[tid];
     if (tid < 64) {
         if (tid < PD_A / 4) {
             float c[4];
@@ -893,12 +981,12 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
 // HELPED: the workgroup's layer-1 recurrent half comes from a helper workgroup (the one-group kernel) and is fetched here
 // zt: 0, or a per-step opaque zero (the group kernels: nothing of the chain's address arithmetic may be hoisted out of the step loop)
 // MIRROR (mixed precision): the prenet output and the context leave as the bf16 mirror (kernels.h gt_blk_off_h) only
-template <bool HELPED, bool MIRROR = false, bool TV128 = false>
+template <bool HELPED, bool MIRROR = false, bool TV128 = false, bool LSA = false>
 // HELPED: `hraw` returns the four sums around this thread's element of the helper's layer-1 half (step > 0; element tid % 4 is its own)
 __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdChainLds& L, const PdChainRegs& R, int t, int b, PdShared* sh, float4& hraw, int zt = 0) {
     float4 ra[16], rb[16];
     pd_chain_issue(A, R, t, b, zt, ra, rb);
-    pd_chain_rest<HELPED, MIRROR, TV128>(A, L, R, t, b, sh, hraw, zt, ra, rb);
+    pd_chain_rest<HELPED, MIRROR, TV128, LSA>(A, L, R, t, b, sh, hraw, zt, ra, rb);
 }
 
 // ====================================================================================================================== roles
@@ -906,7 +994,9 @@ __device__ __forceinline__ void pd_chain(const PersistDecodeArgs& A, const PdCha
 // the roles, not their sum.
 __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* smem, PdShared* sh) {
     float* lds = smem;
-    const PdChainLds L = pd_carve(smem, A.tvp);
+    PdChainLds L = pd_carve(smem, A.tvp);
+    const bool lsa = A.att_type == GSTTACO_ATT_LSA;         // (the launcher: then tvp = 128 and the LDS holds the LSA operands behind the tile)
+    if (lsa) L.lpack = L.lfeat + 128 * gt_lsa_pack(PD_A, A.loc_f, A.loc_k).LFS;
     const int tile = blockIdx.x, b = blockIdx.x, tid = threadIdx.x, col = tid & 15;
     const bool live = b < A.B;                                  // (batches below 32: the spare chain workgroups only run their LSTM tile)
     // nothing of this tile's LSTM weights stays resident here: the chain's own operands (all of prenet 1's weights, prefetched)
@@ -923,15 +1013,19 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
         R.seed = R.hashed ? *A.seed_ptr : 0ull;
         R.bias1 = tid < PD_P ? A.b1[tid] : 0.f;
         R.biasq = tid < PD_A ? A.bq[tid] : 0.f;
-        R.sbias = A.score_bias[0];
+        R.sbias = lsa ? 0.f : A.score_bias[0];
         // processed memory of utterance b -> LDS, once (rows >= T_v: zeros, as the launch path's bounded descriptor reads them)
         const float4* src = reinterpret_cast<const float4*>(A.pm + (size_t)b * A.Tv * PD_A);
         for (int e = tid; e < A.tvp * PD_A / 4; e += PD_NT) {
             const int row = e / (PD_A / 4), c4 = e % (PD_A / 4);
             *reinterpret_cast<float4*>(L.tile + row * PD_LDV + 4 * c4) = row < R.Tv ? src[(size_t)row * (PD_A / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (tid < PD_A) L.vs[tid] = A.av[tid];
-        if (tid < A.tvp) L.pv[tid] = tid == 0 ? 1.f : 0.f;     // one-hot(0) initial alignment (Steps.py:201-206)
+        if (tid < PD_A) L.vs[tid] = lsa ? 0.f : A.av[tid];      // LSA has no attention_v (Layers.py:407)
+        if (tid < A.tvp) L.pv[tid] = (tid == 0 && !lsa) ? 1.f : 0.f;     // one-hot(0) initial alignment (Steps.py:201-206); LSA: the zero state (Layers.py:356)
+        if (lsa) {
+            const int n4 = gt_lsa_pack(PD_A, A.loc_f, A.loc_k).total >> 2;
+            for (int i = tid; i < n4; i += PD_NT) reinterpret_cast<float4*>(L.lpack)[i] = reinterpret_cast<const float4*>(A.loc_pack)[i];
+        }
     }
     __syncthreads();
     for (int t = 0; t < A.steps; ++t) {
@@ -946,7 +1040,8 @@ __device__ __forceinline__ void pd_run_chain(const PersistDecodeArgs& A, float* 
         if (live) {
             PD_ZT(zt);
             float4 hraw;
-            if (A.tvp == 128) pd_chain<true, false, true>(A, L, R, t, b, sh, hraw, zt);
+            if (lsa) pd_chain<true, false, true, true>(A, L, R, t, b, sh, hraw, zt);
+            else if (A.tvp == 128) pd_chain<true, false, true>(A, L, R, t, b, sh, hraw, zt);
             else pd_chain<true>(A, L, R, t, b, sh, hraw, zt);
             PD_PHASE_ABORT(sh);
             if (t > 0) { const int e = tid & 3; p1v = e == 0 ? hraw.x : e == 1 ? hraw.y : e == 2 ? hraw.z : hraw.w; }
@@ -1068,6 +1163,10 @@ size_t gt_persist_decode_ctl_words() { return PD_CTL_WORDS; }
 
 int gt_persist_decode_max_batch() { return PD_BMAX; }
 
+bool gt_persist_decode_lsa_fits(int B, int Tv, int loc_f, int loc_k) {
+    return B <= 32 && Tv <= 128 && loc_f >= 1 && loc_k >= 1 && pd_lds_floats(128) + pd_lsa_floats(loc_f, loc_k) <= pd_lds_floats(PD_TVMAX, true);   // (the opted-in LDS size)
+}
+
 // `split16`: a batch of 17..32 rows as two groups of 16 (experiment; the default is the one-group kernel with its helper workgroups)
 // the bf16 kernel's LDS: slabs of 64 rows; the chain workgroups' 16 (or, beside more than 128 tokens, 8) + their chain state
 __host__ __device__ constexpr int pdh_chain_floats(int tvp, int nslab) { return nslab * PDH_SLAB + 3 * PD_P + 2 * PD_A + 4 * tvp + tvp * PD_LDV; }
@@ -1133,13 +1232,16 @@ hipError_t gt_launch_persist_decode(const PersistDecodeArgs& a_in, const float* 
         return hipGetLastError();
     }
     int mtg = 2;
+    const bool lsa = a.att_type == GSTTACO_ATT_LSA;
+    if (lsa) split16 = 0;
     const PdKernel k = pd_kernel_for(a.B, split16, &a.G, &mtg);
-    a.tvp = (a.Tv + 63) / 64 * 64;
+    a.tvp = lsa ? 128 : (a.Tv + 63) / 64 * 64;       // (LSA: the 128-token chain only; gt_persist_decode_lsa_fits)
     const bool gk = k != gt_persist_decode_kernel;
+    if (lsa && (gk || !gt_persist_decode_lsa_fits(a.B, a.Tv, a.loc_f, a.loc_k))) return hipErrorInvalidValue;
     a.n_chain = gk ? a.B : PD_UTT;
     a.twopass = pd_chain_slabs(a.tvp, gk) == 8 ? 1 : 0;
     const int n = PD_CTL_WORDS > a.B * PD_P ? PD_CTL_WORDS : a.B * PD_P;
     hipLaunchKernelGGL(gt_persist_decode_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.z0g, b0, a.ctl, a.B);
-    hipLaunchKernelGGL(k, dim3(PD_NWG), dim3(PD_NT), (size_t)pd_lds_floats(a.tvp, gk) * 4, stream, a);
+    hipLaunchKernelGGL(k, dim3(PD_NWG), dim3(PD_NT), (size_t)(pd_lds_floats(a.tvp, gk) + (lsa ? pd_lsa_floats(a.loc_f, a.loc_k) : 0)) * 4, stream, a);
     return hipGetLastError();
 }

@@ -103,7 +103,12 @@ def test_vocoder_alone_matches_oracle(B, T):
 def _full_case(B, Tv, Tref, steps, seed, att="SMA", lens=None, rate=0.5):
     from gst_tacotron_amd import synthetic, weights
     hp = synthetic.config_hp("cfg2")
-    hp["Tacotron2"]["Decoder"]["Attention"]["Type"] = att
+    if att.startswith("LSA"):           # "LSA" or "LSA/filters/kernel[/s]" (s: the smoothing normalisation)
+        p = att.split("/")
+        hp["Tacotron2"]["Decoder"]["Attention"] = {"Type": "LSA", "Size": 128, "Conv": {"Filters": int(p[1]) if len(p) > 1 else 32,
+                                                   "Kernel_Size": int(p[2]) if len(p) > 2 else 31}, "Smoothing": len(p) > 3}
+    else:
+        hp["Tacotron2"]["Decoder"]["Attention"]["Type"] = att
     hp["Tacotron2"]["Decoder"]["Prenet"]["Dropout_Rate"] = rate
     w = weights.synthetic_weights(hp, seed=0)
     rng = np.random.default_rng(seed)
@@ -329,6 +334,10 @@ PERSIST_CASES = [
     # mixed precision (round 5): the bf16 kernel -- one group of up to 64 rows, activations as bf16 mirrors only -- against the bf16 launch path
     (64, 128, "SMA", "hashed", 100, {"MIXED": "1"}), (40, 60, "BMA", "injected", 100, {"MIXED": "1"}), (20, 150, "SMA", "masked", 100, {"MIXED": "1"}),
     (57, 100, "SMA", "rate25", 60, {"MIXED": "1"}), (5, 33, "BMA", "nodrop", 100, {"MIXED": "1"}),
+    # the step-wise LSA extension in the chain (round 5: the one-group kernel, up to 128 tokens; both location products on the fp32 matrix
+    # pipe as in dec_front_lsa.hip, the score's channel halves summed as that kernel's two waves sum them): against the launch path's
+    # fused front end; filter / tap counts off the MFMA granules; smoothing; masked
+    (32, 128, "LSA", "hashed", 100, {}), (11, 90, "LSA", "injected", 100, {}), (20, 128, "LSA/20/9/s", "masked", 60, {}), (7, 33, "LSA/8/7", "nodrop", 100, {}),
     # 17..32 rows as two groups of 16 (GSTTACO_PERSIST_SPLIT16=1: the measured alternative to the helpers of the one-group kernel)
     (32, 128, "SMA", "hashed", 100, {"GSTTACO_PERSIST_SPLIT16": "1"}), (23, 70, "BMA", "injected", 100, {"GSTTACO_PERSIST_SPLIT16": "1"}),
 ]

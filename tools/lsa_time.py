@@ -1,7 +1,7 @@
 """How much the step-wise LSA extension loses by running on the launch path: whole Inference_Step at the headline shape
 (batch 32 x 128 tokens x 1000 frames) with Attention.Type = LSA (k = 31, 32 filters) against SMA on the persistent launch and on the
 launch path (GSTTACO_PERSIST_DECODE=0).    python tools/lsa_time.py"""
-import os, sys, time
+import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gst_tacotron_amd import synthetic, weights
@@ -29,6 +29,7 @@ def run(att, env):
     for k in env:
         del os.environ[k]
     del m
+    gc.collect()        # (the persistent launch is taken only while the process has ONE live context: no lingering one)
 
 run("SMA", {})
 run("SMA", {"GSTTACO_PERSIST_DECODE": "0"})

@@ -1,7 +1,7 @@
 """What decoder sizes other than the reference's cost today: whole Inference_Step at the headline shape (batch 32 x 128
 tokens x 1000 frames) for hyper-parameters the persistent launch does not take -- they run the launch path (3 launches per decode step).
     python tools/other_sizes_time.py"""
-import os, sys, time
+import gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gst_tacotron_amd import synthetic, weights
@@ -30,6 +30,7 @@ def run(tag, edit, env=None):
     for k in env:
         del os.environ[k]
     del m
+    gc.collect()        # (the persistent launch is taken only while the process has ONE live context: no lingering one)
 
 dec = lambda hp: hp["Tacotron2"]["Decoder"]
 run("reference sizes (256/256, 128, 1024/1024)", lambda hp: None)
