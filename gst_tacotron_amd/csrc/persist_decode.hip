@@ -1126,6 +1126,8 @@ __global__ __launch_bounds__(PD_NT) void gt_persist_decode_kernel(PersistDecodeA
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ PdShared sh;
     if (threadIdx.x == 0) sh.abort = 0;
+    // (diagnostic: when workgroups 0 and 255 enter the kernel -- slots 9 / 10 of the chain role; against the first step's start in slot 24)
+    if (A.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == PD_NWG - 1)) A.dbg[blockIdx.x == 0 ? 9 : 10] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     const int tile = blockIdx.x;
     const int n_pj = A.pj_tiles * A.MT;

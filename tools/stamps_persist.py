@@ -37,10 +37,12 @@ chain_legend = dict(legend); chain_legend.update({13: "weights requested", 14: "
 legend.update({21: "cell 2 fragments requested", 22: "cell 2 sums reduced"})
 for r in range(3):
     t0 = buf[r * 32]
-    st = sorted((buf[r * 32 + i], i) for i in range(1, 24 if r == 0 else 32) if buf[r * 32 + i])
+    st = sorted((buf[r * 32 + i], i) for i in range(1, 24 if r == 0 else 32) if buf[r * 32 + i] and not (r == 0 and i in (9, 10)))
     lg = chain_legend if r == 0 else legend
     print(names[r], "(us since its step start):", ", ".join("[%d %s] %.2f" % (i, lg.get(i, ""), (v - t0) / 100.0) for v, i in st))
 print("step starts relative to chain WG 0's (us): proj %.2f plain %.2f" % ((buf[32] - buf[0]) / 100.0, (buf[64] - buf[0]) / 100.0))
+if buf[9] and buf[24]:
+    print("kernel entry of workgroup 0 -> its step 0 starts: %.1f us; workgroup 255 enters %.1f us after workgroup 0" % ((buf[24] - buf[9]) / 100.0, (buf[10] - buf[9]) / 100.0))
 steps = 500
 ts = [0, 1, 2, 8, 64, steps >> 1, (3 * steps) >> 2, steps - 1]
 tv = [buf[24 + k] for k in range(8)]
