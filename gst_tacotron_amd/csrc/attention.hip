@@ -159,14 +159,14 @@ __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs 
             const int t0 = tid * per, t1 = min(Tv, t0 + per);
             float mx = -INFINITY;
             for (int t = t0; t < t1; ++t) mx = fmaxf(mx, sc[t]);
-            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            mx = gt_wave_max(mx);
             float sum = 0.f;
             for (int t = t0; t < t1; ++t) {
                 const float e = P.lsa_smoothing ? 1.f / (1.f + expf(-sc[t])) : expf(sc[t] - mx);
                 al[t] = e;
                 sum += e;
             }
-            for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            sum = gt_wave_sum(sum);
             const float inv = 1.f / sum;
             for (int t = t0; t < t1; ++t) {
                 al[t] *= inv;

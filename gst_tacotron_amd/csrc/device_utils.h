@@ -34,6 +34,10 @@ __device__ __forceinline__ uint32_t gt_row_sum_u32(uint32_t s) {
     if (L >= 16) s += gt_dpp_u32<0x140>(s);
     return s;
 }
+// over all 64 lanes, every lane holding the result: the four in-row steps as DPP moves, the two cross-row steps through the LDS crossbar
+// (two ds_bpermute round trips instead of six)
+__device__ __forceinline__ float gt_wave_sum(float s);
+__device__ __forceinline__ float gt_wave_max(float m);
 // the value of lane i + N of the same 16-lane row (row_shl:N) = __shfl_down(x, N, 16)
 template <int N>
 __device__ __forceinline__ float gt_row_down(float x) {
@@ -51,6 +55,21 @@ __device__ __forceinline__ float gt_row_sum(float s) {
     if (L >= 8) s += gt_dpp<0x141>(s);      // row_half_mirror
     if (L >= 16) s += gt_dpp<0x140>(s);     // row_mirror
     return s;
+}
+__device__ __forceinline__ float gt_wave_sum(float s) {
+    s = gt_row_sum<16>(s);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;
+}
+__device__ __forceinline__ float gt_wave_max(float m) {
+    m = fmaxf(m, gt_dpp<0xB1>(m));
+    m = fmaxf(m, gt_dpp<0x4E>(m));
+    m = fmaxf(m, gt_dpp<0x141>(m));
+    m = fmaxf(m, gt_dpp<0x140>(m));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    return m;
 }
 
 // tanh(x) = 1 - 2/(exp(2x)+1) on one v_exp_f32 + one v_rcp_f32 (5 VALU ops).  No clamp is needed: exp(2x) -> inf

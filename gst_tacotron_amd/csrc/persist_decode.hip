@@ -598,6 +598,32 @@ __device__ __forceinline__ void pd_chain_issue(const PersistDecodeArgs& A, const
 // the chain behind its weight requests (pd_chain_issue)
 // TV128: at most 128 tokens (the headline shape: two score passes, one context chunk -- as compile-time constants they are worth
 // ~0.2 us per step, same-box A/B profiles/r05_ab.txt)
+// LSA chain: location features of the 128 rows from the state in L.pv = Conv1D(state) + bias as a Toeplitz product (front_body.h), for the
+// score pass of the step: called at the step's start, in front of the poll for the projection's hand-off (the state was updated at the end
+// of the previous step's chain, barriers ago)
+__device__ __forceinline__ void pd_lsa_features(const PersistDecodeArgs& A, const PdChainLds& L, int Tv) {
+    const LsaPack lp = gt_lsa_pack(PD_A, A.loc_f, A.loc_k);
+    const int LK = A.loc_k, LFS = lp.LFS, LCS = lp.LCS;
+    const float* lcw = L.lpack + lp.off_cw;
+    const float* lcbs = L.lpack + lp.off_cb;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, lq = lane >> 4, lpad = (LK - 1) / 2;
+    const int NF = lp.LFc >> 4;
+    for (int it = wave; it < 8 * NF; it += PD_NW) {
+        const int m = it / NF, n = it - m * NF;
+        const float cb = lcbs[16 * n + l15];
+        f32x4 acc = {cb, cb, cb, cb};
+#pragma unroll 2
+        for (int ks = 0; ks < (lp.LKp >> 2); ++ks) {
+            const int j = 4 * ks + lq, ts = 16 * m + l15 + j - lpad;
+            const float xv = (j < LK && ts >= 0 && ts < Tv) ? L.pv[ts] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, lcw[j * LCS + 16 * n + l15], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) L.lfeat[(16 * m + 4 * lq + i) * LFS + 16 * n + l15] = acc[i];
+    }
+}
+
 // LSA (with TV128, tvp = 128; the one-group kernel): the step-wise location-sensitive extension in the chain -- dec_front_lsa.hip's two
 // MFMA products on 8 waves instead of 16, each score row's two channel halves summed as the 16-wave kernel's two waves sum them
 // (bitwise that kernel); the weight image stays in LDS for the whole launch, the cumulative alignment lives in L.pv
@@ -628,6 +654,9 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
     const uint32_t ua = (uint32_t)__builtin_amdgcn_readlane((int)qba, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qba, 32);
     const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)qbb, 0) | (uint32_t)__builtin_amdgcn_readlane((int)qbb, 32);
     if (tid < Tv) L.nz[tid] = A.sigmoid_noise * nzv;        // (in front of the poll too: behind it, a kernel-argument reload sat on the critical path)
+    // (LSA: this step's location features from the state the previous step left -- here, where the workgroup waits for the projection's
+    // hand-off anyway; in front of the score pass they were 0.7 us of the critical path.  The barriers below lie in front of their use.)
+    if (LSA) pd_lsa_features(A, L, Tv);
     PD_PIN();
     PD_STAMP(0, 13);
     // ---- S1: this utterance's row of prenet-0 pre-activations (granules tagged with the step they are for)
@@ -765,27 +794,11 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
         // = a second product, both on v_mfma_f32_16x16x4_f32 -- a k-ordered fmaf chain, so a tile's sums do not depend on which wave
         // computes it -- then score = sum_a tanh(q + key + loc + bias))
         const LsaPack lp = gt_lsa_pack(PD_A, A.loc_f, A.loc_k);
-        const int LK = A.loc_k, LFS = lp.LFS, LDWS = lp.LDWS, LCS = lp.LCS;
+        const int LFS = lp.LFS, LDWS = lp.LDWS;
         const float* ldw = L.lpack;
-        const float* lcw = L.lpack + lp.off_cw;
-        const float* lcbs = L.lpack + lp.off_cb;
         const float* labias = L.lpack + lp.off_ab;
-        const int l15 = lane & 15, lq = lane >> 4, lpad = (LK - 1) / 2;
-        const int NF = lp.LFc >> 4;
-        for (int it = wave; it < 8 * NF; it += PD_NW) {
-            const int m = it / NF, n = it - m * NF;
-            const float cb = lcbs[16 * n + l15];
-            f32x4 acc = {cb, cb, cb, cb};
-#pragma unroll 2
-            for (int ks = 0; ks < (lp.LKp >> 2); ++ks) {
-                const int j = 4 * ks + lq, ts = 16 * m + l15 + j - lpad;
-                const float xv = (j < LK && ts >= 0 && ts < Tv) ? L.pv[ts] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, lcw[j * LCS + 16 * n + l15], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) L.lfeat[(16 * m + 4 * lq + i) * LFS + 16 * n + l15] = acc[i];
-        }
-        __syncthreads();
+        const int l15 = lane & 15, lq = lane >> 4;
+        // (the location features were computed at the END of the previous step -- pd_lsa_features -- from the state that step left)
         {   // wave = 16-row tile; its two halves of the channels are the 16-wave kernel's two waves of that tile: summed separately, then added
             const int m = wave;
             float z[4] = {0.f, 0.f, 0.f, 0.f};
@@ -802,16 +815,17 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, lwr[4 * ks * LDWS + 16 * g], acc[g], 0, 0, 0);
                 }
-                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                // (two rows at a time on the packed fp32 ops: per element the same operations in the same order as gt_tanh)
+                f32x2 e01 = {0.f, 0.f}, e23 = {0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int a = 16 * (wn * 4 + g) + l15;
                     const float qa = L.qs[a];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) e[i] += gt_tanh(qa + L.tile[(16 * m + 4 * lq + i) * PD_LDV + a] + acc[g][i]);
+                    const float* tr = L.tile + (16 * m + 4 * lq) * PD_LDV + a;
+                    e01 += gt_tanh2((f32x2{qa, qa} + f32x2{tr[0], tr[PD_LDV]}) + f32x2{acc[g][0], acc[g][1]});
+                    e23 += gt_tanh2((f32x2{qa, qa} + f32x2{tr[2 * PD_LDV], tr[3 * PD_LDV]}) + f32x2{acc[g][2], acc[g][3]});
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) z[i] += gt_row_sum<16>(e[i]);
+                z[0] += gt_row_sum<16>(e01.x); z[1] += gt_row_sum<16>(e01.y); z[2] += gt_row_sum<16>(e23.x); z[3] += gt_row_sum<16>(e23.y);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -854,14 +868,14 @@ __device__ __forceinline__ void pd_chain_rest(const PersistDecodeArgs& A, const 
             const int t0 = lane * per, t1 = min(Tv, t0 + per);
             float mx = -INFINITY;
             for (int tt = t0; tt < t1; ++tt) mx = fmaxf(mx, L.sc[tt]);
-            for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            mx = gt_wave_max(mx);
             float sum = 0.f;
             for (int tt = t0; tt < t1; ++tt) {
                 const float e = A.lsa_smoothing ? 1.f / (1.f + expf(-L.sc[tt])) : expf(L.sc[tt] - mx);
                 L.al[tt] = e;
                 sum += e;
             }
-            for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+            sum = gt_wave_sum(sum);
             const float inv = 1.f / sum;
             for (int tt = t0; tt < t1; ++tt) {
                 L.al[tt] *= inv;
