@@ -30,14 +30,7 @@ size_t gt_attn_lds_bytes(int Tv, int A, int loc_f, int loc_k, int* rows_lds) {
     return fl * sizeof(float);
 }
 
-__device__ __forceinline__ float wave_incl_scan(float x, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    return x;
-}
+__device__ __forceinline__ float wave_incl_scan(float x, int lane) { return gt_wave_incl_scan(x, lane); }
 
 __global__ __launch_bounds__(ATT_THREADS) void gt_attn_step_kernel(AttnStepArgs P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

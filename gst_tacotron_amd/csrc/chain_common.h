@@ -2,6 +2,7 @@
 // kernel (persist_decode.hip): the two must sum in the same order (their results are compared bitwise).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "device_utils.h"
 
 // acc += x * r, one fused multiply-add per component.  EXPLICIT: `a += b * c` leaves the fusion to the optimiser, call site by call
 // site; the chain exists in three kernels (general, lean, persistent) whose outputs are compared bitwise.
@@ -25,11 +26,4 @@ __device__ __forceinline__ float reduce_partial(const float* partial, int kparts
     return z;
 }
 
-__device__ __forceinline__ float front_wave_incl_scan(float x, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        float y = __shfl_up(x, d, 64);
-        if (lane >= d) x += y;
-    }
-    return x;
-}
+__device__ __forceinline__ float front_wave_incl_scan(float x, int lane) { return gt_wave_incl_scan(x, lane); }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -38,6 +39,24 @@ __device__ __forceinline__ uint32_t gt_row_sum_u32(uint32_t s) {
 // (two ds_bpermute round trips instead of six)
 __device__ __forceinline__ float gt_wave_sum(float s);
 __device__ __forceinline__ float gt_wave_max(float m);
+// inclusive prefix sum over the 64 lanes of a FULLY ACTIVE wave: Hillis-Steele inside each 16-lane row on DPP row_shr moves (a lane
+// without a source adds 0), then the totals of the rows in front, read as scalars (v_readlane) -- no LDS-crossbar round trip (as six
+// __shfl_up steps it was six, twice per BMA alignment).  Row r adds ((T0 + T1) + T2) up to its predecessor, in that order.
+__device__ __forceinline__ float gt_wave_incl_scan(float x, int lane) {
+    auto shr = [](float v, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xF, 0xF, true));
+    };
+    x += shr(x, std::integral_constant<int, 0x111>{});
+    x += shr(x, std::integral_constant<int, 0x112>{});
+    x += shr(x, std::integral_constant<int, 0x114>{});
+    x += shr(x, std::integral_constant<int, 0x118>{});
+    const float t0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 15));
+    const float t1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 31));
+    const float t2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 47));
+    const int r = lane >> 4;
+    const float before = r == 0 ? 0.f : (r == 1 ? t0 : (r == 2 ? t0 + t1 : (t0 + t1) + t2));
+    return r == 0 ? x : x + before;
+}
 // the value of lane i + N of the same 16-lane row (row_shl:N) = __shfl_down(x, N, 16)
 template <int N>
 __device__ __forceinline__ float gt_row_down(float x) {

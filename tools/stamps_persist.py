@@ -12,6 +12,8 @@ nums = [int(a) for a in sys.argv[1:] if a.isdigit()]
 B = nums[0] if nums else 32
 Tv = nums[1] if len(nums) > 1 else 128
 hp, inputs = synthetic.config_inputs("cfg2", batch=B)
+if os.environ.get("STAMPS_BMA") == "1":
+    hp["Tacotron2"]["Decoder"]["Attention"]["Type"] = "BMA"
 if os.environ.get("STAMPS_LSA") == "1":      # the LSA chain of the one-group kernel (up to 128 tokens)
     hp["Tacotron2"]["Decoder"]["Attention"] = {"Type": "LSA", "Size": 128, "Conv": {"Filters": 32, "Kernel_Size": 31}, "Smoothing": False}
 w = weights.synthetic_weights(hp, seed=0)
