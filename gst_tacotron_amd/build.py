@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgsttaco.so")
-SOURCES = ["gsttaco.cpp", "skinny_gemm.hip", "gemm_conv.hip", "attention.hip", "dec_front.hip", "dec_front_lsa.hip", "persist_decode.hip", "gst.hip", "audio.hip"]
+SOURCES = ["gsttaco.cpp", "skinny_gemm.hip", "gemm_conv.hip", "conv_wino_split.hip", "attention.hip", "dec_front.hip", "dec_front_lsa.hip", "persist_decode.hip", "gst.hip", "audio.hip"]
 FLAGS_STAMP = os.path.join(LIBDIR, ".flags")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -89,6 +89,23 @@ def build(force=False, verbose=False, debug=False):
     with open(FLAGS_STAMP, "w") as f:
         f.write(" ".join([_hipcc()] + FLAGS))
     return LIB
+
+
+def describe():
+    """One line saying which binary a process is about to load, WITHOUT compiling anything: whether the in-tree library is up to date
+    against the sources lying beside it, its hash and size.  ``__graft_entry__.smoke()`` prints it, so the record of a GPU run says
+    which build it tested (the GPU box runs the library cross-compiled in the build container)."""
+    import hashlib
+    if not os.path.exists(LIB):
+        return "build_mode: NO LIBRARY at {} (python -m gst_tacotron_amd.build)".format(LIB)
+    hdrs = _headers()
+    stale = [src for src in SOURCES if _stale(os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o"), [os.path.join(CSRC, src)] + hdrs)]
+    objs = [os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o") for src in SOURCES]
+    state = ("prebuilt in-tree library, up to date against csrc/ (nothing compiled in this process)" if not stale and not _stale(LIB, [o for o in objs if os.path.exists(o)])
+             else "prebuilt in-tree library, OLDER than " + ", ".join(stale or ["its objects"]))
+    data = open(LIB, "rb").read()
+    return "build_mode: {}; libgsttaco.so sha256[:16] {} ({} bytes){}".format(
+        state, hashlib.sha256(data).hexdigest()[:16], len(data), "; flags changed since the build" if _flags_changed() else "")
 
 
 if __name__ == "__main__":

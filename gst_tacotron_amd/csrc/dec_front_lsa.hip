@@ -1,8 +1,10 @@
 // The step-wise location-sensitive attention extension (reference Modules/Attention/Layers.py:289-444 restated per
 // decoder step) on the fused front end: the LSA = true instantiations of the general utterance kernel (front_body.h
 // gt_dec_front_kernel, where the design note is).  A translation unit of its own so that the two sets of instantiations compile
-// side by side.  The lean utterance path and the persistent decode launch do not know LSA: the decode loop then runs on the
-// launch path with this kernel as its first launch of every step.
+// side by side.  Which path an LSA model takes: fp32, <= 32 utterances and <= 128 tokens (gt_persist_decode_lsa_fits) run the
+// persistent decode launch, whose one-group chain carries the same two MFMA products (persist_decode.hip pd_chain_rest<.., LSA>,
+// bitwise this kernel); everything else -- more rows or tokens, mixed precision, several live contexts -- runs the launch path with
+// this kernel as the first launch of every step (the lean utterance path does not know LSA).
 #include "front_body.h"
 
 // without the prenet-0 pre-activations (step 0, or prenet-0 fusion off) the predicated variant, as for BMA / SMA (dec_front.hip front_launch2)

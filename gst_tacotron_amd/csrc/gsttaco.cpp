@@ -48,6 +48,8 @@ struct ConvLayer {
     float* wino_u = nullptr;    // Winograd F(2,5) transform of w, [6][wino_cin][Cout], for 5-tap layers (gemm_conv.hip)
     float* wino_u4 = nullptr;   // F(4,5): [8][wino_cin][Cout]
     int wino_cin = 0;
+    void *wino_s = nullptr, *wino_s4 = nullptr;     // the same U as three bf16 planes [xi][plane][wino_npad][wino_cin] (conv_wino_split.hip)
+    int wino_npad = 0;
     float* w = nullptr;     // [taps*Cin, Cout]
     float* scale = nullptr;
     float* shift = nullptr;
@@ -156,6 +158,8 @@ struct gsttaco_ctx {
     int proj_both_m = 0;         // projection launch at 17..32 rows: one workgroup per tile over both M-tiles (GSTTACO_PROJ_BOTH_M, debug builds)
     int wino = 4;                // Winograd for the 5-tap Conv1D layers that fill the chip: 4 = F(4,5) where its grid fills the chip and F(2,5)
                                  // otherwise, 2 = F(2,5) only, 0 = implicit GEMM only (GSTTACO_WINO)
+    bool wino_split = true;      // the Winograd layers' transform-domain GEMMs as split-bf16 x6 on the bf16 matrix pipe, fp32 accuracy
+                                 // (conv_wino_split.hip; GSTTACO_WINO_SPLIT=0: the fp32-MFMA Winograd kernel)
     bool bilstm_persist = true;  // one persistent launch per BiLSTM instead of one per time step (GSTTACO_BILSTM_PERSIST=0: per step)
     bool keep_hash = true;       // throughput mode: hashed keep decisions, dropped weight rows not requested (GSTTACO_DEBUG: KEEP_HASH=0)
     bool fuse12 = true;          // both decode LSTM cells in one launch with an in-kernel hand-off (GSTTACO_FUSED_LSTM=0: two launches)
@@ -531,6 +535,35 @@ int pack_linear(gsttaco_ctx* c, PackedLinear* out, const std::vector<std::pair<c
     return upload(c, &out->bias, bp.data(), bp.size());
 }
 
+// Split-bf16 planes of the Winograd-domain weights (conv_wino_split.hip): u = hi + mid + lo, each a bf16 rounded to nearest even from
+// what the planes before it left of the FLOAT64 transform (24 significand bits in all); layout [xi][plane][npad columns][wino_cin]
+// with k contiguous -- a B fragment of the bf16 MFMA is 8 consecutive k of one column.  Padding columns / channels are zero.
+int upload_wino_split(gsttaco_ctx* c, void** dst, const std::vector<double>& u, int al, int cin, int wino_cin, int cout, int npad) {
+    std::vector<uint16_t> planes((size_t)al * 3 * npad * wino_cin, 0);
+    auto bf = [](double v, uint16_t* bits) {       // rne(v) as bf16; returns the value it represents
+        const uint16_t b = bf16_bits((float)v);
+        *bits = b;
+        const uint32_t w = (uint32_t)b << 16;
+        float f;
+        memcpy(&f, &w, 4);
+        return (double)f;
+    };
+    for (int xi = 0; xi < al; ++xi)
+        for (int k = 0; k < cin; ++k)
+            for (int n = 0; n < cout; ++n) {
+                double v = u[((size_t)xi * cin + k) * cout + n];
+                for (int p = 0; p < 3; ++p) {
+                    uint16_t bits;
+                    v -= bf(v, &bits);
+                    planes[(((size_t)xi * 3 + p) * npad + n) * wino_cin + k] = bits;
+                }
+            }
+    int rc = dev_alloc(c, dst, planes.size() * 2);
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpy(*dst, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
     const HostTensor& k = T(c, prefix + ".kernel");
     L->taps = (int)k.shape[0];
@@ -554,13 +587,18 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
         L->wino_cin = std::max(128, (L->cin + 63) / 64 * 64);   // zero rows for the padding channels (an even number >= 4 of 32-channel slices)
         const size_t cnp = (size_t)L->wino_cin * L->cout;
         std::vector<float> u(6 * cnp, 0.f);
+        const bool split = c->wino_split && !c->cfg.mixed_precision;      // (mixed precision runs the bf16 five-tap kernel instead)
+        std::vector<double> ud(split ? 8 * cn : 0);
+        L->wino_npad = (L->cout + 127) / 128 * 128;
         for (int xi = 0; xi < 6; ++xi)
             for (size_t i = 0; i < cn; ++i) {
                 double acc = 0.0;
                 for (int tap = 0; tap < 5; ++tap) acc += G[xi][tap] * (double)k.data[(size_t)tap * cn + i];
                 u[xi * cnp + i] = (float)acc;
+                if (split) ud[xi * cn + i] = acc;
             }
         rc = upload(c, &L->wino_u, u.data(), u.size());
+        if (!rc && split) rc = upload_wino_split(c, &L->wino_s, ud, 6, L->cin, L->wino_cin, L->cout, L->wino_npad);
         if (!rc && c->wino >= 4) {
             // F(4,5), points 0, +-1, +-1/2, +-2, infinity
             static const double G4[8][5] = {{-1, 0, 0, 0, 0},
@@ -577,8 +615,10 @@ int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
                     double acc = 0.0;
                     for (int tap = 0; tap < 5; ++tap) acc += G4[xi][tap] * (double)k.data[(size_t)tap * cn + i];
                     u4[xi * cnp + i] = (float)acc;
+                    if (split) ud[xi * cn + i] = acc;
                 }
             rc = upload(c, &L->wino_u4, u4.data(), u4.size());
+            if (!rc && split) rc = upload_wino_split(c, &L->wino_s4, ud, 8, L->cin, L->wino_cin, L->cout, L->wino_npad);
         }
     }
     return rc;
@@ -1244,6 +1284,7 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
         ConvGemmArgs a{};
         a.x = x; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
         a.wino_u = L.wino_u; a.wino_u4 = L.wino_u4; a.wino_cin = L.wino_cin;
+        a.wino_s = L.wino_s; a.wino_s4 = L.wino_s4; a.wino_npad = L.wino_npad;
         a.out = last ? out : c->w_post[cur]; a.ldo = L.cout;
         a.res = last ? pre : nullptr;                       // post = postnet(x) + x (Taco2.py:230)
         a.B = B; a.T = Tf; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;
@@ -1711,6 +1752,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->gst_fork = std::min(2, std::max(0, env_int("GSTTACO_GST_FORK", 0)));
     c->wino = env_int("GSTTACO_WINO", 4);
     if (c->wino != 0 && c->wino != 2) c->wino = 4;      // {0, 2, 4}; any other non-zero value (the old boolean's 1 included) means the default
+    c->wino_split = env_int("GSTTACO_WINO_SPLIT", 1) != 0;
     c->stamps = env_int("GSTTACO_STAMPS", 0) == 1;
 #ifdef GSTTACO_DEBUG
     // experiment knobs, compiled only into -DGSTTACO_DEBUG builds (python -m gst_tacotron_amd.build --debug)
@@ -2125,6 +2167,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     HIPCHECK(c, gt_gst_init());
     HIPCHECK(c, gt_bilstm_persist_init());
     HIPCHECK(c, gt_conv5_bf16_init());
+    HIPCHECK(c, gt_conv_wino5s_init());
     HIPCHECK(c, gt_persist_decode_init());
     // the persistent BiLSTM's groups need their 32 members each on a CU of their own: exactly one workgroup per CU must fit
     if (c->bilstm_persist && gt_bilstm_persist_blocks_per_cu() != 1) {

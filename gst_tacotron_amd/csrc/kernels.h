@@ -202,6 +202,11 @@ struct ConvGemmArgs {
     const float* wino_u;    // F(2,5): [6][wino_cin][N]
     const float* wino_u4;   // F(4,5): [8][wino_cin][N], or NULL
     int wino_cin;           // rows of each U_xi: Cin rounded up to a multiple of 32 (zero rows for the padding)
+    // the same U as three bf16 planes (hi + mid + lo = the float64 transform to 2^-25), [xi][plane][wino_npad columns][wino_cin], k
+    // contiguous: the transform-domain GEMMs then run as split-bf16 x6 on the bf16 matrix pipe at fp32 accuracy (conv_wino_split.hip)
+    const void* wino_s;     // F(2,5), or NULL
+    const void* wino_s4;    // F(4,5), or NULL
+    int wino_npad;          // N rounded up to the kernel's 128-column block
     float* out;             // [B*T, ldo]
     int64_t ldo;
     int B, T, Cin, N, taps, pad_before, act;
@@ -213,6 +218,9 @@ struct ConvGemmArgs {
 
 hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
 hipError_t gt_conv5_bf16_init();           // opt in to >64 KiB dynamic LDS; call once outside stream capture
+// conv_wino_split.hip: the Winograd five-tap kernel on the bf16 pipe (split-bf16 x6); mo = 4 / 2 outputs per tile
+hipError_t gt_conv_wino5s_init();
+hipError_t gt_launch_conv_wino5s(const ConvGemmArgs& a, int mo, hipStream_t stream);
 // Highwaynet combine (reference Taco2.py:409-424): z [M, 2S] = [relu-branch | sigmoid-branch] pre-activations,
 // out = relu(z_h) * sigmoid(z_t) + x * (1 - sigmoid(z_t));  S % 4 == 0
 hipError_t gt_launch_highway(const float* z, const float* x, float* out, int64_t M, int S, hipStream_t stream);

@@ -213,7 +213,13 @@ def test_winograd_postnet_matches_the_oracle_and_the_implicit_gemm(monkeypatch):
     for B, T in ((8, 1024), (9, 999), (16, 1022)):
         x = np.clip(np.random.default_rng(T).normal(0, 1.5, (B, T, 80)), -4, 4).astype(np.float32)
         outs = {}
-        for name, env in (("F(4,5)|F(2,5)", {"GSTTACO_WINO": "4"}), ("F(2,5)", {"GSTTACO_WINO": "2"}), ("implicit GEMM", {"GSTTACO_WINO": "0"})):
+        # (round 6: the transform-domain GEMMs as split-bf16 x6 on the bf16 matrix pipe -- conv_wino_split.hip, the default -- and on the
+        # fp32 matrix pipe, GSTTACO_WINO_SPLIT=0: the same bar for both)
+        for name, env in (("F(4,5)|F(2,5) split-bf16 x6", {"GSTTACO_WINO": "4", "GSTTACO_WINO_SPLIT": "1"}),
+                          ("F(2,5) split-bf16 x6", {"GSTTACO_WINO": "2", "GSTTACO_WINO_SPLIT": "1"}),
+                          ("F(4,5)|F(2,5) fp32 MFMA", {"GSTTACO_WINO": "4", "GSTTACO_WINO_SPLIT": "0"}),
+                          ("F(2,5) fp32 MFMA", {"GSTTACO_WINO": "2", "GSTTACO_WINO_SPLIT": "0"}),
+                          ("implicit GEMM", {"GSTTACO_WINO": "0", "GSTTACO_WINO_SPLIT": "0"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             hpv = dict(hp); hpv["Max_Step"] = 1024
@@ -521,6 +527,9 @@ def test_persistent_decode_launch_under_a_foreign_gemm_stream():
     print("3 calls under a foreign GEMM stream: give-ups", gave_up, "persistent launches", m.decode_counters(), "seconds %.2f" % dt)
     assert gave_up <= 1 and dt < 60.0        # (after a give-up the context stays on the launch forms)
     assert m.handoff_error() == 0
+    # which form produced the results compared above: without a give-up every call replayed the ONE captured persistent launch and the
+    # context is still on it; after a give-up the context has left the persistent form (and nothing further was enqueued on it)
+    assert m.decode_counters() == ((1, 1) if gave_up == 0 else (1, 0)), (gave_up, m.decode_counters())
 
 
 def test_persistent_decode_launch_2000_steps_bitwise_the_launches(monkeypatch):
