@@ -315,6 +315,67 @@ def serving_throughput(hp, w, holder, tok, mels, lens, device_index, B, Tv, Tref
                     "resident weights); `value` is the better of the two".format(streams, B, streams, streams, B * streams)}
 
 
+def dry_run(args, overlap):
+    """``--dry-run``: the N-rank control flow of this file on CPU ranks -- the launcher environment (or the self-spawned ranks), a gloo
+    process group, ``gdist.run_steps`` with the chosen gather ordering around a stand-in for ``Inference_Step`` (a tensor that carries
+    its rank and step), the all-reduced give-up flag and the max-over-ranks clock -- and rank 0's line, flagged ``dry_run`` and
+    carrying NO measurement.  What it checks itself: the gathered batch holds every rank's rows in rank order for the LAST step, and
+    the order in which steps were enqueued and gathers claimed is the one the knob promises."""
+    rank, local_rank, world = gdist.init_process_group(backend="gloo")
+    B, frames, mel = 4, 6, 5
+    log = []
+
+    def one_step(i):
+        log.append(("enqueue", i))
+        out = torch.full((B, frames, mel), float(1000 * i + rank))
+
+        class Claim:
+            def __init__(self, pend):
+                self.pend = pend
+
+            def result(self):
+                log.append(("claim", i))
+                return self.pend.result()
+        return Claim(gdist.gather_to_root(out, n_total=B * world, async_op=True))
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    last = gdist.run_steps(args.steps, one_step, overlap_gather=overlap, first=args.warmup)
+    elapsed = time.perf_counter() - t0
+    want = []
+    for i in range(args.warmup, args.warmup + args.steps):
+        if overlap:
+            want += [("enqueue", i)] + ([("claim", i - 1)] if i > args.warmup else [])
+        else:
+            want += [("enqueue", i), ("claim", i)]
+    if overlap:
+        want.append(("claim", args.warmup + args.steps - 1))
+    assert log == want, (log, want)
+    if world > 1:
+        flag = torch.tensor([1 if (args.inject_give_up and rank == world - 1) else 0], dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        any_gave_up = bool(flag.item())
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    else:
+        any_gave_up = bool(args.inject_give_up)
+    if rank == 0:
+        i_last = args.warmup + args.steps - 1
+        assert tuple(last.shape) == (B * world, frames, mel)
+        for r in range(world):
+            assert bool((last[r * B:(r + 1) * B] == float(1000 * i_last + r)).all()), r
+        print(json.dumps({"metric": "mel-frames/s", "value": None, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "data": "none (CPU ranks, gloo, a stand-in for the model: control flow only)",
+                          "config": {"parallelism": "utterance-sharded x{} + final gather".format(world),
+                                     "gather": "overlapped" if overlap else "claimed before the next batch is enqueued"},
+                          "order": [list(e) for e in log], "fallback_taken": any_gave_up}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -328,6 +389,13 @@ def main():
                     "configuration; BASELINE configs[4] uses 64 with --mixed).  Any other value is NOT the headline metric")
     ap.add_argument("--inject-give-up", action="store_true", help="test hook: make the first timed run's in-kernel hand-off give up "
                     "(gsttaco_debug_raise_handoff_error), to exercise the discard-and-repeat path; the line then carries fallback_taken")
+    ap.add_argument("--overlap-gather", type=int, default=None, choices=(0, 1), help="N > 1: 1 = batch i's RCCL gather is claimed after batch i + 1 has "
+                    "been enqueued (the collective runs beside the next batch's compute); 0 = claimed before (the next batch's persistent decode "
+                    "launch can then never meet a resident receive kernel).  Default 0: nobody could measure N > 1 for this repo, so the default is "
+                    "the form that is safe by construction (gst_tacotron_amd.distributed.run_steps)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU ranks, gloo, a stand-in for the model: exercises the launcher, the process group, the "
+                    "step / gather ordering, the give-up all-reduce and the line's assembly without a GPU (tests/test_host.py); the line carries "
+                    "dry_run: true and no measurement")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="wall-time budget of the bounded CPU-baseline sample (both thread counts)")
     args = ap.parse_args()
 
@@ -340,6 +408,9 @@ def main():
     if env_world != args.gpus:
         raise SystemExit("bench.py: --gpus {} but the launcher's WORLD_SIZE is {}: refusing to print a line that would "
                          "misreport n_gpus".format(args.gpus, env_world))
+    overlap = bool(args.overlap_gather) if args.overlap_gather is not None else False
+    if args.dry_run:
+        return dry_run(args, overlap)
     if torch.cuda.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
     rank, local_rank, world = gdist.init_process_group(device_index=int(os.environ.get("LOCAL_RANK", "0")))
@@ -393,16 +464,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        pending = None
-        for i in range(args.steps):
-            if i == args.steps - 1:
+
+        def timed_step(i):
+            if i == args.warmup + args.steps - 1:
                 set_prof(True)
-            nxt = one_step(args.warmup + i)
-            if pending is not None:
-                pending.result()
-            pending = nxt
-        last = pending.result()                    # every gather has completed before the clock stops
-        torch.cuda.synchronize()
+            return one_step(i)
+        # (gather ordering: gdist.run_steps -- N > 1 claims batch i's gather before batch i + 1 is enqueued unless --overlap-gather 1)
+        last = gdist.run_steps(args.steps, timed_step, overlap_gather=overlap, first=args.warmup)
+        torch.cuda.synchronize()                   # every gather has completed before the clock stops
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
@@ -575,12 +644,20 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.mixed else "f32", "data": "synthetic",
+            # what the dtype's arithmetic runs on: since round 6 the fp32 path's Winograd-domain GEMMs (postnet, two encoder layers) run on the
+            # bf16 matrix pipe as split-bf16 x6 (three bf16 planes per fp32 operand, six plane products, fp32 accumulation: the fp32 MFMA
+            # chain's accuracy -- tools/split_bf16.hip, profiles/r06_split_bf16.txt); everything else of the fp32 path on fp32 MFMA / VALU
+            "arith": ("bf16 operands, fp32 accumulate (Use_Mixed_Precision)" if args.mixed else
+                      "fp32; five-tap Conv1D layers (postnet, encoder convs 2-3): Winograd-domain GEMMs as split-bf16 x6, fp32 accumulate"
+                      if os.environ.get("GSTTACO_WINO_SPLIT", "1") != "0" else "fp32"),
             "config": {"workload": ("" if args.batch_per_gpu == BATCH_PER_GPU and not args.mixed else "NOT THE HEADLINE CONFIGURATION -- ") +
                                    "BASELINE configs[1]: GST on, batch {} per GPU, 128-token utterances, ".format(args.batch_per_gpu) +
                                    "Step_Reduction 2, Max_Step 1000, LJSpeech 80-mel hparams; whole Inference_Step "
                                    "(encoder+GST+decode+postnet, vocoder excluded)",
                        "global_batch": n_total, "tokens": Tv, "ref_frames": Tref1 - 1,
-                       "parallelism": "utterance-sharded x{} + final RCCL gather".format(world)},
+                       "parallelism": "utterance-sharded x{} + final RCCL gather".format(world),
+                       "gather": ("none (one rank)" if world == 1 else "overlapped with the next batch's compute (--overlap-gather 1)" if overlap else
+                                  "claimed before the next batch is enqueued (safe by construction: a persistent decode launch never meets a resident receive kernel)")},
             "roofline": {"bound": step_bound, "kernel": KNAMES[dom],
                          "achieved": achieved, "peak": peak, "unit": unit, "frac": achieved / peak,
                          "frac_basis": ("measured live in this run: HIP event-record nodes inside the replayed graph around the ONE persistent launch of the last timed "
@@ -603,6 +680,7 @@ def main():
                                          "rows once in and once out" + (" ({:.2f} MB per step x {} steps per launch)".format(bytes1 / 1e6, n_steps_dec) if persistent else "")),
                          "end_to_end_frac": ideal_ms(model.dims, B, Tv, Tref1 - 1, args.mixed, n_steps_dec) / (1e3 * elapsed / args.steps),
                          "end_to_end_ideal_ms": ideal_ms(model.dims, B, Tv, Tref1 - 1, args.mixed, n_steps_dec),
+                         "bound_effective": "latency" if persistent else step_bound,
                          "limiter": ("dependent hand-offs and one CU's per-utterance chain (latency), not bytes: this launch keeps its weights in registers, "
                                      "so `frac` (algorithmic bytes, the contract's definition) overstates what the memory system does -- see "
                                      "persistent_decode.frac_compulsory and frac_traffic" if persistent else None),

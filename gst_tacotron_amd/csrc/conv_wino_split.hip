@@ -16,14 +16,29 @@
 // one accumulator tile per transform-domain GEMM, slice-major steps (xi, 32-channel slice) on two LDS stages with one barrier per step,
 // the next step's B planes and the next slice's raw taps in flight under the MFMAs, every load unconditional.
 // LDS per stage: A planes [3][64 rows][32 k + 8] bf16 (rows 80 bytes apart: the 32 rows of a fragment read hit all banks), B planes
-// [3][128 columns][32 k] bf16 with the four 16-byte chunks of a column XOR-swizzled by (column / 2) % 4 (unpadded, conflict-free both ways).
+// [3][128 columns][32 k] bf16 with the four 16-byte chunks of a column XOR-swizzled by (column / 8) % 4: a ds_read_b128 is served in four
+// groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- over 64 banks, and the column quads {0, 3, 5, 6} /
+// {1, 2, 4, 7} of a group then sit at four different chunk positions (unpadded, conflict-free for the reads and the 16-byte stores).
 #include "wino_common.h"
+#include <type_traits>
+
+// (ablation switches of tools/wino_split_bench.hip: -DWS_NO_MFMA, -DWS_NO_SPLIT; the product compiles the plain forms)
 
 namespace {
 
 constexpr int WS_BMP = 64, WS_BN = 128, WS_BK = 32, WS_LDA = WS_BK + 8;
 constexpr int WS_A_STAGE = 3 * WS_BMP * WS_LDA, WS_B_STAGE = 3 * WS_BN * WS_BK;      // bf16 elements
-constexpr int WS_LDS_BYTES = 2 * (WS_A_STAGE + WS_B_STAGE) * 2;
+constexpr int WS_LDS_BYTES = (2 * WS_A_STAGE + 3 * WS_B_STAGE) * 2;      // A: two stages; B: three (its planes are requested two steps ahead)
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+// 16 bytes per lane from a buffer straight into LDS: lane l's data lands at lds_addr + 16 l (lds_addr wave-uniform).  Inline asm, as in
+// gemm_conv.hip's five-tap bf16 kernel (through the builtin the compiler orders every later LDS read behind the DMA with a vmcnt(0));
+// the caller waits (s_waitcnt vmcnt(0)) and synchronises before the data is read.
+__device__ __forceinline__ void ws_lds_dma16(__amdgpu_buffer_rsrc_t rs, const uint32_t lds_addr, const uint32_t voff, const uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+#pragma clang diagnostic pop
 
 // v = hi + mid + lo (bf16 each, round to nearest even); the two remainders are exact in fp32
 __device__ __forceinline__ void ws_split(const float v, __bf16& h, __bf16& m, __bf16& l) {
@@ -39,7 +54,7 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     constexpr int AL = Wino<MO>::ALPHA;
     extern __shared__ __attribute__((aligned(16))) __bf16 ws_lds[];
     __bf16* As = ws_lds;                            // [2][3][64][WS_LDA]
-    __bf16* Bs = ws_lds + 2 * WS_A_STAGE;           // [2][3][128][32]
+    __bf16* Bs = ws_lds + 2 * WS_A_STAGE;           // [3][3][128][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int Pu = (A.T + MO - 1) / MO;                  // tiles per utterance
@@ -72,79 +87,124 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     const int nsl = A.wino_cin / WS_BK;                   // even, >= 4
     int cur = 0;
 
-    // this thread's piece of a step's B planes: column tid >> 2 of the 128, 16-byte chunk tid & 3 of its 32 k -- the same for every step
-    // and plane, so the per-thread offset is one register and (xi, plane, slice) ride in the scalar offset
+    // B planes of a step: straight from memory into LDS (buffer_load ... lds: no staging registers, no ds_write -- the 16-byte LDS stores
+    // of 24 KB per step were 300 cycles of the CU's store path).  A DMA instruction writes its 64 lanes' 16 bytes side by side = 16
+    // columns of one plane; wave w fills columns 16 w .. 16 w + 15 of each plane; lane l: column l / 4 of the sixteen, position l % 4, for
+    // which it FETCHES logical chunk (l % 4) ^ swizzle(column) -- the swizzle costs the DMA nothing and the fragment reads undo it.
     const auto rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Us), 0, (int)((size_t)AL * 3 * npad * A.wino_cin * 2), 0x00020000);
-    const int bcol = tid >> 2, bchk = tid & 3;
-    const uint32_t vb = (uint32_t)((((n0 + bcol) * A.wino_cin) + bchk * 8) * 2);
-    const int b_st = bcol * WS_BK + ((bchk ^ ((bcol >> 1) & 3)) * 8);           // element offset inside a plane of a stage
+    const int bcol = __builtin_amdgcn_readfirstlane(wave) * 16 + (lane >> 2);
+    const uint32_t vb = (uint32_t)((((n0 + bcol) * A.wino_cin) + (((lane & 3) ^ ((bcol >> 3) & 3)) * 8)) * 2);
+    const uint32_t lds_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Bs + (uint32_t)(__builtin_amdgcn_readfirstlane(wave) * 16 * WS_BK * 2);
     const int a_st = (tid >> 3) * WS_LDA + (tid & 7) * 4;
-    u32x4 bP[3];
-    auto issue_b = [&](const int xi, const int c0) {
+    auto dma_b = [&](const int st, const int xi, const int c0) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)vb, (int)((((size_t)(xi * 3 + p) * npad) * A.wino_cin + c0) * 2), 0);
-            __builtin_memcpy(&bP[p], &t, 16);
-        }
+        for (int p = 0; p < 3; ++p)
+            ws_lds_dma16(rs_u, lds_b + (uint32_t)((st * WS_B_STAGE + p * WS_BN * WS_BK) * 2), vb, (uint32_t)((((size_t)(xi * 3 + p) * npad) * A.wino_cin + c0) * 2));
     };
-    auto store_slice = [&](const int st, const float4 v) {
-        bf16x4 h, m, l;
-        const float ve[4] = {v.x, v.y, v.z, v.w};
+    // the NEXT step's A planes, in four pieces that are dealt between the current step's MFMAs below: transform of channels (0, 1) /
+    // (2, 3) of this thread's quad, split of each pair, one 8-byte store per plane
+    auto xform2 = [&](auto xi_c, auto half_c, const float4 (&d)[AL]) {
+        constexpr int XI = decltype(xi_c)::value, HALF = decltype(half_c)::value;
+        f32x2 v = {0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int tap = 0; tap < AL; ++tap) {
+            const float cf = Wino<MO>::bt(XI, tap);
+            if (cf != 0.f) v = __builtin_elementwise_fma((f32x2){cf, cf}, HALF ? (f32x2){d[tap].z, d[tap].w} : (f32x2){d[tap].x, d[tap].y}, v);
+        }
+        return v;
+    };
+    auto split2 = [&](const f32x2 v, bf16x2& h, bf16x2& m, bf16x2& l) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
             __bf16 he, me, le;
-            ws_split(ve[e], he, me, le);
+#ifdef WS_NO_SPLIT
+            he = (__bf16)v[e]; me = he; le = he;
+#else
+            ws_split(v[e], he, me, le);
+#endif
             h[e] = he; m[e] = me; l[e] = le;
         }
+    };
+    auto store_planes = [&](const int st, const bf16x2 (&h)[2], const bf16x2 (&m)[2], const bf16x2 (&l)[2]) {
         __bf16* as = As + st * WS_A_STAGE + a_st;
-        *reinterpret_cast<bf16x4*>(as) = h;
-        *reinterpret_cast<bf16x4*>(as + WS_BMP * WS_LDA) = m;
-        *reinterpret_cast<bf16x4*>(as + 2 * WS_BMP * WS_LDA) = l;
-        __bf16* bs = Bs + st * WS_B_STAGE + b_st;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(bs + p * WS_BN * WS_BK) = bP[p];
+        *reinterpret_cast<bf16x4*>(as) = bf16x4{h[0][0], h[0][1], h[1][0], h[1][1]};
+        *reinterpret_cast<bf16x4*>(as + WS_BMP * WS_LDA) = bf16x4{m[0][0], m[0][1], m[1][0], m[1][1]};
+        *reinterpret_cast<bf16x4*>(as + 2 * WS_BMP * WS_LDA) = bf16x4{l[0][0], l[0][1], l[1][0], l[1][1]};
     };
     // one step's products: per 16 k the three A and three B plane fragments, then hh, hm, mh, mm, hl, lh into the GEMM's accumulator
     const int a_rd = (wm * 32 + l31) * WS_LDA + kh * 8;
-    const int bc = wn * 32 + l31, b_sw = (bc >> 1) & 3;
-#define WS_MMA(ACC) do {                                                                                           \
-        const __bf16* ab_ = As + cur * WS_A_STAGE + a_rd;                                                          \
-        const __bf16* bb_ = Bs + cur * WS_B_STAGE + bc * WS_BK;                                                    \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                         \
-            bf16x8 a_[3], b_[3];                                                                                   \
-            _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                        \
-                a_[p] = *reinterpret_cast<const bf16x8*>(ab_ + p * WS_BMP * WS_LDA + ks * 16);                     \
-                b_[p] = *reinterpret_cast<const bf16x8*>(bb_ + p * WS_BN * WS_BK + (((2 * ks + kh) ^ b_sw) * 8));  \
-            }                                                                                                      \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[0], ACC, 0, 0, 0);                             \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[1], ACC, 0, 0, 0);                             \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], b_[0], ACC, 0, 0, 0);                             \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[1], b_[1], ACC, 0, 0, 0);                             \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[0], b_[2], ACC, 0, 0, 0);                             \
-            ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[2], b_[0], ACC, 0, 0, 0);                             \
-            if (ks == 0) __builtin_amdgcn_sched_barrier(0);                                                        \
-        }                                                                                                          \
-    } while (0)
+    const int bc = wn * 32 + l31, b_sw = (bc >> 3) & 3;
+#define WS_RD(ks, p, WHICH)                                                                                        \
+        do { if (WHICH & 1) a_[ks][p] = *reinterpret_cast<const bf16x8*>(ab_ + p * WS_BMP * WS_LDA + ks * 16);     \
+             if (WHICH & 2) b_[ks][p] = *reinterpret_cast<const bf16x8*>(bb_ + p * WS_BN * WS_BK + (((2 * ks + kh) ^ b_sw) * 8)); } while (0)
+#ifdef WS_NO_MFMA
+#define WS_MFMA(ACC, x, y) ACC[0] += (float)(x)[0] + (float)(y)[1]
+#else
+#define WS_MFMA(ACC, x, y) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, ACC, 0, 0, 0)
+#endif
+#define WS_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // The step as four fenced segments of three dependent MFMAs each (96 cycles of the matrix pipe) with a quarter of the NEXT step's
+    // transform + split (~10 vector instructions, independent of them) behind the segment's MFMAs: on the bf16 pipe a wave's vector
+    // instructions run under its own MFMAs (under fp32 MFMAs they do not: tools/mfma_rate.hip).  Left to the scheduler -- also with
+    // sched_group_barrier pipelines -- all of it lands behind the twelfth MFMA.
     float4 dE[AL], dO[AL];
-#define WS_STEP(XI, DCUR, DNXT, s_)                                                                                \
+#define WS_STEP(XI, DCUR, DNXT, DX, s_)                                                                            \
     {                                                                                                             \
         constexpr int XI1 = (XI + 1) % AL;                                                                         \
         /* (past the last step: a valid address whose data is never used) */                                      \
-        issue_b(XI1, min((s_) + (XI + 1 >= AL ? 1 : 0), nsl - 1) * WS_BK);                                         \
+        constexpr int XI2 = (XI + 2) % AL;                                                                         \
+        /* B planes of step g + 2 into the stage step g - 1 read (three stages: a step is ~0.5 us, shorter than an L2 round trip under */ \
+        /* load -- requested one step ahead, the wait at the end of every step exposed it: 169 us of the 253 per 512 -> 512 layer) */ \
+        dma_b(bnx, XI2, min((s_) + (XI + 2 >= AL ? 1 : 0), nsl - 1) * WS_BK);                                      \
         if constexpr (XI == 0) wino_issue_taps<MO>(A, rs_x, voff, first, len, min((s_) + 1, nsl - 1) * WS_BK, (s_) + 1 < nsl, DNXT); \
-        WS_MMA(M[XI]);                                                                                            \
-        if constexpr (XI + 1 < AL) store_slice(cur ^ 1, wino_xform<MO, XI1>(DCUR));                               \
-        else store_slice(cur ^ 1, wino_xform<MO, 0>(DNXT));                                                       \
+        const __bf16* ab_ = As + cur * WS_A_STAGE + a_rd;                                                          \
+        const __bf16* bb_ = Bs + bcur * WS_B_STAGE + bc * WS_BK;                                                   \
+        bf16x8 a_[2][3], b_[2][3];                                                                                 \
+        bf16x2 h_[2], m_[2], l_[2];                                                                                \
+        WS_RD(0, 0, 3); WS_RD(0, 1, 3); WS_RD(0, 2, 3);                                                            \
+        WS_FENCE();                                                                                               \
+        WS_MFMA(M[XI], a_[0][0], b_[0][0]); WS_MFMA(M[XI], a_[0][0], b_[0][1]); WS_MFMA(M[XI], a_[0][1], b_[0][0]); \
+        const f32x2 v0_ = xform2(std::integral_constant<int, XI1>{}, std::integral_constant<int, 0>{}, DX);        \
+        WS_FENCE();                                                                                               \
+        WS_MFMA(M[XI], a_[0][1], b_[0][1]); WS_MFMA(M[XI], a_[0][0], b_[0][2]); WS_MFMA(M[XI], a_[0][2], b_[0][0]); \
+        WS_RD(1, 0, 3); WS_RD(1, 1, 3);       /* (the second 16 k: the low planes a segment later -- 16 registers less at the peak) */ \
+        split2(v0_, h_[0], m_[0], l_[0]);                                                                          \
+        WS_FENCE();                                                                                               \
+        WS_MFMA(M[XI], a_[1][0], b_[1][0]); WS_MFMA(M[XI], a_[1][0], b_[1][1]); WS_MFMA(M[XI], a_[1][1], b_[1][0]); \
+        WS_RD(1, 2, 3);                                                                                            \
+        const f32x2 v1_ = xform2(std::integral_constant<int, XI1>{}, std::integral_constant<int, 1>{}, DX);        \
+        WS_FENCE();                                                                                               \
+        WS_MFMA(M[XI], a_[1][1], b_[1][1]); WS_MFMA(M[XI], a_[1][0], b_[1][2]); WS_MFMA(M[XI], a_[1][2], b_[1][0]); \
+        split2(v1_, h_[1], m_[1], l_[1]);                                                                          \
+        store_planes(cur ^ 1, h_, m_, l_);                                                                         \
+        WS_FENCE();                                                                                               \
+        /* the NEXT step's B planes have landed (requested a step ago; loads complete in order): what may still be in flight is this */ \
+        /* step's three DMAs and, at XI == 0 and 1, the next slice's AL tap loads requested behind XI == 0's DMAs */ \
+        if constexpr (XI <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + AL) : "memory");                      \
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                     \
         __syncthreads();                                                                                          \
         cur ^= 1;                                                                                                 \
+        bcur = bcur == 2 ? 0 : bcur + 1;                                                                           \
+        bnx = bnx == 2 ? 0 : bnx + 1;                                                                              \
     }
+    /* (DX: the tap set the NEXT step's transform reads -- this slice's until its last step, then the next slice's) */ \
+
 #define WS_SLICE(DCUR, DNXT, s_)                                                                                   \
-    WS_STEP(0, DCUR, DNXT, s_) WS_STEP(1, DCUR, DNXT, s_) WS_STEP(2, DCUR, DNXT, s_) WS_STEP(3, DCUR, DNXT, s_)   \
-    WS_STEP(4, DCUR, DNXT, s_) WS_STEP(5, DCUR, DNXT, s_)                                                          \
-    if constexpr (AL == 8) { WS_STEP(6 % AL, DCUR, DNXT, s_) WS_STEP(7 % AL, DCUR, DNXT, s_) }
+    WS_STEP(0, DCUR, DNXT, DCUR, s_) WS_STEP(1, DCUR, DNXT, DCUR, s_) WS_STEP(2, DCUR, DNXT, DCUR, s_) WS_STEP(3, DCUR, DNXT, DCUR, s_) \
+    WS_STEP(4, DCUR, DNXT, DCUR, s_)                                                                               \
+    if constexpr (AL == 8) { WS_STEP(5, DCUR, DNXT, DCUR, s_) WS_STEP(6 % AL, DCUR, DNXT, DCUR, s_) WS_STEP(7 % AL, DCUR, DNXT, DNXT, s_) } \
+    else { WS_STEP(5, DCUR, DNXT, DNXT, s_) }
     wino_issue_taps<MO>(A, rs_x, voff, first, len, 0, true, dE);
-    issue_b(0, 0);
-    store_slice(0, wino_xform<MO, 0>(dE));
+    dma_b(0, 0, 0);
+    dma_b(1, 1, 0);
+    int bcur = 0, bnx = 2;                  // B stage of the current step / of the step two ahead (scalar, cycling 0 1 2)
+    {
+        bf16x2 h_[2], m_[2], l_[2];
+        split2(xform2(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, dE), h_[0], m_[0], l_[0]);
+        split2(xform2(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, dE), h_[1], m_[1], l_[1]);
+        store_planes(0, h_, m_, l_);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int s = 0; s < nsl; s += 2) {
         WS_SLICE(dE, dO, s)
@@ -152,7 +212,9 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     }
 #undef WS_SLICE
 #undef WS_STEP
-#undef WS_MMA
+#undef WS_RD
+#undef WS_MFMA
+#undef WS_FENCE
 
     // epilogue (the fp32 kernel's); 32x32 C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); tile row -> MO output rows
     const int n = n0 + wn * 32 + l31;

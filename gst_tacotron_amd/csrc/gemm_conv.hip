@@ -884,7 +884,7 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         // worth it when the grid (nearly) fills the chip: the 4096-row encoder convs would leave half of it idle (one round of
         // 128 Winograd workgroups ~275 us against 136 us for the implicit GEMM); 250 workgroups (the 512 -> 80 layer) do pay.
         // F(4,5) where its (half as large) grid still does, else F(2,5).
-        constexpr int min_wgs = 240;
+        const int min_wgs = a.wino_min_wgs > 0 ? a.wino_min_wgs : 240;
         const int nb = (a.N + 127) / 128;
         const int P4 = a.B * ((a.T + 3) / 4), P2 = a.B * ((a.T + 1) / 2);
         // (1-D grids: 8 XCDs x ceil(row blocks / 8) x column blocks, see the kernel)

@@ -93,6 +93,12 @@ struct gsttaco_ctx {
     gsttaco_config cfg{};
     std::vector<HostTensor> tensors;
     std::map<std::string, int> index;
+    // Decoder sizes below the ones the persistent decode kernels are written for (prenet 256 / 256, attention 128, LSTM 1024 / 1024) are
+    // ZERO-PADDED up to them at finalize (pad_decoder): the padded copies of the decoder's tensors, consulted by T() in front of `tensors`
+    // (whose shapes stay the caller's: gsttaco_weight_info).  dims_true: the caller's P0, P1, att, H1, H2.
+    std::map<std::string, HostTensor> padded;
+    bool dec_padded = false;
+    int P0t = 0, P1t = 0, attt = 0, H1t = 0, H2t = 0;
     mutable std::string err;
     bool finalized = false;
     bool use_graph = true;
@@ -160,6 +166,8 @@ struct gsttaco_ctx {
                                  // otherwise, 2 = F(2,5) only, 0 = implicit GEMM only (GSTTACO_WINO)
     bool wino_split = true;      // the Winograd layers' transform-domain GEMMs as split-bf16 x6 on the bf16 matrix pipe, fp32 accuracy
                                  // (conv_wino_split.hip; GSTTACO_WINO_SPLIT=0: the fp32-MFMA Winograd kernel)
+    int enc_wino = 2;            // the text encoder's five-tap layers behind the token gather on the split-bf16 Winograd kernel (GSTTACO_ENC_WINO)
+    bool pad_dec = true;         // a decoder smaller than the reference's is zero-padded up to it (pad_decoder; GSTTACO_PAD_DECODER=0: its own sizes)
     bool bilstm_persist = true;  // one persistent launch per BiLSTM instead of one per time step (GSTTACO_BILSTM_PERSIST=0: per step)
     bool keep_hash = true;       // throughput mode: hashed keep decisions, dropped weight rows not requested (GSTTACO_DEBUG: KEEP_HASH=0)
     bool fuse12 = true;          // both decode LSTM cells in one launch with an in-kernel hand-off (GSTTACO_FUSED_LSTM=0: two launches)
@@ -389,7 +397,69 @@ void build_manifest(gsttaco_ctx* c) {
     }
 }
 
-const HostTensor& T(const gsttaco_ctx* c, const std::string& name) { return c->tensors[c->index.at(name)]; }
+const HostTensor& T(const gsttaco_ctx* c, const std::string& name) {
+    auto it = c->padded.find(name);
+    return it != c->padded.end() ? it->second : c->tensors[c->index.at(name)];
+}
+
+// A decoder smaller than the reference's (Taco2.py:61-89 builds every layer from hp_Dict: any prenet / attention / LSTM size) used to leave
+// every fast path at once -- the persistent decode kernels, the lean bodies and the fused front end are written for prenet 256 / 256,
+// attention 128, LSTM 1024 / 1024 -- and ran 40-65 % SLOWER than the larger reference model (profiles/r05c_other_sizes.txt).  Such a
+// model is now embedded in the reference-sized one with zeros, which is exact:
+//   * a padded prenet unit has zero weights and bias: relu(0) = 0, times any keep decision = 0; its outgoing rows are zero;
+//   * a padded attention channel has query = key = 0 and v = 0 (LSA: no v, tanh(0 + 0 + 0 + 0) = 0): it adds an exact 0 to every score,
+//     and its context column is 0 (zero Value column) with zero outgoing rows;
+//   * a padded LSTM unit has zero pre-activations: i = f = o = 1/2, c~ = 0, so c stays 0 and h = o tanh(0) = 0 for ever; zero outgoing rows.
+// Adding exact zeros changes no sum, so the result is the unpadded model's up to fp32 summation ORDER (the k-blocks regroup): the same
+// 5e-5 bar against the float64 oracle (tests/test_gpu_configs.py), not bitwise the unpadded launch path.  Cost: the small model runs at
+// the reference model's speed, not faster.  Row / column maps: TF layouts -- Dense kernels [in, out]; LSTM kernels [in, 4 units]
+// gate-major (i | f | c~ | o); LSTM 1's input is [prenet | context], the projection's [h2 | context].
+void pad_decoder(gsttaco_ctx* c) {
+    const int P0 = 256, P1 = 256, A = 128, H1 = 1024, H2 = 1024;
+    const int p0 = c->P0, p1 = c->P1, a = c->att, h1 = c->H1, h2 = c->H2;
+    c->P0t = p0; c->P1t = p1; c->attt = a; c->H1t = h1; c->H2t = h2;
+    if (!c->pad_dec || p0 > P0 || p1 > P1 || a > A || h1 > H1 || h2 > H2 || (p0 == P0 && p1 == P1 && a == A && h1 == H1 && h2 == H2)) return;
+    // dst[rmap(r)][cmap(cc)] = src[r][cc]
+    auto embed = [&](const std::string& name, int rows_out, int cols_out, auto rmap, auto cmap) {
+        const HostTensor& src = c->tensors[c->index.at(name)];
+        const int rows = src.shape.size() == 2 ? (int)src.shape[0] : 1, cols = (int)src.shape.back();
+        HostTensor t;
+        t.name = name; t.loaded = true;
+        t.shape = src.shape.size() == 2 ? std::vector<int64_t>{rows_out, cols_out} : std::vector<int64_t>{cols_out};
+        t.data.assign((size_t)rows_out * cols_out, 0.f);
+        for (int r = 0; r < rows; ++r)
+            for (int cc = 0; cc < cols; ++cc) t.data[(size_t)rmap(r) * cols_out + cmap(cc)] = src.data[(size_t)r * cols + cc];
+        c->padded[name] = std::move(t);
+    };
+    auto id = [](int i) { return i; };
+    auto gate = [](int h, int H) { return [h, H](int cc) { return (cc / h) * H + cc % h; }; };        // gate-major columns
+    auto cat = [](int n, int N) { return [n, N](int r) { return r < n ? r : N + (r - n); }; };        // [first | second] rows
+    const int mel = c->cfg.mel_dim;
+    embed("decoder.prenet0.kernel", mel, P0, id, id);
+    embed("decoder.prenet0.bias", 1, P0, id, id);
+    embed("decoder.prenet1.kernel", P0, P1, id, id);
+    embed("decoder.prenet1.bias", 1, P1, id, id);
+    embed("decoder.attention.query.kernel", P1, A, id, id);
+    embed("decoder.attention.query.bias", 1, A, id, id);
+    embed("decoder.attention.value.kernel", c->mem_dim, A, id, id);
+    embed("decoder.attention.value.bias", 1, A, id, id);
+    if (c->cfg.att_type == GSTTACO_ATT_LSA) {
+        embed("decoder.attention.location_dense.kernel", c->cfg.loc_filters, A, id, id);
+        embed("decoder.attention.location_dense.bias", 1, A, id, id);
+        embed("decoder.attention.bias", 1, A, id, id);
+    } else {
+        embed("decoder.attention.v", 1, A, id, id);
+    }
+    embed("decoder.lstm0.kernel", P1 + A, 4 * H1, cat(p1, P1), gate(h1, H1));
+    embed("decoder.lstm0.recurrent_kernel", H1, 4 * H1, id, gate(h1, H1));
+    embed("decoder.lstm0.bias", 1, 4 * H1, id, gate(h1, H1));
+    embed("decoder.lstm1.kernel", H1, 4 * H2, id, gate(h2, H2));
+    embed("decoder.lstm1.recurrent_kernel", H2, 4 * H2, id, gate(h2, H2));
+    embed("decoder.lstm1.bias", 1, 4 * H2, id, gate(h2, H2));
+    embed("decoder.projection.kernel", H2 + A, c->proj_out, cat(h2, H2), id);
+    c->P0 = P0; c->P1 = P1; c->att = A; c->H1 = H1; c->H2 = H2;
+    c->dec_padded = true;
+}
 
 int dev_alloc(gsttaco_ctx* c, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -776,6 +846,14 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
         a.pad_before = same_pad_before(Tv, L.taps, 1, nullptr);
         a.act = ACT_RELU;
         a.row_len = tlen;
+        // (round 6) the five-tap layers behind the token gather as Winograd on the bf16 pipe (conv_wino_split.hip): B x Tv = 4 096 rows are
+        // 128 workgroups of F(2,5) -- half the chip, where the fp32 Winograd kernel lost to the implicit GEMM (275 against 136 us) --
+        // enc_wino: 0 = implicit GEMM, 2 = F(2,5), 4 = F(4,5) where its grid reaches 60 workgroups
+        if (c->enc_wino && !tok && L.wino_s) {
+            a.wino_u = L.wino_u; a.wino_u4 = c->enc_wino == 4 ? L.wino_u4 : nullptr; a.wino_cin = L.wino_cin;
+            a.wino_s = L.wino_s; a.wino_s4 = c->enc_wino == 4 ? L.wino_s4 : nullptr; a.wino_npad = L.wino_npad;
+            a.wino_min_wgs = c->enc_wino == 4 ? 60 : 100;
+        }
         HIPCHECK(c, launch_conv(c, a, s));
         x = c->w_act[cur]; tok = nullptr; cur ^= 1;
     }
@@ -857,8 +935,8 @@ int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
         memset(&k, 0, sizeof(k));
         k.wp = c->val_gst.wp; k.bf16 = c->val_gst.bf16; k.bias = c->val_gst.bias;
         k.seg[0] = SkinnySeg{c->w_gst, g.gst_att, g.gst_att / 16, 0};
-        k.nkb = c->val_gst.nkb; k.M = B; k.N = g.att_size; k.n_split = g.att_size; k.MT = (B + 15) / 16;
-        k.out = c->w_rowbias; k.ldo = g.att_size;
+        k.nkb = c->val_gst.nkb; k.M = B; k.N = c->att; k.n_split = c->att; k.MT = (B + 15) / 16;
+        k.out = c->w_rowbias; k.ldo = c->att;
         HIPCHECK(c, launch_skinny(c, EPI_LINEAR, k, nullptr, c->val_gst.ntiles, s));
         rowbias = c->w_rowbias;
     }
@@ -866,8 +944,8 @@ int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
     a.x = c->w_enc; a.w = c->val_enc_w;
     a.shift = g.gst_use ? nullptr : c->val_bias;
     a.rowbias = rowbias;
-    a.out = c->w_pm; a.ldo = g.att_size;
-    a.B = B; a.T = Tv; a.Cin = c->enc_out; a.N = g.att_size; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
+    a.out = c->w_pm; a.ldo = c->att;
+    a.B = B; a.T = Tv; a.Cin = c->enc_out; a.N = c->att; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
     HIPCHECK(c, launch_conv(c, a, s));
     return 0;
 }
@@ -1753,6 +1831,9 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->wino = env_int("GSTTACO_WINO", 4);
     if (c->wino != 0 && c->wino != 2) c->wino = 4;      // {0, 2, 4}; any other non-zero value (the old boolean's 1 included) means the default
     c->wino_split = env_int("GSTTACO_WINO_SPLIT", 1) != 0;
+    c->enc_wino = env_int("GSTTACO_ENC_WINO", 2);
+    if (c->enc_wino != 0 && c->enc_wino != 4) c->enc_wino = 2;
+    c->pad_dec = env_int("GSTTACO_PAD_DECODER", 1) != 0;
     c->stamps = env_int("GSTTACO_STAMPS", 0) == 1;
 #ifdef GSTTACO_DEBUG
     // experiment knobs, compiled only into -DGSTTACO_DEBUG builds (python -m gst_tacotron_amd.build --debug)
@@ -1901,6 +1982,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         if ((rc = upload(c, &c->v_tok, vt.data(), vt.size()))) return rc;
     }
     // ---- decoder step
+    pad_decoder(c);
     {
         const HostTensor &k0 = T(c, "decoder.prenet0.kernel"), &b0 = T(c, "decoder.prenet0.bias");
         const HostTensor &k1 = T(c, "decoder.prenet1.kernel"), &b1 = T(c, "decoder.prenet1.bias");
@@ -1955,12 +2037,13 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
         for (int l = 0; l < 2; ++l) {
             std::string p = "decoder.lstm" + std::to_string(l);
             const HostTensor &k = T(c, p + ".kernel"), &u = T(c, p + ".recurrent_kernel"), &b = T(c, p + ".bias");
+            const int Hl = l == 0 ? c->H1 : c->H2;          // (the padded size where the decoder was padded)
             if ((rc = pack_linear(c, l == 0 ? &c->lstm0 : &c->lstm1,
                                   {{k.data.data(), (int)k.shape[0]}, {u.data.data(), (int)u.shape[0]}},
-                                  4 * g.dec_rnn[l], b.data.data(), g.dec_rnn[l]))) return rc;
+                                  4 * Hl, b.data.data(), Hl))) return rc;
             // split form: z = x.W_x + (h_prev.W_h + b); the second term is computed by the front kernel's workers
-            if ((rc = pack_linear(c, &c->lstm_x[l], {{k.data.data(), (int)k.shape[0]}}, 4 * g.dec_rnn[l], nullptr, g.dec_rnn[l]))) return rc;
-            if ((rc = pack_linear(c, &c->lstm_h[l], {{u.data.data(), (int)u.shape[0]}}, 4 * g.dec_rnn[l], b.data.data(), g.dec_rnn[l]))) return rc;
+            if ((rc = pack_linear(c, &c->lstm_x[l], {{k.data.data(), (int)k.shape[0]}}, 4 * Hl, nullptr, Hl))) return rc;
+            if ((rc = pack_linear(c, &c->lstm_h[l], {{u.data.data(), (int)u.shape[0]}}, 4 * Hl, b.data.data(), Hl))) return rc;
         }
         const HostTensor &pk = T(c, "decoder.projection.kernel"), &pb = T(c, "decoder.projection.bias");
         if ((rc = pack_linear(c, &c->proj, {{pk.data.data(), (int)pk.shape[0]}}, c->proj_out, pb.data.data(), 0))) return rc;
@@ -2184,6 +2267,7 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
     HIPCHECK(c, hipDeviceSynchronize());
     // host copies are no longer needed
     for (auto& t : c->tensors) std::vector<float>().swap(t.data);
+    c->padded.clear();
     c->finalized = true;
     return 0;
 }

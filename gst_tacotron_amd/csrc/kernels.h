@@ -207,6 +207,8 @@ struct ConvGemmArgs {
     const void* wino_s;     // F(2,5), or NULL
     const void* wino_s4;    // F(4,5), or NULL
     int wino_npad;          // N rounded up to the kernel's 128-column block
+    int wino_min_wgs;       // 0 = the default grid-fill rule (Winograd only where >= 240 workgroups); else the caller's threshold -- the
+                            // split-bf16 kernel also pays on the encoder's 4 096-row layers, whose F(2,5) grid is 128 workgroups
     float* out;             // [B*T, ldo]
     int64_t ldo;
     int B, T, Cin, N, taps, pad_before, act;

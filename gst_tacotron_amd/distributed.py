@@ -132,3 +132,30 @@ def gather_to_root(local, n_total=None, dst=0, async_op=False, force=False):
     if rank != dst:
         return None
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def run_steps(n_steps, one_step, overlap_gather=False, first=0):
+    """The multi-GPU step loop of ``bench.py``: ``one_step(i)`` enqueues batch ``i`` on this rank's stream and returns the
+    ``PendingGather`` of its output; returns the last batch's gathered result.
+
+    ``overlap_gather=False`` (the default for a world of more than one rank): batch ``i``'s gather is CLAIMED -- the compute stream
+    is made to wait for it -- before batch ``i + 1`` is enqueued.  The decode loop of a batch is one persistent launch of 256
+    workgroups that must all be resident (one per CU, 157 KB of LDS each); a collective's receive kernel still resident on rank 0
+    when that launch starts -- waiting for a late peer -- would keep one workgroup out until the bounded hand-off waits give up
+    (caught and repeated on the launch forms, but then every number is the slow path's).  With the claim in front, the launch is
+    stream-ordered behind the gather's completion, so the two can never be co-resident: safe by construction, at the cost of the
+    gather's ~0.1 ms per 11 ms batch that the overlapped form hides.
+    ``overlap_gather=True``: batch ``i``'s gather is claimed after batch ``i + 1`` has been enqueued (the collective runs on the
+    backend's stream beside the next batch's compute) -- the faster form where measurement shows the launches do not collide."""
+    last = pending = None
+    for i in range(n_steps):
+        nxt = one_step(first + i)
+        if not overlap_gather:
+            last = nxt.result()
+            continue
+        if pending is not None:
+            pending.result()
+        pending = nxt
+    if overlap_gather and pending is not None:
+        last = pending.result()
+    return last

@@ -291,3 +291,42 @@ def test_bench_prices_the_decode_step_at_the_surveys_bytes():
     assert abs(bench.ideal_ms(d, 32, 128, 256, False, 500) - 5.9) < 0.05
     comp = bench.persistent_compulsory_bytes(d, 32, 128, False, 500)
     assert w < comp < 500 * total / 50
+
+
+def test_run_steps_claims_each_gather_before_the_next_batch_unless_told_to_overlap():
+    """N > 1 default of bench.py (gst_tacotron_amd.distributed.run_steps): batch i's gather is claimed BEFORE batch i + 1 is enqueued,
+    so a persistent decode launch (256 workgroups that must all be resident) is stream-ordered behind the previous gather and can
+    never meet a resident receive kernel; --overlap-gather 1 keeps the round-5 form (claimed one batch later)."""
+    from gst_tacotron_amd.distributed import run_steps
+    for overlap, want in ((False, "e0 c0 e1 c1 e2 c2"), (True, "e0 e1 c0 e2 c1 c2")):
+        log = []
+
+        class P:
+            def __init__(self, i):
+                self.i = i
+
+            def result(self):
+                log.append("c%d" % self.i)
+                return self.i
+
+        def one_step(i):
+            log.append("e%d" % i)
+            return P(i)
+        assert run_steps(3, one_step, overlap_gather=overlap) == 2
+        assert " ".join(log) == want
+
+
+def test_bench_dry_run_on_two_cpu_ranks():
+    """`bench.py --gpus 2 --dry-run`: the self-spawned ranks, a gloo process group, the step / gather ordering, the all-reduced
+    give-up flag and rank 0's line -- without a GPU.  The default ordering is the safe one; the line says which was used."""
+    import json
+    for extra, gather, gave_up in (([], "claimed before the next batch is enqueued", False),
+                                   (["--overlap-gather", "1", "--inject-give-up"], "overlapped", True)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"] + extra,
+                           capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout            # ONE line, from rank 0
+        d = json.loads(lines[0])
+        assert d["dry_run"] is True and d["value"] is None and d["n_gpus"] == 2 and d["config"]["gather"] == gather
+        assert d["fallback_taken"] is gave_up       # (raised on the LAST rank only: rank 0 knows through the all-reduce)
