@@ -310,6 +310,33 @@ hipError_t gt_launch_zero(float* p, size_t n_floats, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Injected keep masks of a zero-padded decoder (gsttaco.cpp pad_decoder): the caller's [steps][B * p0 | B * p1] tensor re-laid out as the
+// padded model's [steps][B * P0 | B * P1].  Padding columns get 1: whatever they keep is an exact zero (never garbage: NaN * 0).
+// to_padded = 0: the other way round (gsttaco_debug_randomness hands back the caller's layout).
+__global__ __launch_bounds__(256) void gt_relayout_masks_kernel(const float* src, float* dst, int steps, int B, int p0, int p1, int P0, int P1, int to_padded) {
+    const int64_t per_big = (int64_t)B * (P0 + P1), per_small = (int64_t)B * (p0 + p1);
+    const int64_t n = (int64_t)steps * (to_padded ? per_big : per_small);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t per = to_padded ? per_big : per_small;
+        const int t = (int)(i / per);
+        const int64_t e = i - (int64_t)t * per;
+        const int W0 = to_padded ? P0 : p0, W1 = to_padded ? P1 : p1;
+        const bool second = e >= (int64_t)B * W0;
+        const int64_t r = second ? e - (int64_t)B * W0 : e;
+        const int W = second ? W1 : W0, b = (int)(r / W), col = (int)(r % W);
+        const int w_other = to_padded ? (second ? p1 : p0) : (second ? P1 : P0);
+        const int64_t base_other = (int64_t)t * (to_padded ? per_small : per_big) + (second ? (int64_t)B * (to_padded ? p0 : P0) : 0);
+        dst[i] = col < w_other ? src[base_other + (int64_t)b * w_other + col] : 1.f;
+    }
+}
+
+hipError_t gt_launch_relayout_masks(const float* src, float* dst, int steps, int B, int p0, int p1, int P0, int P1, int to_padded, hipStream_t stream) {
+    const int64_t n = (int64_t)steps * B * (to_padded ? P0 + P1 : p0 + p1);
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gt_relayout_masks_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, stream, src, dst, steps, B, p0, p1, P0, P1, to_padded);
+    return hipGetLastError();
+}
+
 hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream) {
     hipLaunchKernelGGL(gt_set_seed_kernel, dim3(1), dim3(1), 0, stream, dst, seed);
     return hipGetLastError();

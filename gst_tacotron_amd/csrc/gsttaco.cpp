@@ -2305,7 +2305,9 @@ int gsttaco_gst(gsttaco_ctx* c, const float* mels, const int32_t* lens, int B, i
 
 static int stage_randomness(gsttaco_ctx* c, hipStream_t s, const float* mask, const float* noise, uint64_t seed,
                             int B, int Tv, int steps) {
-    if (mask)
+    if (mask && c->dec_padded)      // (the caller's masks have the caller's prenet sizes: re-laid out for the padded model)
+        HIPCHECK(c, gt_launch_relayout_masks(mask, c->w_masks, steps, B, c->P0t, c->P1t, c->P0, c->P1, 1, s));
+    else if (mask)
         HIPCHECK(c, hipMemcpyAsync(c->w_masks, mask, (size_t)steps * B * (c->P0 + c->P1) * 4, hipMemcpyDeviceToDevice, s));
     if (noise)
         HIPCHECK(c, hipMemcpyAsync(c->w_noise, noise, (size_t)steps * B * Tv * 4, hipMemcpyDeviceToDevice, s));
@@ -2611,7 +2613,15 @@ int gsttaco_debug_randomness(gsttaco_ctx* c, float* host_masks, float* host_nois
         HIPCHECK(c, gt_launch_rng_fill(c->w_seed, c->w_masks, nullptr, steps, B, c->P0, c->P1, Tv, c->cfg.prenet_rate, nullptr));
         HIPCHECK(c, hipDeviceSynchronize());
     }
-    if (host_masks)
+    if (host_masks && c->dec_padded) {          // (in the caller's layout: the columns of the caller's prenet sizes)
+        float* tmp = nullptr;
+        const size_t n = (size_t)steps * B * (c->P0t + c->P1t);
+        HIPCHECK(c, hipMalloc((void**)&tmp, n * 4));
+        hipError_t e = gt_launch_relayout_masks(c->w_masks, tmp, steps, B, c->P0t, c->P1t, c->P0, c->P1, 0, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(host_masks, tmp, n * 4, hipMemcpyDeviceToHost);
+        (void)hipFree(tmp);
+        HIPCHECK(c, e);
+    } else if (host_masks)
         HIPCHECK(c, hipMemcpy(host_masks, c->w_masks, (size_t)steps * B * (c->P0 + c->P1) * 4, hipMemcpyDeviceToHost));
     if (host_noise) HIPCHECK(c, hipMemcpy(host_noise, c->w_noise, (size_t)steps * B * Tv * 4, hipMemcpyDeviceToHost));
     return 0;

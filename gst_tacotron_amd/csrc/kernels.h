@@ -255,6 +255,7 @@ hipError_t gt_attn_init();     // opt in to >64 KiB dynamic LDS; call once outsi
 hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream);
 hipError_t gt_launch_rng_fill(const uint64_t* seed_ptr, float* masks, float* noise, int steps, int B, int P0, int P1, int Tv,
                               float drop_rate, hipStream_t stream);
+hipError_t gt_launch_relayout_masks(const float* src, float* dst, int steps, int B, int p0, int p1, int P0, int P1, int to_padded, hipStream_t stream);
 hipError_t gt_launch_zero(float* p, size_t n_floats, hipStream_t stream);   // n rounded up to a multiple of 4 floats
 size_t gt_attn_lds_bytes(int Tv, int A, int loc_f, int loc_k, int* rows_lds);
 

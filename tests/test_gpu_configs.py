@@ -559,3 +559,61 @@ def test_persistent_decode_launch_2000_steps_bitwise_the_launches(monkeypatch):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
     assert not np.array_equal(outs["1"][0][0], outs["1"][1][0])                 # (the seeds did change the trajectories)
+
+
+@pytest.mark.parametrize("prenet,att,rnn,att_type", [([128, 128], 128, [1024, 1024], "SMA"), ([256, 256], 128, [512, 512], "BMA"),
+                                                     ([256, 256], 64, [1024, 1024], "SMA"), ([128, 128], 64, [512, 512], "SMA"),
+                                                     ([240, 112], 96, [768, 512], "BMA"), ([128, 128], 64, [512, 512], "LSA")])
+def test_smaller_decoders_take_the_persistent_launch_zero_padded(monkeypatch, prenet, att, rnn, att_type):
+    """The reference builds every decoder layer from hp_Dict (Taco2.py:61-89): any prenet / attention / LSTM size.  Sizes up to the
+    reference's 256 / 256, 128, 1024 / 1024 are zero-padded to them at finalize (gsttaco.cpp pad_decoder: exact -- padded units stay
+    zero) and so keep every fast path: the whole decode loop must run as ONE persistent launch (asserted), match the float64 oracle of
+    the UNPADDED model at the suite's 5e-5 with injected masks in the caller's layout, hand the caller's layout back from
+    ``debug_randomness``, and agree with the unpadded launch path (GSTTACO_PAD_DECODER=0) within the same bar."""
+    import gc
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    from oracle import oracle_np
+    hp = synthetic.config_hp("cfg2")
+    dec = hp["Tacotron2"]["Decoder"]
+    dec["Prenet"]["Size"] = list(prenet)
+    dec["Attention"] = {"Type": att_type, "Size": att}
+    if att_type == "LSA":
+        dec["Attention"]["Conv"] = {"Filters": 20, "Kernel_Size": 9}
+    dec["RNN"]["Size"] = list(rnn)
+    hp["Max_Step"] = 80
+    w = weights.synthetic_weights(hp, seed=21)
+    rng = np.random.default_rng(22)
+    B, Tv, Tref, steps = 5, 37, 90, 40
+    tokens, tl = synthetic.make_tokens(rng, B, Tv)
+    mels, ml = synthetic.make_ref_mels(rng, B, Tref)
+    if prenet[0] == prenet[1]:
+        masks, noise = synthetic.make_randomness(rng, steps, B, Tv, prenet)
+    else:       # (a stacked [steps, 2, B, P] tensor needs equal sizes: the flat layout [steps][B * P0 | B * P1] the C-ABI takes)
+        masks = (rng.random((steps, B * (prenet[0] + prenet[1]))) >= 0.5).astype(np.float32)
+        noise = rng.standard_normal((steps, B, Tv)).astype(np.float32)
+    outs = {}
+    for pad in ("1", "0"):
+        monkeypatch.setenv("GSTTACO_PAD_DECODER", pad)
+        gc.collect()
+        m = _model(hp, w, B, Tv, Tref + 1)
+        mel, stop, _, align = m.Inference_Step(tokens, None, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=steps)
+        m.synchronize()
+        n_persist, on = m.decode_counters()
+        if pad == "1":
+            assert on == 1 and n_persist >= 1, ("a smaller decoder did not take the persistent launch", n_persist, on, m.last_message())
+            if prenet[0] == prenet[1]:
+                back, _ = m.debug_randomness(steps, B, Tv)
+                assert np.array_equal(back, np.asarray(masks).reshape(back.shape))
+        else:
+            assert n_persist == 0
+        outs[pad] = (mel.cpu().numpy(), stop.cpu().numpy(), align.cpu().numpy())
+        del m
+    if prenet[0] == prenet[1]:
+        ref = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
+        errs = {k: float(np.abs(outs["1"][i] - ref[j]).max()) for k, i, j in (("mel", 0, 0), ("stop", 1, 1), ("align", 2, 3))}
+        print(prenet, att, rnn, att_type, "padded persistent launch vs the float64 oracle of the unpadded model:", errs)
+        assert max(errs.values()) <= TOL
+    d = [float(np.abs(a - b).max()) for a, b in zip(outs["1"], outs["0"])]
+    print(prenet, att, rnn, att_type, "padded persistent launch vs the unpadded launch path:", d)
+    assert max(d) <= TOL
