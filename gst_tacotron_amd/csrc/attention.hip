@@ -337,6 +337,26 @@ hipError_t gt_launch_relayout_masks(const float* src, float* dst, int steps, int
     return hipGetLastError();
 }
 
+// Embedding lookup as rows (Taco2.py:18-21): out[row] = table[tokens[row]], 16 bytes per thread.  The encoder's first convolution used to
+// resolve the lookup inside its im2col gather (implicit GEMM only); as rows in memory the layer can take the Winograd kernel on the bf16
+// pipe like the two behind it (4 096 rows x 512 channels: 8 MB written once, read back from L2).
+__global__ __launch_bounds__(256) void gt_embed_rows_kernel(const float4* __restrict__ table, const int32_t* __restrict__ tokens, float4* __restrict__ out, int rows, int c4) {
+    const int64_t n = (int64_t)rows * c4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / c4), q = (int)(i - (int64_t)r * c4);
+        out[i] = table[(int64_t)tokens[r] * c4 + q];
+    }
+}
+
+hipError_t gt_launch_embed_rows(const float* table, const int32_t* tokens, float* out, int rows, int C, hipStream_t stream) {
+    if (C & 3) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)rows * (C / 4);
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gt_embed_rows_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, stream, reinterpret_cast<const float4*>(table), tokens,
+                       reinterpret_cast<float4*>(out), rows, C / 4);
+    return hipGetLastError();
+}
+
 hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream) {
     hipLaunchKernelGGL(gt_set_seed_kernel, dim3(1), dim3(1), 0, stream, dst, seed);
     return hipGetLastError();

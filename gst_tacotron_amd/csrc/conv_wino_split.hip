@@ -246,10 +246,138 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------- plain GEMM, split-bf16 x6
+// out[M, N] = act(scale . (x[M, K] . W[K, N]) + shift + rowbias) for the path's tall plain GEMMs -- the BiLSTM's hoisted input halves
+// (4 096 x 512 x 2 048 at the headline shape: 109 us on the fp32 matrix pipe) and the attention's Value projection (Steps.py:123,
+// hoisted) -- on the bf16 pipe at fp32 accuracy, with the Winograd kernel's machinery minus its transforms: a workgroup = 64 rows x 128
+// columns, 8 waves as 2 x 4 MFMA tiles of 32 x 32, steps of 32 k.  Everything that comes from memory comes by LDS-DMA two steps ahead
+// (three-slot rings): the step's three W planes (24 KB, pre-split at finalize, [plane][n][k]) and the step's RAW fp32 x tile (8 KB);
+// a thread reads back the 16 bytes it fetched itself one step later (behind its own vmcnt wait: no barrier), splits them into the three
+// bf16 planes and stores those for the step after -- dealt between the current step's twelve MFMAs, as in the Winograd kernel.
+constexpr int GS_ARAW = WS_BMP * WS_BK;                                 // floats per raw x slot
+constexpr int GS_LDS_BYTES = 3 * GS_ARAW * 4 + (2 * WS_A_STAGE + 3 * WS_B_STAGE) * 2;
+
+__global__ __launch_bounds__(WT, 2) void gt_gemm_split_kernel(ConvGemmArgs A, const __bf16* __restrict__ Ws, const int npad) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 ws_lds[];
+    float* Ar = reinterpret_cast<float*>(ws_lds);                        // [3][64 rows][32 k] raw fp32
+    __bf16* As = ws_lds + 3 * GS_ARAW * 2;                                // [2][3 planes][64][WS_LDA]
+    __bf16* Bs = As + 2 * WS_A_STAGE;                                     // [3][3 planes][128][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int M = A.B * A.T, K = A.Cin;
+    const int ncb = (A.N + WS_BN - 1) / WS_BN;
+    const int wi = blockIdx.x >> 3;
+    const int rb = (wi / ncb) * 8 + (blockIdx.x & 7), cb = wi % ncb;
+    if (rb * WS_BMP >= M) return;
+    const int p0 = rb * WS_BMP, n0 = cb * WS_BN;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int nsl = K / WS_BK;
+    // x by DMA: wave w fetches rows 8 w .. 8 w + 7 of the tile (lane l: row l / 8, 16-byte chunk l % 8); rows past M get an out-of-range
+    // offset and land as zeros.  W planes as in the Winograd kernel (wave w: columns 16 w .. 16 w + 15 of each plane, chunks swizzled).
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x), 0, (int)((size_t)M * K * 4), 0x00020000);
+    const int xrow = p0 + wv * 8 + (lane >> 3);
+    const uint32_t vx = xrow < M ? (uint32_t)(((size_t)xrow * K + (lane & 7) * 4) * 4) : 0x80000000u;
+    const uint32_t lds_x = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Ar + (uint32_t)(wv * 8 * WS_BK * 4);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(Ws), 0, (int)((size_t)3 * npad * K * 2), 0x00020000);
+    const int bcol = wv * 16 + (lane >> 2);
+    const uint32_t vb = (uint32_t)((((n0 + bcol) * K) + (((lane & 3) ^ ((bcol >> 3) & 3)) * 8)) * 2);
+    const uint32_t lds_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Bs + (uint32_t)(wv * 16 * WS_BK * 2);
+    auto dma = [&](const int slot, const int c0) {
+        ws_lds_dma16(rs_x, lds_x + (uint32_t)(slot * GS_ARAW * 4), vx, (uint32_t)(c0 * 4));
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            ws_lds_dma16(rs_w, lds_b + (uint32_t)((slot * WS_B_STAGE + p * WS_BN * WS_BK) * 2), vb, (uint32_t)((((size_t)p * npad) * K + c0) * 2));
+    };
+    const int a_own = (wave * 8 + (lane >> 3)) * WS_BK + (lane & 7) * 4;           // this thread's 16 bytes of a raw slot (floats)
+    const int a_st = (tid >> 3) * WS_LDA + (tid & 7) * 4;                          // ... and of a plane (row tid / 8 = 8 wave + lane / 8)
+    const int a_rd = (wm * 32 + l31) * WS_LDA + kh * 8;
+    const int bc = wn * 32 + l31, b_sw = (bc >> 3) & 3;
+    auto split2 = [&](const float v0, const float v1, bf16x2& h, bf16x2& m, bf16x2& l) {
+        __bf16 he, me, le;
+        ws_split(v0, he, me, le); h[0] = he; m[0] = me; l[0] = le;
+        ws_split(v1, he, me, le); h[1] = he; m[1] = me; l[1] = le;
+    };
+    auto store_planes = [&](const int st, const bf16x2 (&h)[2], const bf16x2 (&m)[2], const bf16x2 (&l)[2]) {
+        __bf16* as = As + st * WS_A_STAGE + a_st;
+        *reinterpret_cast<bf16x4*>(as) = bf16x4{h[0][0], h[0][1], h[1][0], h[1][1]};
+        *reinterpret_cast<bf16x4*>(as + WS_BMP * WS_LDA) = bf16x4{m[0][0], m[0][1], m[1][0], m[1][1]};
+        *reinterpret_cast<bf16x4*>(as + 2 * WS_BMP * WS_LDA) = bf16x4{l[0][0], l[0][1], l[1][0], l[1][1]};
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    // prologue: steps 0 and 1 requested; step 0's x split
+    dma(0, 0);
+    dma(1, min(1, nsl - 1) * WS_BK);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    {
+        const float4 v = *reinterpret_cast<const float4*>(Ar + a_own);
+        bf16x2 h_[2], m_[2], l_[2];
+        split2(v.x, v.y, h_[0], m_[0], l_[0]);
+        split2(v.z, v.w, h_[1], m_[1], l_[1]);
+        store_planes(0, h_, m_, l_);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0, s3 = 0, s3n = 1, s3nn = 2;        // plane stage of the step; ring slots of steps s, s + 1, s + 2
+#define GS_RD(ks, p, WHICH)                                                                                        \
+        do { if (WHICH & 1) a_[ks][p] = *reinterpret_cast<const bf16x8*>(ab_ + p * WS_BMP * WS_LDA + ks * 16);     \
+             if (WHICH & 2) b_[ks][p] = *reinterpret_cast<const bf16x8*>(bb_ + p * WS_BN * WS_BK + (((2 * ks + kh) ^ b_sw) * 8)); } while (0)
+#define GS_MFMA(x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0)
+    for (int s = 0; s < nsl; ++s) {
+        dma(s3nn, min(s + 2, nsl - 1) * WS_BK);     // (past the end: a valid address whose data is never used)
+        const __bf16* ab_ = As + cur * WS_A_STAGE + a_rd;
+        const __bf16* bb_ = Bs + s3 * WS_B_STAGE + bc * WS_BK;
+        bf16x8 a_[2][3], b_[2][3];
+        bf16x2 h_[2], m_[2], l_[2];
+        GS_RD(0, 0, 3); GS_RD(0, 1, 3); GS_RD(0, 2, 3);
+        const float4 v = *reinterpret_cast<const float4*>(Ar + s3n * GS_ARAW + a_own);       // step s + 1's x: landed behind the last step's wait
+        __builtin_amdgcn_sched_barrier(0);
+        GS_MFMA(a_[0][0], b_[0][0]); GS_MFMA(a_[0][0], b_[0][1]); GS_MFMA(a_[0][1], b_[0][0]);
+        split2(v.x, v.y, h_[0], m_[0], l_[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        GS_MFMA(a_[0][1], b_[0][1]); GS_MFMA(a_[0][0], b_[0][2]); GS_MFMA(a_[0][2], b_[0][0]);
+        GS_RD(1, 0, 3); GS_RD(1, 1, 3);
+        split2(v.z, v.w, h_[1], m_[1], l_[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        GS_MFMA(a_[1][0], b_[1][0]); GS_MFMA(a_[1][0], b_[1][1]); GS_MFMA(a_[1][1], b_[1][0]);
+        GS_RD(1, 2, 3);
+        store_planes(cur ^ 1, h_, m_, l_);
+        __builtin_amdgcn_sched_barrier(0);
+        GS_MFMA(a_[1][1], b_[1][1]); GS_MFMA(a_[1][0], b_[1][2]); GS_MFMA(a_[1][2], b_[1][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // all but this step's four DMAs: the next step's x and W have landed
+        __syncthreads();
+        cur ^= 1;
+        const int t3 = s3; s3 = s3n; s3n = s3nn; s3nn = t3;
+    }
+#undef GS_RD
+#undef GS_MFMA
+    // epilogue; 32x32 C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int n = n0 + wn * 32 + l31;
+    if (n < A.N) {
+        const float sc = A.scale ? A.scale[n] : 1.f;
+        const float sh = A.shift ? A.shift[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = p0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (row >= M) continue;
+            float v = acc[e] * sc + sh;
+            if (A.rowbias) v += A.rowbias[(int64_t)(row / A.T) * A.N + n];
+            if (A.act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (A.act == ACT_TANH) v = gt_tanh(v);
+            if (A.res) v += A.res[(int64_t)row * A.ldo + n];
+            A.out[(int64_t)row * A.ldo + n] = v;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t gt_conv_wino5s_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv_wino5s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv_wino5s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv_wino5s_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
     return e;
 }
@@ -261,5 +389,19 @@ hipError_t gt_launch_conv_wino5s(const ConvGemmArgs& a, int mo, hipStream_t stre
     const dim3 grid(8 * (((P + WS_BMP - 1) / WS_BMP + 7) / 8) * nb);
     if (mo == 4) hipLaunchKernelGGL(gt_conv_wino5s_kernel<4>, grid, dim3(WT), WS_LDS_BYTES, stream, a, reinterpret_cast<const __bf16*>(a.wino_s4), a.wino_npad);
     else hipLaunchKernelGGL(gt_conv_wino5s_kernel<2>, grid, dim3(WT), WS_LDS_BYTES, stream, a, reinterpret_cast<const __bf16*>(a.wino_s), a.wino_npad);
+    return hipGetLastError();
+}
+
+// plain GEMM (taps == 1, no gather): a.gemm_s = the W planes [3][a.wino_npad][Cin]; Cin a multiple of 32, >= 64
+bool gt_gemm_split_applies(const ConvGemmArgs& a) {
+    return a.gemm_s && a.taps == 1 && !a.tokens && !a.row_len && !a.pool2 && !a.conv2d && !a.wt_bf16 && a.Cin % WS_BK == 0 && a.Cin >= 2 * WS_BK &&
+           (size_t)a.B * a.T * a.Cin * 4 < 0x7FFFFFFFull && a.wino_npad >= (a.N + WS_BN - 1) / WS_BN * WS_BN;
+}
+
+hipError_t gt_launch_gemm_split(const ConvGemmArgs& a, hipStream_t stream) {
+    const int nb = (a.N + WS_BN - 1) / WS_BN;
+    const int M = a.B * a.T;
+    const dim3 grid(8 * (((M + WS_BMP - 1) / WS_BMP + 7) / 8) * nb);
+    hipLaunchKernelGGL(gt_gemm_split_kernel, grid, dim3(WT), GS_LDS_BYTES, stream, a, reinterpret_cast<const __bf16*>(a.gemm_s), a.wino_npad);
     return hipGetLastError();
 }

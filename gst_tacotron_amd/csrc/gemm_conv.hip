@@ -880,6 +880,7 @@ hipError_t gt_launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 #undef GT_CG_LAUNCH
         return hipGetLastError();
     }
+    if (gt_gemm_split_applies(a) && ((M + 63) / 64) * ((a.N + 127) / 128) >= 48) return gt_launch_gemm_split(a, stream);
     if (gt_conv_wino5_applies(a)) {
         // worth it when the grid (nearly) fills the chip: the 4096-row encoder convs would leave half of it idle (one round of
         // 128 Winograd workgroups ~275 us against 136 us for the implicit GEMM); 250 workgroups (the 512 -> 80 layer) do pay.

@@ -130,9 +130,10 @@ struct gsttaco_ctx {
     struct LeanBiLstm {
         PackedLinear h[2];
         float *xw = nullptr, *xb = nullptr;         // [C, 2*4H], [2*4H]
+        void* xw_s = nullptr; int xw_npad = 0;      // xw as three bf16 planes (the hoisted GEMM on the bf16 pipe, split-bf16 x6)
         float *z = nullptr, *hb[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-        float* ph = nullptr;                        // persistent kernel: [8 groups][2 parities] blocked state of 16 rows
-        uint32_t* pflags = nullptr;                 // persistent kernel: [8 groups][2 parities][32] publish tags + [8] member counters
+        float* ph = nullptr;                        // persistent kernel: [8 groups][3 slots] blocked state of 16 rows, tagged in bit 30
+        uint32_t* pflags = nullptr;                 // persistent kernel: [8] member counters (right behind ph)
         int H = 0, C = 0;
     } enc_lean, voc_lean;
     struct { float *w, *scale, *shift; int k, cin, cout, stride; } ref_conv[GSTTACO_MAX_LAYERS]{};
@@ -186,6 +187,7 @@ struct gsttaco_ctx {
     int z_col0 = 0;
     float* w_z0 = nullptr;
     float *val_enc_w = nullptr, *val_bias = nullptr, *att_v = nullptr, *att_sb = nullptr;
+    void* val_enc_s = nullptr; int val_enc_npad = 0;        // val_enc_w as three bf16 planes (split-bf16 x6 GEMM)
     float *loc_cw = nullptr, *loc_cb = nullptr, *loc_dw = nullptr, *loc_db = nullptr, *att_bias = nullptr;   // LSA extension
     float* loc_pack = nullptr;          // the same as the fused front end's LDS image (kernels.h LsaPack)
     float* w_lsa_state = nullptr;
@@ -634,6 +636,29 @@ int upload_wino_split(gsttaco_ctx* c, void** dst, const std::vector<double>& u, 
     return 0;
 }
 
+// the same for a plain GEMM's weights w [K, N] (row stride ldw): [plane][npad][K], k contiguous (conv_wino_split.hip gt_gemm_split_kernel)
+int upload_gemm_split(gsttaco_ctx* c, void** dst, const float* w, int K, int N, int ldw, int* npad_out) {
+    const int npad = (N + 127) / 128 * 128;
+    std::vector<uint16_t> planes((size_t)3 * npad * K, 0);
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) {
+            float v = w[(size_t)k * ldw + n];
+            for (int p = 0; p < 3; ++p) {
+                const uint16_t b = bf16_bits(v);
+                const uint32_t u = (uint32_t)b << 16;
+                float f;
+                memcpy(&f, &u, 4);
+                v -= f;                                          // (exact: the remainder of a round-to-nearest to 8 bits)
+                planes[((size_t)p * npad + n) * K + k] = b;
+            }
+        }
+    int rc = dev_alloc(c, dst, planes.size() * 2);
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpy(*dst, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+    *npad_out = npad;
+    return 0;
+}
+
 int upload_conv(gsttaco_ctx* c, ConvLayer* L, const std::string& prefix) {
     const HostTensor& k = T(c, prefix + ".kernel");
     L->taps = (int)k.shape[0];
@@ -747,6 +772,7 @@ int build_lean_bilstm(gsttaco_ctx* c, gsttaco_ctx::LeanBiLstm* L, const std::str
     }
     if ((rc = upload(c, &L->xw, xw.data(), xw.size()))) return rc;
     if ((rc = add_bf16(c, L->xw, xw.data(), C, 8 * H, 8 * H))) return rc;
+    if (c->wino_split && !c->cfg.mixed_precision && C % 32 == 0 && (rc = upload_gemm_split(c, &L->xw_s, xw.data(), C, 8 * H, 8 * H, &L->xw_npad))) return rc;
     if ((rc = upload(c, &L->xb, xb.data(), xb.size()))) return rc;
     L->H = H; L->C = C;
     return 0;
@@ -760,8 +786,9 @@ int alloc_lean_bilstm(gsttaco_ctx* c, gsttaco_ctx::LeanBiLstm* L, size_t B, size
         for (int q = 0; q < 2; ++q)
             if ((rc = dev_alloc(c, (void**)&L->hb[d][q], ((B + 15) / 16) * 16 * L->H * sizeof(float)))) return rc;
     if (gt_bilstm_persist_supported(L->H, 1, c->n_cu)) {        // used for calls of up to 64 utterances (8 groups)
-        if ((rc = dev_alloc(c, (void**)&L->ph, (size_t)8 * 2 * 16 * L->H * sizeof(float)))) return rc;
-        if ((rc = dev_alloc(c, (void**)&L->pflags, (size_t)(8 * 2 * 32 + 8) * sizeof(uint32_t)))) return rc;
+        // [8 groups][3 slots] of tagged state + the 8 member counters right behind it (one zero-fill per launch covers both)
+        if ((rc = dev_alloc(c, (void**)&L->ph, ((size_t)8 * 3 * 16 * L->H + 8) * sizeof(float)))) return rc;
+        L->pflags = reinterpret_cast<uint32_t*>(L->ph + (size_t)8 * 3 * 16 * L->H);
     }
     return 0;
 }
@@ -780,6 +807,7 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
     a.x = x; a.w = L.xw; a.shift = L.xb;
     a.out = L.z; a.ldo = 8 * H;
     a.B = B; a.T = Tn; a.Cin = L.C; a.N = 8 * H; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
+    a.gemm_s = L.xw_s; a.wino_npad = L.xw_npad;         // (round 6: on the bf16 matrix pipe as split-bf16 x6 where the grid allows)
     if (c->enc_part != 2) HIPCHECK(c, launch_conv(c, a, s));
     if (c->enc_part == 1) return 0;
     // One persistent launch for the whole sequence, one (direction, 16 utterances) group per XCD (skinny_gemm.hip
@@ -789,7 +817,7 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
         // different utterances are independent, so the slabs simply follow each other on the stream
         for (int r0 = 0; r0 < B; r0 += 64) {
             const int Bs = std::min(64, B - r0);
-            HIPCHECK(c, gt_launch_zero(reinterpret_cast<float*>(L.pflags), (size_t)8 * 2 * 32 + 8, s));
+            HIPCHECK(c, gt_launch_zero(L.ph, (size_t)8 * 3 * 16 * H + 8, s));        // (tagged state: tag 0 = never written; + the member counters)
             BiLstmPersistArgs k{};
             k.wp[0] = L.h[0].wp; k.wp[1] = L.h[1].wp;
             k.ldz = (int64_t)Tn * 8 * H; k.ldo = (int64_t)Tn * EO;
@@ -836,6 +864,13 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
         const int rg = enqueue_gst(c, c->side_stream, B, gst_Tref1);
         if (rg) return rg;
         HIPCHECK(c, hipEventRecord(c->ev_join, c->side_stream));
+    }
+    // (round 6) the embedding lookup as rows in memory when the first convolution can then take the Winograd kernel on the bf16 pipe
+    // (it resolves the lookup inside its gather only as an implicit GEMM: 140 us against ~90 for lookup + Winograd at 4 096 rows)
+    if (c->enc_part != 2 && g.n_enc_conv > 0 && c->enc_wino && c->enc_conv[0].wino_s && tok && c->enc_conv[0].cin == g.emb &&
+        (B * ((Tv + 1) / 2) + 63) / 64 * ((c->enc_conv[0].cout + 127) / 128) >= 100) {
+        HIPCHECK(c, gt_launch_embed_rows(c->d_emb, tok, c->w_act[1], B * Tv, g.emb, s));
+        x = c->w_act[1]; tok = nullptr;
     }
     for (int i = 0; i < g.n_enc_conv && c->enc_part != 2; ++i) {
         const ConvLayer& L = c->enc_conv[i];
@@ -945,7 +980,8 @@ int enqueue_value_proj(gsttaco_ctx* c, hipStream_t s, int B, int Tv) {
     a.shift = g.gst_use ? nullptr : c->val_bias;
     a.rowbias = rowbias;
     a.out = c->w_pm; a.ldo = c->att;
-    a.B = B; a.T = Tv; a.Cin = c->enc_out; a.N = c->att; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
+    a.B = B; a.T = Tv; a.gemm_s = c->val_enc_s; a.wino_npad = c->val_enc_npad;
+    a.Cin = c->enc_out; a.N = c->att; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
     HIPCHECK(c, launch_conv(c, a, s));
     return 0;
 }
@@ -2002,6 +2038,8 @@ int gsttaco_finalize_weights(gsttaco_ctx* c) {
             if ((rc = pack_linear(c, &c->val_gst, {{vk.data.data(), g.gst_att}}, c->att, vb.data.data(), 0))) return rc;
         if ((rc = upload(c, &c->val_enc_w, vk.data.data() + (size_t)goff * c->att, (size_t)c->enc_out * c->att))) return rc;
         if ((rc = add_bf16(c, c->val_enc_w, vk.data.data() + (size_t)goff * c->att, c->enc_out, c->att, c->att))) return rc;
+        if (c->wino_split && !g.mixed_precision && c->enc_out % 32 == 0 &&
+            (rc = upload_gemm_split(c, &c->val_enc_s, vk.data.data() + (size_t)goff * c->att, c->enc_out, c->att, c->att, &c->val_enc_npad))) return rc;
         if ((rc = upload(c, &c->val_bias, vb.data.data(), vb.data.size()))) return rc;
         if (g.att_type == GSTTACO_ATT_LSA) {
             auto up = [&](float** dst, const char* name) {

@@ -142,8 +142,9 @@ struct BiLstmPersistArgs {
     const float* wp[2];         // packed W_h per direction [H/4 tiles][H/16][64][4] (bf16 pack [tiles][H/32][64][8] in mixed precision)
     const float* zx;            // hoisted input halves: (row, time tt, direction d, tile, col) at zx[row*ldz + tt*8H + d*4H + tile*16 + col]
     float* out;                 // (row, tt, d, unit) at out[row*ldo + tt*2H + d*H + unit]
-    float* h;                   // workspace [8 groups][2 parities][H/16][64][4]: blocked state of the group's 16 rows
-    uint32_t* flags;            // workspace [8 groups][2 parities][32 members] + [8] member counters, zeroed before the launch
+    float* h;                   // workspace [8 groups][3 slots][H/16][64][4]: blocked state of the group's 16 rows, each word tagged in bit 30;
+                                // ZEROED before the launch (tag 0 = never written)
+    uint32_t* flags;            // [8] member counters, zeroed before the launch (the words right behind `h`: one zero-fill for both)
     const int32_t* row_len;     // masked-mode extension (A12) or NULL
     uint32_t* err;              // host-mapped; bit 0: a wait gave up (every member then leaves the launch)
     int64_t ldz, ldo;
@@ -207,6 +208,8 @@ struct ConvGemmArgs {
     const void* wino_s;     // F(2,5), or NULL
     const void* wino_s4;    // F(4,5), or NULL
     int wino_npad;          // N rounded up to the kernel's 128-column block
+    const void* gemm_s;     // taps == 1: W itself as three bf16 planes [plane][wino_npad][Cin], k contiguous -> the plain split-bf16 GEMM
+                            // (conv_wino_split.hip gt_gemm_split_kernel), or NULL
     int wino_min_wgs;       // 0 = the default grid-fill rule (Winograd only where >= 240 workgroups); else the caller's threshold -- the
                             // split-bf16 kernel also pays on the encoder's 4 096-row layers, whose F(2,5) grid is 128 workgroups
     float* out;             // [B*T, ldo]
@@ -223,6 +226,8 @@ hipError_t gt_conv5_bf16_init();           // opt in to >64 KiB dynamic LDS; cal
 // conv_wino_split.hip: the Winograd five-tap kernel on the bf16 pipe (split-bf16 x6); mo = 4 / 2 outputs per tile
 hipError_t gt_conv_wino5s_init();
 hipError_t gt_launch_conv_wino5s(const ConvGemmArgs& a, int mo, hipStream_t stream);
+bool gt_gemm_split_applies(const ConvGemmArgs& a);
+hipError_t gt_launch_gemm_split(const ConvGemmArgs& a, hipStream_t stream);
 // Highwaynet combine (reference Taco2.py:409-424): z [M, 2S] = [relu-branch | sigmoid-branch] pre-activations,
 // out = relu(z_h) * sigmoid(z_t) + x * (1 - sigmoid(z_t));  S % 4 == 0
 hipError_t gt_launch_highway(const float* z, const float* x, float* out, int64_t M, int S, hipStream_t stream);
@@ -256,6 +261,7 @@ hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream);
 hipError_t gt_launch_rng_fill(const uint64_t* seed_ptr, float* masks, float* noise, int steps, int B, int P0, int P1, int Tv,
                               float drop_rate, hipStream_t stream);
 hipError_t gt_launch_relayout_masks(const float* src, float* dst, int steps, int B, int p0, int p1, int P0, int P1, int to_padded, hipStream_t stream);
+hipError_t gt_launch_embed_rows(const float* table, const int32_t* tokens, float* out, int rows, int C, hipStream_t stream);
 hipError_t gt_launch_zero(float* p, size_t n_floats, hipStream_t stream);   // n rounded up to a multiple of 4 floats
 size_t gt_attn_lds_bytes(int Tv, int A, int loc_f, int loc_k, int* rows_lds);
 

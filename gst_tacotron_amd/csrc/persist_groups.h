@@ -354,7 +354,10 @@ __device__ __forceinline__ void pd_g_run_proj(const PersistDecodeArgs& A, float*
         PD_PHASE_ABORT(sh);
 #pragma unroll
         for (int g = 0; g < GM; ++g)
-            if (g < A.G) pd_proj<true>(A, wpj, t, ptile, MTG * g + pm, lds, sh, g);
+            // (an M-tile past the batch's last -- 33..48 rows: group 1's second -- does not exist: its fragment would be read one block
+            // past the END of the state buffers, harmless (its rows are never stored) until the buffer is the last of a mapping: round 6
+            // met that layout as a memory fault at 40 rows.  The workgroup skips the tile; the condition is uniform.)
+            if (g < A.G && MTG * g + pm < A.MT) pd_proj<true>(A, wpj, t, ptile, MTG * g + pm, lds, sh, g);
         if (t + 1 == A.steps) break;
         pd_load_tile<8>(A.w2h, tile, W.h2);
         PD_PIN();

@@ -687,11 +687,17 @@ __global__ __launch_bounds__(NW * 64) void gt_bilstm_lean_kernel(BiLstmArgs A) {
 // have nothing to do and arrivals beyond the 32nd exit at once.  (Nothing is assumed about blockIdx -> XCD except that
 // every XCD receives at least 32 of the 512.)
 //
-// Hand-off per step inside a group: the 128 owner lanes store h_t into the group's blocked 16 KiB state (parity t & 1), every
-// storing wave drains (vmcnt(0)), workgroup barrier, one lane stores the member's flag (= t + 1, tags only grow; zeroed before
-// the launch); every wave polls the group's 32 flags itself (sc1 loads, one per lane) and then loads its two k-blocks of the
-// state with sc1 loads.  A member can only overwrite the parity of step t - 2 once all members have published t - 1, i.e.
-// have finished reading t - 2.  Waits are bounded (error word instead of a hung GPU).
+// Hand-off per step inside a group (round 6: the state carries its own validity, no flags): |h| < 1, so bit 30 of an h word -- the top
+// exponent bit, set only from 2.0 up -- is free.  The owner lanes store h_t with a TAG in that bit into slot t % 3 of the group's blocked
+// state (plain 4-byte stores: the XCD's L2 is coherent for its own CUs), and that is all a producer does: no drain, no barrier, no flag.
+// A consumer wave polls its two k-blocks of the state ITSELF (two 16-byte sc1 loads per lane) until all eight words of every lane show
+// the tag of the step it waits for, and strips it: ONE L2 round trip per step where the flag form took two (poll the 32 flags, then
+// fetch the state) plus the producers' store acknowledgement and a barrier -- 1.9 -> see DESIGN 3.5 us per time step.  Tags: slot s is written
+// at steps s, s + 3, s + 6, ... with tag ((t / 3) & 1) ^ 1 (the launch starts from a zeroed state: tag 0 = "never written"), so what a
+// slot held before differs in the tag.  Three slots, not two: a member overwrites slot t % 3 at step t + 3, for which it needs step
+// t + 2 of its four source members, who needed step t + 1 of EVERY member, who had therefore all finished reading step t (with two
+// slots nothing orders a producer behind a reader it does not depend on).  The LDS partial sums alternate between two buffers by step
+// parity, so the one barrier per step (spill -> reduce) also orders their re-use.  Waits are bounded (error word instead of a hung GPU).
 //
 // Arithmetic = gt_bilstm_lean_kernel<8, 2>'s exactly (k-block kb on wave kb % 8, ascending; partial sums added over waves in
 // ascending order after the hoisted input half): bitwise equal outputs, which is what the GPU test checks.
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const int g = (int)(xcc & 7);
     if (g >= 2 * A.MT) return;
-    if (tid == 0) { s_slot = (int)atomicAdd(A.flags + 8 * 2 * NM + g, 1u); s_abort = 0; }
+    if (tid == 0) { s_slot = (int)atomicAdd(A.flags + g, 1u); s_abort = 0; }
     __syncthreads();
     const int rank = s_slot;
     if (rank >= NM) return;
@@ -751,13 +757,14 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
             for (int j = 0; j < NT; ++j)
                 b[i][j] = (reinterpret_cast<const float4*>(A.wp[d]) + ((size_t)(tile0 + j) * (NW * KPW) + wave + i * NW) * 64)[lane];
     }
-    float* hbuf = A.h + (size_t)g * 2 * 16 * H;                     // [2 parities][H/16 k-blocks][64 lanes][4]
-    uint32_t* fl = A.flags + (size_t)g * 2 * NM;                   // [2 parities][32 members]
+    float* hbuf = A.h + (size_t)g * 3 * 16 * H;                     // [3 slots][H/16 k-blocks][64 lanes][4]
     // (rows beyond M read the group's first row, which exists, and are never used: no load under a branch, no wait at its join)
     const float* zrow = A.zx + (size_t)(real ? grow : mt * 16) * A.ldz + (size_t)d * 4 * H + (tile0 + j_own) * 16 + col;
     float c_state = 0.f;
     float pin = zrow[(size_t)(d == 0 ? 0 : A.T - 1) * 8 * H];
     const int n_valid = (A.row_len && real) ? A.row_len[grow] : A.T;       // masked mode: steps tt >= n_valid do not exist for this row
+    int slot_w = 0, slot_r = 2;                                    // slot this step writes (t % 3) / reads ((t - 1) % 3)
+    uint32_t tag_w = 1u << 30, tag_r = 0u;                         // ... and their tags
     for (int t = 0; t < A.T; ++t) {
         const int tt = d == 0 ? t : A.T - 1 - t;
         float4 x[KPW];
@@ -765,22 +772,36 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
 #pragma unroll
             for (int i = 0; i < KPW; ++i) x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            const int par = (t - 1) & 1;
-            const uint32_t want = (uint32_t)t;                     // step t - 1 publishes tag t
             // Bounded wait.  A member that gives up raises the (host-mapped) error word; every waiting wave of every group looks
             // at that word now and then, so the WHOLE launch drains within microseconds of the first give-up instead of every
             // remaining time step spinning its full bound again.  The workgroup leaves together behind its next barrier.
+            const float* hp = hbuf + (size_t)slot_r * 16 * H + lane * 4;
+            const float* p0 = BF16 ? hp + (size_t)(2 * wave) * 256 : hp + (size_t)wave * 256;
+            const float* p1 = BF16 ? hp + (size_t)(2 * wave + 1) * 256 : hp + (size_t)(wave + NW) * 256;
             uint32_t spins = 0;
             for (;;) {
-                const uint32_t v = lane < NM ? gt_ldu_sc1(fl + par * NM + lane) : want;
-                if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(v >= want))) == 64) break;
+                gt_ld2x4_sc1(p0, p1, x[0], x[1]);
+                const uint32_t all = __builtin_bit_cast(uint32_t, x[0].x) & __builtin_bit_cast(uint32_t, x[0].y) & __builtin_bit_cast(uint32_t, x[0].z) &
+                                     __builtin_bit_cast(uint32_t, x[0].w) & __builtin_bit_cast(uint32_t, x[1].x) & __builtin_bit_cast(uint32_t, x[1].y) &
+                                     __builtin_bit_cast(uint32_t, x[1].z) & __builtin_bit_cast(uint32_t, x[1].w);
+                const uint32_t any = __builtin_bit_cast(uint32_t, x[0].x) | __builtin_bit_cast(uint32_t, x[0].y) | __builtin_bit_cast(uint32_t, x[0].z) |
+                                     __builtin_bit_cast(uint32_t, x[0].w) | __builtin_bit_cast(uint32_t, x[1].x) | __builtin_bit_cast(uint32_t, x[1].y) |
+                                     __builtin_bit_cast(uint32_t, x[1].z) | __builtin_bit_cast(uint32_t, x[1].w);
+                // every word carries the wanted tag: all of them set (tag 1) / none of them set (tag 0)
+                const bool ok = tag_r ? (all & (1u << 30)) != 0u : (any & (1u << 30)) == 0u;
+                if (__builtin_amdgcn_readfirstlane(__popcll(__ballot(ok))) == 64) break;
                 ++spins;
                 if (spins > (1u << 18)) { if (lane == 0) { atomicOr(A.err, 1u); s_abort = 1; } break; }
                 if ((spins & 63u) == 0u && __builtin_amdgcn_readfirstlane(gt_ldu_sc1(A.err)) != 0u) { if (lane == 0) s_abort = 1; break; }
             }
-            const float* hp = hbuf + (size_t)par * 16 * H + lane * 4;
-            if constexpr (BF16) gt_ld2x4_sc1(hp + (size_t)(2 * wave) * 256, hp + (size_t)(2 * wave + 1) * 256, x[0], x[1]);
-            else gt_ld2x4_sc1(hp + (size_t)wave * 256, hp + (size_t)(wave + NW) * 256, x[0], x[1]);
+            const uint32_t keep = ~(1u << 30);
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                x[i].x = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x[i].x) & keep);
+                x[i].y = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x[i].y) & keep);
+                x[i].z = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x[i].z) & keep);
+                x[i].w = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x[i].w) & keep);
+            }
         }
         // the next step's hoisted input half: requested now, needed after the next wait
         const float cur = pin;
@@ -810,18 +831,19 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[i].w, b[i][j].w, acc[j], 0, 0, 0);
                 }
         }
+        float (*pt)[NT][16][17] = part + (t & 1) * NW;              // (two buffers by step parity: the one barrier below orders their re-use)
         {   // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
             const int r = lane & 15, q = lane >> 4;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) part[wave][j][q * 4 + v][r] = acc[j][v];
+                for (int v = 0; v < 4; ++v) pt[wave][j][q * 4 + v][r] = acc[j][v];
         }
         __syncthreads();
         if (s_abort) return;                                        // (uniform: written before the barrier)
         float z = cur;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) z += part[w][j_own][row][col];
+        for (int w = 0; w < NW; ++w) z += pt[w][j_own][row][col];
         const float zf = gt_row_down<4>(z), zg = gt_row_down<8>(z), zo = gt_row_down<12>(z);
         float hv = 0.f;
         if (owner && real && tt < n_valid) {
@@ -829,14 +851,12 @@ __global__ __launch_bounds__(512) void gt_bilstm_persist_kernel(BiLstmPersistArg
             c_state = __builtin_fmaf(gf, c_state, gi * gg);
             hv = go * gt_tanh(c_state);
         }
-        // (the encoding first: its acknowledgement is then waited for together with the state's)
+        // the state first (somebody waits for it), tagged; then the encoding
+        if (owner && t + 1 < A.T)
+            reinterpret_cast<uint32_t*>(hbuf)[(size_t)slot_w * 16 * H + gt_blk_off(row, unit, 1)] = __builtin_bit_cast(uint32_t, hv) | tag_w;
         if (owner && real) A.out[(size_t)grow * A.ldo + (size_t)tt * 2 * H + (size_t)d * H + unit] = hv;
-        if (t + 1 < A.T) {
-            if (owner) hbuf[(size_t)(t & 1) * 16 * H + gt_blk_off(row, unit, 1)] = hv;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's part of h_t is in the L2
-            __syncthreads();                                        // ... every wave's; and the LDS partials have been read
-            if (tid == 0) fl[(t & 1) * NM + rank] = (uint32_t)(t + 1);
-        }
+        slot_r = slot_w; tag_r = tag_w;
+        if (slot_w == 2) { slot_w = 0; tag_w ^= 1u << 30; } else ++slot_w;
     }
 }
 
