@@ -357,6 +357,38 @@ hipError_t gt_launch_embed_rows(const float* table, const int32_t* tokens, float
     return hipGetLastError();
 }
 
+// Several device-to-device copies (and the call's seed) as ONE launch: gsttaco_inference_step stages its inputs into the workspace the
+// cached graphs read and its outputs out of the one they write -- as three hipMemcpyAsync + a seed kernel in front of the graphs and
+// three behind them that was seven dependent ~5 us boundaries per call for ~20 MB of copies the chip moves in a few microseconds.
+__global__ __launch_bounds__(256) void gt_copy_segments_kernel(GtCopySegs S) {
+    if (S.seed_dst && blockIdx.x == 0 && threadIdx.x == 0) *S.seed_dst = S.seed;
+    for (int k = 0; k < S.n; ++k) {
+        const size_t n = S.words[k];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(S.src[k]);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(S.dst[k]);
+        if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+            const size_t n4 = n >> 2;
+            const uint4* s4 = reinterpret_cast<const uint4*>(src);
+            uint4* d4 = reinterpret_cast<uint4*>(dst);
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) d4[i] = s4[i];
+            for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+        } else {
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+        }
+    }
+}
+
+hipError_t gt_launch_copy_segments(const GtCopySegs& S, hipStream_t stream) {
+    size_t total = 0;
+    for (int k = 0; k < S.n; ++k) total += S.words[k];
+    if (total == 0 && !S.seed_dst) return hipSuccess;
+    size_t blocks = (total / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gt_copy_segments_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, S);
+    return hipGetLastError();
+}
+
 hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream) {
     hipLaunchKernelGGL(gt_set_seed_kernel, dim3(1), dim3(1), 0, stream, dst, seed);
     return hipGetLastError();

@@ -147,20 +147,12 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     // transform + split (~10 vector instructions, independent of them) behind the segment's MFMAs: on the bf16 pipe a wave's vector
     // instructions run under its own MFMAs (under fp32 MFMAs they do not: tools/mfma_rate.hip).  Left to the scheduler -- also with
     // sched_group_barrier pipelines -- all of it lands behind the twelfth MFMA.
-    float4 dE[AL], dO[AL];
-#define WS_STEP(XI, DCUR, DNXT, DX, s_)                                                                            \
-    {                                                                                                             \
-        constexpr int XI1 = (XI + 1) % AL;                                                                         \
-        /* (past the last step: a valid address whose data is never used) */                                      \
-        constexpr int XI2 = (XI + 2) % AL;                                                                         \
-        /* B planes of step g + 2 into the stage step g - 1 read (three stages: a step is ~0.5 us, shorter than an L2 round trip under */ \
-        /* load -- requested one step ahead, the wait at the end of every step exposed it: 169 us of the 253 per 512 -> 512 layer) */ \
-        dma_b(bnx, XI2, min((s_) + (XI + 2 >= AL ? 1 : 0), nsl - 1) * WS_BK);                                      \
-        if constexpr (XI == 0) wino_issue_taps<MO>(A, rs_x, voff, first, len, min((s_) + 1, nsl - 1) * WS_BK, (s_) + 1 < nsl, DNXT); \
-        const __bf16* ab_ = As + cur * WS_A_STAGE + a_rd;                                                          \
-        const __bf16* bb_ = Bs + bcur * WS_B_STAGE + bc * WS_BK;                                                   \
-        bf16x8 a_[2][3], b_[2][3];                                                                                 \
-        bf16x2 h_[2], m_[2], l_[2];                                                                                \
+#ifndef WS_STAGGER
+#define WS_STAGGER 0
+#endif
+    // WS_STAGGER (experiment, tools/wino_split_bench.hip): the two waves that share a SIMD (w and w + 4) run the step's two halves in
+    // opposite order -- waves 0-3 MFMAs first, waves 4-7 transform + split + store first -- instead of both interleaving them
+#define WS_BODY_INTERLEAVED(XI, XI1, DX)                                                                           \
         WS_RD(0, 0, 3); WS_RD(0, 1, 3); WS_RD(0, 2, 3);                                                            \
         WS_FENCE();                                                                                               \
         WS_MFMA(M[XI], a_[0][0], b_[0][0]); WS_MFMA(M[XI], a_[0][0], b_[0][1]); WS_MFMA(M[XI], a_[0][1], b_[0][0]); \
@@ -177,7 +169,41 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
         WS_MFMA(M[XI], a_[1][1], b_[1][1]); WS_MFMA(M[XI], a_[1][0], b_[1][2]); WS_MFMA(M[XI], a_[1][2], b_[1][0]); \
         split2(v1_, h_[1], m_[1], l_[1]);                                                                          \
         store_planes(cur ^ 1, h_, m_, l_);                                                                         \
-        WS_FENCE();                                                                                               \
+        WS_FENCE();
+#define WS_ALL_MFMA(XI)                                                                                            \
+        WS_RD(0, 0, 3); WS_RD(0, 1, 3); WS_RD(0, 2, 3); WS_RD(1, 0, 3); WS_RD(1, 1, 3);                            \
+        WS_MFMA(M[XI], a_[0][0], b_[0][0]); WS_MFMA(M[XI], a_[0][0], b_[0][1]); WS_MFMA(M[XI], a_[0][1], b_[0][0]); \
+        WS_MFMA(M[XI], a_[0][1], b_[0][1]); WS_MFMA(M[XI], a_[0][0], b_[0][2]); WS_MFMA(M[XI], a_[0][2], b_[0][0]); \
+        WS_RD(1, 2, 3);                                                                                            \
+        WS_MFMA(M[XI], a_[1][0], b_[1][0]); WS_MFMA(M[XI], a_[1][0], b_[1][1]); WS_MFMA(M[XI], a_[1][1], b_[1][0]); \
+        WS_MFMA(M[XI], a_[1][1], b_[1][1]); WS_MFMA(M[XI], a_[1][0], b_[1][2]); WS_MFMA(M[XI], a_[1][2], b_[1][0]);
+#define WS_ALL_XFORM(XI1, DX)                                                                                      \
+        split2(xform2(std::integral_constant<int, XI1>{}, std::integral_constant<int, 0>{}, DX), h_[0], m_[0], l_[0]); \
+        split2(xform2(std::integral_constant<int, XI1>{}, std::integral_constant<int, 1>{}, DX), h_[1], m_[1], l_[1]); \
+        store_planes(cur ^ 1, h_, m_, l_);
+#if WS_STAGGER
+#define WS_BODY(XI, XI1, DX)                                                                                       \
+        if (__builtin_amdgcn_readfirstlane(wave) < 4) { WS_ALL_MFMA(XI) WS_FENCE(); WS_ALL_XFORM(XI1, DX) }        \
+        else { WS_ALL_XFORM(XI1, DX) WS_FENCE(); WS_ALL_MFMA(XI) }                                                 \
+        WS_FENCE();
+#else
+#define WS_BODY(XI, XI1, DX) WS_BODY_INTERLEAVED(XI, XI1, DX)
+#endif
+    float4 dE[AL], dO[AL];
+#define WS_STEP(XI, DCUR, DNXT, DX, s_)                                                                            \
+    {                                                                                                             \
+        constexpr int XI1 = (XI + 1) % AL;                                                                         \
+        /* (past the last step: a valid address whose data is never used) */                                      \
+        constexpr int XI2 = (XI + 2) % AL;                                                                         \
+        /* B planes of step g + 2 into the stage step g - 1 read (three stages: a step is ~0.5 us, shorter than an L2 round trip under */ \
+        /* load -- requested one step ahead, the wait at the end of every step exposed it: 169 us of the 253 per 512 -> 512 layer) */ \
+        dma_b(bnx, XI2, min((s_) + (XI + 2 >= AL ? 1 : 0), nsl - 1) * WS_BK);                                      \
+        if constexpr (XI == 0) wino_issue_taps<MO>(A, rs_x, voff, first, len, min((s_) + 1, nsl - 1) * WS_BK, (s_) + 1 < nsl, DNXT); \
+        const __bf16* ab_ = As + cur * WS_A_STAGE + a_rd;                                                          \
+        const __bf16* bb_ = Bs + bcur * WS_B_STAGE + bc * WS_BK;                                                   \
+        bf16x8 a_[2][3], b_[2][3];                                                                                 \
+        bf16x2 h_[2], m_[2], l_[2];                                                                                \
+        WS_BODY(XI, XI1, DX)                                                                                       \
         /* the NEXT step's B planes have landed (requested a step ago; loads complete in order): what may still be in flight is this */ \
         /* step's three DMAs and, at XI == 0 and 1, the next slice's AL tap loads requested behind XI == 0's DMAs */ \
         if constexpr (XI <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + AL) : "memory");                      \
@@ -212,6 +238,10 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     }
 #undef WS_SLICE
 #undef WS_STEP
+#undef WS_BODY
+#undef WS_BODY_INTERLEAVED
+#undef WS_ALL_MFMA
+#undef WS_ALL_XFORM
 #undef WS_RD
 #undef WS_MFMA
 #undef WS_FENCE
@@ -250,17 +280,20 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
 // out[M, N] = act(scale . (x[M, K] . W[K, N]) + shift + rowbias) for the path's tall plain GEMMs -- the BiLSTM's hoisted input halves
 // (4 096 x 512 x 2 048 at the headline shape: 109 us on the fp32 matrix pipe) and the attention's Value projection (Steps.py:123,
 // hoisted) -- on the bf16 pipe at fp32 accuracy, with the Winograd kernel's machinery minus its transforms: a workgroup = 64 rows x 128
-// columns, 8 waves as 2 x 4 MFMA tiles of 32 x 32, steps of 32 k.  Everything that comes from memory comes by LDS-DMA two steps ahead
-// (three-slot rings): the step's three W planes (24 KB, pre-split at finalize, [plane][n][k]) and the step's RAW fp32 x tile (8 KB);
-// a thread reads back the 16 bytes it fetched itself one step later (behind its own vmcnt wait: no barrier), splits them into the three
-// bf16 planes and stores those for the step after -- dealt between the current step's twelve MFMAs, as in the Winograd kernel.
+// columns, 8 waves as 2 x 4 MFMA tiles of 32 x 32, steps of 32 k.  Everything that comes from memory comes by LDS-DMA: the step's three
+// W planes (24 KB, pre-split at finalize, [plane][n][k]) two steps ahead into a three-slot ring, and the step's RAW fp32 x tile (8 KB)
+// THREE steps ahead into a four-slot ring -- a thread reads back the 16 bytes it fetched itself (behind its own vmcnt wait: no barrier)
+// one step BEFORE the step they belong to, splits them into the three bf16 planes and stores those for that step, dealt between the
+// current step's twelve MFMAs as in the Winograd kernel.  (The end-of-step wait leaves exactly the step's own four DMAs in flight, so
+// what it guarantees is everything requested a step earlier: x at distance two was read while possibly still on its way -- one call
+// in sixteen differed under four contexts on four streams.)
 constexpr int GS_ARAW = WS_BMP * WS_BK;                                 // floats per raw x slot
-constexpr int GS_LDS_BYTES = 3 * GS_ARAW * 4 + (2 * WS_A_STAGE + 3 * WS_B_STAGE) * 2;
+constexpr int GS_LDS_BYTES = 4 * GS_ARAW * 4 + (2 * WS_A_STAGE + 3 * WS_B_STAGE) * 2;
 
 __global__ __launch_bounds__(WT, 2) void gt_gemm_split_kernel(ConvGemmArgs A, const __bf16* __restrict__ Ws, const int npad) {
     extern __shared__ __attribute__((aligned(16))) __bf16 ws_lds[];
-    float* Ar = reinterpret_cast<float*>(ws_lds);                        // [3][64 rows][32 k] raw fp32
-    __bf16* As = ws_lds + 3 * GS_ARAW * 2;                                // [2][3 planes][64][WS_LDA]
+    float* Ar = reinterpret_cast<float*>(ws_lds);                        // [4][64 rows][32 k] raw fp32
+    __bf16* As = ws_lds + 4 * GS_ARAW * 2;                                // [2][3 planes][64][WS_LDA]
     __bf16* Bs = As + 2 * WS_A_STAGE;                                     // [3][3 planes][128][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -283,8 +316,8 @@ __global__ __launch_bounds__(WT, 2) void gt_gemm_split_kernel(ConvGemmArgs A, co
     const int bcol = wv * 16 + (lane >> 2);
     const uint32_t vb = (uint32_t)((((n0 + bcol) * K) + (((lane & 3) ^ ((bcol >> 3) & 3)) * 8)) * 2);
     const uint32_t lds_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Bs + (uint32_t)(wv * 16 * WS_BK * 2);
-    auto dma = [&](const int slot, const int c0) {
-        ws_lds_dma16(rs_x, lds_x + (uint32_t)(slot * GS_ARAW * 4), vx, (uint32_t)(c0 * 4));
+    auto dma_x = [&](const int slot, const int c0) { ws_lds_dma16(rs_x, lds_x + (uint32_t)(slot * GS_ARAW * 4), vx, (uint32_t)(c0 * 4)); };
+    auto dma_b = [&](const int slot, const int c0) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             ws_lds_dma16(rs_w, lds_b + (uint32_t)((slot * WS_B_STAGE + p * WS_BN * WS_BK) * 2), vb, (uint32_t)((((size_t)p * npad) * K + c0) * 2));
@@ -307,10 +340,13 @@ __global__ __launch_bounds__(WT, 2) void gt_gemm_split_kernel(ConvGemmArgs A, co
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    // prologue: steps 0 and 1 requested; step 0's x split
-    dma(0, 0);
-    dma(1, min(1, nsl - 1) * WS_BK);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // prologue: x of steps 0..2 and W of steps 0, 1 requested; step 0's x split
+    dma_x(0, 0);
+    dma_x(1, min(1, nsl - 1) * WS_BK);
+    dma_x(2, min(2, nsl - 1) * WS_BK);
+    dma_b(0, 0);
+    dma_b(1, min(1, nsl - 1) * WS_BK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
         const float4 v = *reinterpret_cast<const float4*>(Ar + a_own);
         bf16x2 h_[2], m_[2], l_[2];
@@ -318,21 +354,21 @@ __global__ __launch_bounds__(WT, 2) void gt_gemm_split_kernel(ConvGemmArgs A, co
         split2(v.z, v.w, h_[1], m_[1], l_[1]);
         store_planes(0, h_, m_, l_);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int cur = 0, s3 = 0, s3n = 1, s3nn = 2;        // plane stage of the step; ring slots of steps s, s + 1, s + 2
+    int cur = 0, s3 = 0, s3nn = 2, x4n = 1, x4nnn = 3;     // plane stage of the step; W ring slots of steps s / s + 2; x ring slots of steps s + 1 / s + 3
 #define GS_RD(ks, p, WHICH)                                                                                        \
         do { if (WHICH & 1) a_[ks][p] = *reinterpret_cast<const bf16x8*>(ab_ + p * WS_BMP * WS_LDA + ks * 16);     \
              if (WHICH & 2) b_[ks][p] = *reinterpret_cast<const bf16x8*>(bb_ + p * WS_BN * WS_BK + (((2 * ks + kh) ^ b_sw) * 8)); } while (0)
 #define GS_MFMA(x, y) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0)
     for (int s = 0; s < nsl; ++s) {
-        dma(s3nn, min(s + 2, nsl - 1) * WS_BK);     // (past the end: a valid address whose data is never used)
+        dma_x(x4nnn, min(s + 3, nsl - 1) * WS_BK);  // (past the end: a valid address whose data is never used)
+        dma_b(s3nn, min(s + 2, nsl - 1) * WS_BK);
         const __bf16* ab_ = As + cur * WS_A_STAGE + a_rd;
         const __bf16* bb_ = Bs + s3 * WS_B_STAGE + bc * WS_BK;
         bf16x8 a_[2][3], b_[2][3];
         bf16x2 h_[2], m_[2], l_[2];
         GS_RD(0, 0, 3); GS_RD(0, 1, 3); GS_RD(0, 2, 3);
-        const float4 v = *reinterpret_cast<const float4*>(Ar + s3n * GS_ARAW + a_own);       // step s + 1's x: landed behind the last step's wait
+        const float4 v = *reinterpret_cast<const float4*>(Ar + x4n * GS_ARAW + a_own);       // step s + 1's x: requested two steps ago, landed behind the last step's wait
         __builtin_amdgcn_sched_barrier(0);
         GS_MFMA(a_[0][0], b_[0][0]); GS_MFMA(a_[0][0], b_[0][1]); GS_MFMA(a_[0][1], b_[0][0]);
         split2(v.x, v.y, h_[0], m_[0], l_[0]);
@@ -350,7 +386,8 @@ __global__ __launch_bounds__(WT, 2) void gt_gemm_split_kernel(ConvGemmArgs A, co
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // all but this step's four DMAs: the next step's x and W have landed
         __syncthreads();
         cur ^= 1;
-        const int t3 = s3; s3 = s3n; s3n = s3nn; s3nn = t3;
+        s3 = s3 == 2 ? 0 : s3 + 1; s3nn = s3nn == 2 ? 0 : s3nn + 1;
+        x4n = (x4n + 1) & 3; x4nnn = (x4nnn + 1) & 3;
     }
 #undef GS_RD
 #undef GS_MFMA

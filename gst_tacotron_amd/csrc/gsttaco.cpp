@@ -116,7 +116,7 @@ struct gsttaco_ctx {
     // EXPERIMENTS round 3, item 2b)
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int gst_fork = 0;            // GSTTACO_GST_FORK: 1 = forked inside the captured encoder graph, 2 = its own graph on the side stream beside the
+    int gst_fork = 1;            // GSTTACO_GST_FORK (default 1 since round 6): 1 = forked inside the captured encoder graph, 2 = its own graph on the side stream beside the
                                  // encoder's convolution graph, joined in front of the BiLSTM graph
     int enc_part = 0;            // (mode 2) which part of the encoder segment is being enqueued: 0 all, 1 up to the hoisted GEMM, 2 the BiLSTM
     bool masks_lazy = false;     // the last decode did not write the keep-mask tensor (hashed decisions): gsttaco_debug_randomness regenerates it
@@ -862,9 +862,18 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
         HIPCHECK(c, hipEventRecord(c->ev_fork, s));
         HIPCHECK(c, hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         const int rg = enqueue_gst(c, c->side_stream, B, gst_Tref1);
-        if (rg) return rg;
-        HIPCHECK(c, hipEventRecord(c->ev_join, c->side_stream));
+        // (joined on the error path too: a side stream left forked would leave an unjoined capture behind -- the capturing stream's
+        // EndCapture fails -- or, eagerly, work of this call running on behind the error return)
+        const hipError_t ej = hipEventRecord(c->ev_join, c->side_stream);
+        if (rg || ej != hipSuccess) {
+            if (ej == hipSuccess) (void)hipStreamWaitEvent(s, c->ev_join, 0);
+            return rg ? rg : fail(c, GSTTACO_E_HIP, std::string("hipEventRecord(ev_join): ") + hipGetErrorString(ej));
+        }
     }
+    struct JoinGuard {      // an error return between the fork and the join below still joins the side stream
+        gsttaco_ctx* c; hipStream_t s; bool armed;
+        ~JoinGuard() { if (armed) (void)hipStreamWaitEvent(s, c->ev_join, 0); }
+    } join_guard{c, s, gst_Tref1 > 0 && c->enc_part == 0};
     // (round 6) the embedding lookup as rows in memory when the first convolution can then take the Winograd kernel on the bf16 pipe
     // (it resolves the lookup inside its gather only as an implicit GEMM: 140 us against ~90 for lookup + Winograd at 4 096 rows)
     if (c->enc_part != 2 && g.n_enc_conv > 0 && c->enc_wino && c->enc_conv[0].wino_s && tok && c->enc_conv[0].cin == g.emb &&
@@ -894,7 +903,7 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
     }
     // BiLSTM: one launch per time step, both directions in grid.z; h is written straight into enc_out.
     const int H = g.enc_rnn, C = c->conv_c, EO = c->enc_out;
-    if (gst_Tref1 > 0 && c->enc_part == 0) HIPCHECK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    if (gst_Tref1 > 0 && c->enc_part == 0) { join_guard.armed = false; HIPCHECK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
     if (c->enc_part != 2) HIPCHECK(c, gt_launch_zero(c->w_cenc, (size_t)2 * B * H, s));
     if (lean_bilstm_usable(c, c->enc_lean, B)) return enqueue_lean_bilstm(c, s, c->enc_lean, x, B, Tv, c->w_cenc, c->w_enc, tlen);
     for (int t = 0; t < Tv; ++t) {
@@ -1045,14 +1054,17 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
     // (mixed precision: the bf16 kernel -- every GEMM pack bf16, the activation mirrors allocated, one group of up to 64 rows)
     const int n_bf16 = c->lstm_x[0].bf16 + c->lstm_x[1].bf16 + c->lstm_h[0].bf16 + c->lstm_h[1].bf16 + c->proj_z.bf16;
     const bool persist_bf16 = n_bf16 == 5 && c->w_xa_h && c->w_xa2_h && c->w_h1_h[0] && c->w_h2_h[0];
+    // (ONE effective value for the host's eligibility check and the launcher's kernel choice: the experiment's two groups of 16 never
+    // apply to LSA or mixed precision, which always take their one-group kernels)
+    const int split16_eff = (c->persist_split16 && g.att_type != GSTTACO_ATT_LSA && !persist_bf16) ? 1 : 0;
     const bool persist_base = c->persist_now && c->fused_front && c->split_rec && c->lean && c->keep_x_weights && c->front_mode >= 2 &&
                               (n_bf16 == 0 || persist_bf16) && c->proj_z.wp != nullptr && c->proj.nkb >= 32 &&
                               c->worker_tiles == 2 && c->co_worker_tiles == 1 &&
                               // (the LSA extension: the one-group fp32 kernel's LSA chain, up to 128 tokens -- else the launch path)
                               (g.att_type != GSTTACO_ATT_LSA || (n_bf16 == 0 && c->loc_pack && gt_persist_decode_lsa_fits(B, Tv, g.loc_filters, g.loc_kernel))) &&
                               front_fits(c, Tv) && c->lstm_x[0].nkb == 24 && c->lstm_x[1].nkb == 64 && c->lstm_h[0].nkb == 64 &&
-                              c->lstm_h[1].nkb == 64 && B <= c->persist_rows && (B <= 16 || !c->persist_split16 || c->w_stash) && (B <= 32 || c->w_stash) &&
-                              gt_persist_decode_supported(mel, r, P0, P1, att, H1, H2, B, Tv, c->proj_z.ntiles, c->proj_z.nkb, c->persist_slots, c->persist_split16,
+                              c->lstm_h[1].nkb == 64 && B <= c->persist_rows && (B <= 16 || !split16_eff || c->w_stash) && (B <= 32 || c->w_stash) &&
+                              gt_persist_decode_supported(mel, r, P0, P1, att, H1, H2, B, Tv, c->proj_z.ntiles, c->proj_z.nkb, c->persist_slots, split16_eff,
                                                           persist_bf16 ? 1 : 0);
     if (!persist_base) {
         HIPCHECK(c, gt_launch_zero(c->w_h1[1], (size_t)MT * 16 * H1, s));
@@ -1148,7 +1160,7 @@ int enqueue_decode(gsttaco_ctx* c, hipStream_t s, int B, int Tv, int steps, bool
             a.dbg = c->stamps ? c->w_dbg : nullptr;
             const bool prof = c->prof_every > 0;
             if (prof) { int rce = prof_begin(2); if (rce) return rce; }
-            HIPCHECK(c, gt_launch_persist_decode(a, c->pb0, c->persist_split16, s));
+            HIPCHECK(c, gt_launch_persist_decode(a, c->pb0, split16_eff, s));
             if (prof) { int rce = prof_end(2); if (rce) return rce; }
             ++c->n_persist_decodes;
             if (c->prof_every > 0)
@@ -1863,7 +1875,10 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->persist_decode = env_int("GSTTACO_PERSIST_DECODE", 1) != 0;
     c->persist_rows = env_int("GSTTACO_PERSIST_ROWS", 128);
     c->persist_split16 = env_int("GSTTACO_PERSIST_SPLIT16", 0) != 0 ? 1 : 0;
-    c->gst_fork = std::min(2, std::max(0, env_int("GSTTACO_GST_FORK", 0)));
+    // (round 6: the encoder's convolutions run on the Winograd split kernel's 128 workgroups = half the chip, and the GST branch -- 0.24 ms of
+    // small launches -- now does hide beside them: 10.75 -> 10.5 ms per Inference_Step at the headline shape; when they filled the chip
+    // the fork measured neutral, EXPERIMENTS round 5 item 6)
+    c->gst_fork = std::min(2, std::max(0, env_int("GSTTACO_GST_FORK", 1)));
     c->wino = env_int("GSTTACO_WINO", 4);
     if (c->wino != 0 && c->wino != 2) c->wino = 4;      // {0, 2, 4}; any other non-zero value (the old boolean's 1 included) means the default
     c->wino_split = env_int("GSTTACO_WINO_SPLIT", 1) != 0;
@@ -2495,15 +2510,23 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
     hipStream_t s = (hipStream_t)stream;
     const bool voc = spectrogram != nullptr;
     const size_t meld = c->cfg.mel_dim;
-    HIPCHECK(c, hipMemcpyAsync(c->w_tokens, tokens, (size_t)B * Tv * 4, hipMemcpyDeviceToDevice, s));
-    if (gst) {
-        HIPCHECK(c, hipMemcpyAsync(c->w_mels_in, mels_for_gst, (size_t)B * Tref1 * meld * 4, hipMemcpyDeviceToDevice, s));
-        HIPCHECK(c, hipMemcpyAsync(c->w_mel_len, mel_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-    }
-    if ((rc = stage_randomness(c, s, mask, noise, seed, B, Tv, steps))) return rc;
-    c->masks_lazy = masks_unused(c, Tv, mask != nullptr);       // (per CALL: a replayed graph does not pass through enqueue_decode)
+    // inputs -> the workspace the cached graphs read, and the seed: ONE launch (injected masks / noise -- parity runs -- keep their copies)
     const bool masked = token_lengths != nullptr;
-    if (masked) HIPCHECK(c, hipMemcpyAsync(c->w_tok_len, token_lengths, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    {
+        GtCopySegs cs{};
+        auto seg = [&](const void* src, void* dst, size_t words) { cs.src[cs.n] = src; cs.dst[cs.n] = dst; cs.words[cs.n] = words; ++cs.n; };
+        seg(tokens, c->w_tokens, (size_t)B * Tv);
+        if (gst) { seg(mels_for_gst, c->w_mels_in, (size_t)B * Tref1 * meld); seg(mel_lengths, c->w_mel_len, (size_t)B); }
+        if (masked) seg(token_lengths, c->w_tok_len, (size_t)B);
+        cs.seed = seed; cs.seed_dst = c->w_seed;
+        HIPCHECK(c, gt_launch_copy_segments(cs, s));
+    }
+    if (mask && c->dec_padded)      // (the caller's masks have the caller's prenet sizes: re-laid out for the padded model)
+        HIPCHECK(c, gt_launch_relayout_masks(mask, c->w_masks, steps, B, c->P0t, c->P1t, c->P0, c->P1, 1, s));
+    else if (mask)
+        HIPCHECK(c, hipMemcpyAsync(c->w_masks, mask, (size_t)steps * B * (c->P0 + c->P1) * 4, hipMemcpyDeviceToDevice, s));
+    if (noise) HIPCHECK(c, hipMemcpyAsync(c->w_noise, noise, (size_t)steps * B * Tv * 4, hipMemcpyDeviceToDevice, s));
+    c->masks_lazy = masks_unused(c, Tv, mask != nullptr);       // (per CALL: a replayed graph does not pass through enqueue_decode)
     // Three graph segments: the encoder and the vocoder each contain a persistent BiLSTM launch and are chained process-wide
     // (run_cached, g_persist_event); the segment between them -- GST, value projection, the decode loop, the postnet: 95 % of the
     // call -- overlaps freely with other contexts' work.  The encoder / vocoder segments share their cached graphs with
@@ -2545,19 +2568,26 @@ int gsttaco_inference_step(gsttaco_ctx* c, const int32_t* tokens, const int32_t*
         GraphKey kvoc{5, B, 0, 0, steps * c->r, 0, 0, 0, 0};
         if ((rc = run_cached(c, s, kvoc, [&](hipStream_t st) { return enqueue_vocoder(c, st, B, steps * c->r, c->w_mel, c->w_spec); }, true))) return rc;
     }
+    // outputs out of the workspace the graphs write: ONE launch
     const size_t nf = (size_t)B * steps * c->r * meld;
-    HIPCHECK(c, hipMemcpyAsync(mel, c->w_mel, nf * 4, hipMemcpyDeviceToDevice, s));
-    if (pre_mel) HIPCHECK(c, hipMemcpyAsync(pre_mel, c->w_pre, nf * 4, hipMemcpyDeviceToDevice, s));
-    if (voc)
-        HIPCHECK(c, hipMemcpyAsync(spectrogram, c->w_spec, (size_t)B * steps * c->r * c->cfg.spec_dim * 4, hipMemcpyDeviceToDevice, s));
-    HIPCHECK(c, hipMemcpyAsync(stop, c->w_stop, (size_t)B * steps * 4, hipMemcpyDeviceToDevice, s));
-    HIPCHECK(c, hipMemcpyAsync(align, c->w_align, (size_t)B * steps * Tv * 4, hipMemcpyDeviceToDevice, s));
+    {
+        GtCopySegs cs{};
+        auto seg = [&](const void* src, void* dst, size_t words) { cs.src[cs.n] = src; cs.dst[cs.n] = dst; cs.words[cs.n] = words; ++cs.n; };
+        seg(c->w_mel, mel, nf);
+        if (pre_mel) seg(c->w_pre, pre_mel, nf);
+        if (voc) seg(c->w_spec, spectrogram, (size_t)B * steps * c->r * c->cfg.spec_dim);
+        seg(c->w_stop, stop, (size_t)B * steps);
+        seg(c->w_align, align, (size_t)B * steps * Tv);
+        HIPCHECK(c, gt_launch_copy_segments(cs, s));
+    }
     return 0;
 }
 
 int gsttaco_synchronize(gsttaco_ctx* c, void* stream) {
     if (!c) return GSTTACO_E_INVALID;
     HIPCHECK(c, hipStreamSynchronize((hipStream_t)stream));
+    // (the GST fork's side stream is joined into `stream` by every call that forks; after an error return in between it may not be)
+    if (c->gst_fork != 0 && c->side_stream && !c->capturing) HIPCHECK(c, hipStreamSynchronize(c->side_stream));
     note_give_up(c);
     if (c->gave_up) {
         // the ONLY place the give-up words are cleared: behind the synchronisation, nothing of this context polls them any more

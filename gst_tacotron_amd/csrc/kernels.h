@@ -261,6 +261,9 @@ hipError_t gt_launch_set_seed(uint64_t* dst, uint64_t seed, hipStream_t stream);
 hipError_t gt_launch_rng_fill(const uint64_t* seed_ptr, float* masks, float* noise, int steps, int B, int P0, int P1, int Tv,
                               float drop_rate, hipStream_t stream);
 hipError_t gt_launch_relayout_masks(const float* src, float* dst, int steps, int B, int p0, int p1, int P0, int P1, int to_padded, hipStream_t stream);
+// up to 8 device-to-device copies of 4-byte words + the call's seed in one launch (attention.hip gt_copy_segments_kernel)
+struct GtCopySegs { const void* src[8]; void* dst[8]; size_t words[8]; int n; uint64_t seed; uint64_t* seed_dst; };
+hipError_t gt_launch_copy_segments(const GtCopySegs& S, hipStream_t stream);
 hipError_t gt_launch_embed_rows(const float* table, const int32_t* tokens, float* out, int rows, int C, hipStream_t stream);
 hipError_t gt_launch_zero(float* p, size_t n_floats, hipStream_t stream);   // n rounded up to a multiple of 4 floats
 size_t gt_attn_lds_bytes(int Tv, int A, int loc_f, int loc_k, int* rows_lds);

@@ -1,6 +1,10 @@
 // The bf16 kernel of the persistent decode launch (Use_Mixed_Precision, <= 64 rows as ONE group, helper workgroups for the chain tiles'
 // recurrent halves): included by persist_decode.hip inside its anonymous namespace, behind the group kernels (it shares their waits and
 // the per-utterance chain).  DESIGN.md 3.1d, EXPERIMENTS.md round 5 item 2.
+// INVARIANT (give-up safety, PD_PHASE_ABORT in persist_decode.hip): after a bounded wait has given up, the workgroup runs the REST of the
+// step on whatever the wait left and leaves at the top of its next step.  That is only safe because NO ADDRESS AND NO LOOP BOUND behind a
+// wait depends on data that came through a hand-off: every index below is a function of blockIdx / threadIdx / the step counter / launch
+// arguments (token lengths are read from the caller's tensor before the first wait).  Keep it so when editing this file.
 #pragma once
 
 // ====================================================================================================================== bf16

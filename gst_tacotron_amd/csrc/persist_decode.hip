@@ -624,6 +624,8 @@ __device__ __forceinline__ void pd_lsa_features(const PersistDecodeArgs& A, cons
     }
 }
 
+// (give-up invariant, PD_PHASE_ABORT: the LSA chain's loop bounds -- filter / tap counts, Tv -- are launch arguments or the caller's token
+// lengths, its LDS indices functions of the thread index: nothing behind a wait is data-dependent)
 // LSA (with TV128, tvp = 128; the one-group kernel): the step-wise location-sensitive extension in the chain -- dec_front_lsa.hip's two
 // MFMA products on 8 waves instead of 16, each score row's two channel halves summed as the 16-wave kernel's two waves sum them
 // (bitwise that kernel); the weight image stays in LDS for the whole launch, the cumulative alignment lives in L.pv

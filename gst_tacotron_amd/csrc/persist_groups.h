@@ -1,6 +1,10 @@
 // Group kernels of the persistent decode launch (fp32, 33..128 rows; 17..32 rows as two groups of 16 as an experiment): included by
 // persist_decode.hip inside its anonymous namespace, behind the one-group kernel whose primitives (waits, fragment loads, MFMA pieces,
 // reductions, the per-utterance chain) they share.  DESIGN.md 3.1c, EXPERIMENTS.md round 5 item 1.
+// INVARIANT (give-up safety, PD_PHASE_ABORT in persist_decode.hip): after a bounded wait has given up, the workgroup runs the REST of the
+// step on whatever the wait left and leaves at the top of its next step.  That is only safe because NO ADDRESS AND NO LOOP BOUND behind a
+// wait depends on data that came through a hand-off: every index below is a function of blockIdx / threadIdx / the step counter / launch
+// arguments (token lengths are read from the caller's tensor before the first wait).  Keep it so when editing this file.
 #pragma once
 
 // ====================================================================================================================== groups

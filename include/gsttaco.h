@@ -278,7 +278,8 @@ int gsttaco_debug_handoff_error(gsttaco_ctx* ctx, uint32_t* host_out);
 /* Test support: out[0] = persistent BiLSTM launches this context has enqueued (eagerly or into a captured graph), out[1] = 1
  * while the context uses the persistent launch, 0 once it has fallen back to one launch per time step; out[2] / out[3] the same
  * for the persistent DECODE launch (the whole decoder loop of Taco2.py:153-228 as one launch: batch <= 128 -- above 32 rows as
- * groups of 32 through one set of resident weights --, T_v <= 256, fp32, the reference's decoder sizes, one live context;
+ * groups of 32 through one set of resident weights --, T_v <= 256, fp32, decoder sizes up to the reference's (smaller ones are
+ * zero-padded to them at finalize: exact, GSTTACO_PAD_DECODER), one live context;
  * GSTTACO_PERSIST_DECODE=0, GSTTACO_PERSIST_ROWS=<max batch> or a give-up: launches per step, bitwise the same). */
 int gsttaco_debug_counters(const gsttaco_ctx* ctx, uint64_t out[4]);
 /* Test support (fault injection).  bits 0..6 / 7 / 8..15: raise the fused launch's / the persistent decode launch's / the persistent

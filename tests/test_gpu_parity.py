@@ -287,8 +287,9 @@ def test_fused_lstm_launch_is_bitwise_the_two_launches(monkeypatch, B, mixed):
         assert np.abs(outs["1"][0] - ref[0]).max() <= TOL and np.abs(outs["1"][2] - ref[3]).max() <= TOL
 
 
-@pytest.mark.parametrize("persist,B,mixed", [("0", 4, False), ("1", 4, False), ("1", 40, False), ("1", 40, True)])
-def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers(monkeypatch, persist, B, mixed):
+@pytest.mark.parametrize("persist,B,mixed,Tv,att", [("0", 4, False, 24, "SMA"), ("1", 4, False, 24, "SMA"), ("1", 40, False, 24, "SMA"), ("1", 40, True, 24, "SMA"),
+                                                    ("1", 128, False, 256, "SMA"), ("1", 7, False, 40, "LSA/20/9")])
+def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers(monkeypatch, persist, B, mixed, Tv, att):
     """The fused LSTM launch's wait (persist = 0) and the persistent decode launch's waits (1) are bounded: with one arrival too
     many expected (fault injection) every workgroup runs into the bound, the call's outputs are invalid and ``synchronize``
     says so; the next call uses the next launch form down (persistent -> fused -> two launches) and is correct."""
@@ -298,9 +299,11 @@ def test_fused_lstm_give_up_is_reported_and_the_next_call_recovers(monkeypatch, 
     from gst_tacotron_amd.capi import GstTacoError
     gc.collect()                                    # (both launch forms are taken only while the process has ONE live context)
     monkeypatch.setenv("GSTTACO_PERSIST_DECODE", persist)
-    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, 24, 40, 3, seed=8)        # (B = 40: the group kernel, two groups of rows)
+    # (B = 40: the group kernel, two groups of rows; 128 x 256 tokens: four groups, the compact LDS layout; LSA: the LSA chain -- the give-up
+    # leaves a failed step's remaining phases running on whatever the wait left: no address or loop bound may depend on it)
+    hp, w, tokens, tl, mels, ml, masks, noise = _full_case(B, Tv, 40, 3, seed=8, att=att)
     hp = dict(hp); hp["Use_Mixed_Precision"] = bool(mixed)                              # (mixed: the bf16 kernel and its helpers' hand-back)
-    m = _model(hp, w, B, 24, 41)
+    m = _model(hp, w, B, Tv, 41)
     assert m.decode_counters()[1] == int(persist)
     ref = m.Inference_Step(tokens, tl, None, mels, ml, prenet_masks=masks, attn_noise=noise, steps=3)[0].cpu().numpy()
     m.synchronize()

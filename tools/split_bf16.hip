@@ -8,9 +8,9 @@
 //   RATE      per-CU loops with every operand plane re-read from LDS (ds_read_b128), 8 waves, MI x NJ tiles of 16 x 16 per wave, random
 //             bf16 bit patterns; fp32-EQUIVALENT TFLOP/s (2 M N K / time) against the 16x16x4 fp32 loop of tools/mfma_rate.hip's kind, and
 //             the cost of splitting an fp32 A fragment in the consumer (VALU) instead of reading planes its producer wrote.
-//   ACCURACY  K = 2 048 dot products (256 of them per case), operands N(0,1) and wide-exponent: error against float64 in units of the fp32
-//             result's ulp, for the fp32 MFMA chain, x6 (one accumulator, and low-order products in an accumulator of their own), x5, x3.
-// Gate: rate >= 2.2 x the 16x16x4 rate AND x6 within 2 ulp-of-the-fp32-sum of the float64 result.
+//   ACCURACY  K = 2 048 dot products (4 096 of them per case), operands N(0,1) and wide-exponent: error against float64 in units of
+//             2^-24 sum|a b|, for the fp32 MFMA chain, x6 (one accumulator, and low-order products in an accumulator of their own), x5, x3.
+// Gate: rate >= 2.2 x the 16x16x4 rate AND x6 as accurate as the fp32 MFMA chain it replaces (within 2 units of it).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/split_bf16 tools/split_bf16.hip && tools/split_bf16
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -265,18 +265,17 @@ static void accuracy_case(const char* name, int K, int wide, unsigned seed) {
                 }
                 ref[(size_t)t * 256 + i * 16 + j] = s; mag[(size_t)t * 256 + i * 16 + j] = m; seq[(size_t)t * 256 + i * 16 + j] = f;
             }
+    // error in units of 2^-24 sum|a b| -- the scale an fp32 summation's rounding errors live on.  (Units of the RESULT's ulp say nothing
+    // here: a random-sign sum is ~sqrt(K) smaller than the sum of its terms' magnitudes, and arbitrarily smaller where it cancels.)
     auto report = [&](const char* what, const std::vector<float>& got) {
-        double max_ulp = 0, rms_ulp = 0, max_rel_mag = 0;
+        double max_u = 0, rms_u = 0;
         for (size_t i = 0; i < got.size(); ++i) {
-            const double err = std::fabs((double)got[i] - ref[i]);
-            const float rf = (float)ref[i];
-            const double ulp = std::fabs((double)std::nextafter(std::fabs(rf), INFINITY) - std::fabs((double)rf));
-            max_ulp = std::max(max_ulp, err / ulp); rms_ulp += (err / ulp) * (err / ulp);
-            max_rel_mag = std::max(max_rel_mag, err / mag[i]);
+            const double u = std::fabs((double)got[i] - ref[i]) / (mag[i] * std::ldexp(1.0, -24));
+            max_u = std::max(max_u, u); rms_u += u * u;
         }
-        printf("  %-58s max %8.2f ulp  rms %7.2f ulp  max err / sum|a b| %.2e\n", what, max_ulp, std::sqrt(rms_ulp / got.size()), max_rel_mag);
+        printf("  %-58s max %6.2f  rms %5.2f   (x 2^-24 sum|a b|)\n", what, max_u, std::sqrt(rms_u / got.size()));
     };
-    printf("%s (K = %d, %d dot products; ulp = of the float64 result rounded to fp32)\n", name, K, NB * 256);
+    printf("%s (K = %d, %d dot products; error against the float64 sum)\n", name, K, NB * 256);
     report("fp32 fma chain on the host (k ascending)", seq);
     const char* names[5] = {"v_mfma_f32_16x16x4_f32 chain", "split-bf16 x6, one accumulator", "split-bf16 x6, low-order products in their own accumulator",
                             "split-bf16 x3 (hh, hm, mh)", "split-bf16 x5 (two-plane b, three-plane a)"};
