@@ -147,11 +147,9 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     // transform + split (~10 vector instructions, independent of them) behind the segment's MFMAs: on the bf16 pipe a wave's vector
     // instructions run under its own MFMAs (under fp32 MFMAs they do not: tools/mfma_rate.hip).  Left to the scheduler -- also with
     // sched_group_barrier pipelines -- all of it lands behind the twelfth MFMA.
-#ifndef WS_STAGGER
-#define WS_STAGGER 0
-#endif
-    // WS_STAGGER (experiment, tools/wino_split_bench.hip): the two waves that share a SIMD (w and w + 4) run the step's two halves in
-    // opposite order -- waves 0-3 MFMAs first, waves 4-7 transform + split + store first -- instead of both interleaving them
+    // (Tried and removed, tools/wino_split_bench -DWS_STAGGER, profiles/r06_wino_stagger.txt: the two waves of a SIMD running the step's halves
+    // in opposite order -- one its twelve MFMAs first, the other its transform + split + store first -- instead of both interleaving them:
+    // 457 against 250 us per 512 -> 512 layer.)
 #define WS_BODY_INTERLEAVED(XI, XI1, DX)                                                                           \
         WS_RD(0, 0, 3); WS_RD(0, 1, 3); WS_RD(0, 2, 3);                                                            \
         WS_FENCE();                                                                                               \
@@ -170,25 +168,7 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
         split2(v1_, h_[1], m_[1], l_[1]);                                                                          \
         store_planes(cur ^ 1, h_, m_, l_);                                                                         \
         WS_FENCE();
-#define WS_ALL_MFMA(XI)                                                                                            \
-        WS_RD(0, 0, 3); WS_RD(0, 1, 3); WS_RD(0, 2, 3); WS_RD(1, 0, 3); WS_RD(1, 1, 3);                            \
-        WS_MFMA(M[XI], a_[0][0], b_[0][0]); WS_MFMA(M[XI], a_[0][0], b_[0][1]); WS_MFMA(M[XI], a_[0][1], b_[0][0]); \
-        WS_MFMA(M[XI], a_[0][1], b_[0][1]); WS_MFMA(M[XI], a_[0][0], b_[0][2]); WS_MFMA(M[XI], a_[0][2], b_[0][0]); \
-        WS_RD(1, 2, 3);                                                                                            \
-        WS_MFMA(M[XI], a_[1][0], b_[1][0]); WS_MFMA(M[XI], a_[1][0], b_[1][1]); WS_MFMA(M[XI], a_[1][1], b_[1][0]); \
-        WS_MFMA(M[XI], a_[1][1], b_[1][1]); WS_MFMA(M[XI], a_[1][0], b_[1][2]); WS_MFMA(M[XI], a_[1][2], b_[1][0]);
-#define WS_ALL_XFORM(XI1, DX)                                                                                      \
-        split2(xform2(std::integral_constant<int, XI1>{}, std::integral_constant<int, 0>{}, DX), h_[0], m_[0], l_[0]); \
-        split2(xform2(std::integral_constant<int, XI1>{}, std::integral_constant<int, 1>{}, DX), h_[1], m_[1], l_[1]); \
-        store_planes(cur ^ 1, h_, m_, l_);
-#if WS_STAGGER
-#define WS_BODY(XI, XI1, DX)                                                                                       \
-        if (__builtin_amdgcn_readfirstlane(wave) < 4) { WS_ALL_MFMA(XI) WS_FENCE(); WS_ALL_XFORM(XI1, DX) }        \
-        else { WS_ALL_XFORM(XI1, DX) WS_FENCE(); WS_ALL_MFMA(XI) }                                                 \
-        WS_FENCE();
-#else
 #define WS_BODY(XI, XI1, DX) WS_BODY_INTERLEAVED(XI, XI1, DX)
-#endif
     float4 dE[AL], dO[AL];
 #define WS_STEP(XI, DCUR, DNXT, DX, s_)                                                                            \
     {                                                                                                             \
@@ -240,8 +220,6 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
 #undef WS_STEP
 #undef WS_BODY
 #undef WS_BODY_INTERLEAVED
-#undef WS_ALL_MFMA
-#undef WS_ALL_XFORM
 #undef WS_RD
 #undef WS_MFMA
 #undef WS_FENCE

@@ -903,6 +903,8 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
     }
     // BiLSTM: one launch per time step, both directions in grid.z; h is written straight into enc_out.
     const int H = g.enc_rnn, C = c->conv_c, EO = c->enc_out;
+    // (joining BEHIND the BiLSTM instead measured 10.83-10.86 against 10.85-10.89 ms per Inference_Step: not worth GST kernels lingering
+    // beside a launch that needs its members co-resident)
     if (gst_Tref1 > 0 && c->enc_part == 0) { join_guard.armed = false; HIPCHECK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
     if (c->enc_part != 2) HIPCHECK(c, gt_launch_zero(c->w_cenc, (size_t)2 * B * H, s));
     if (lean_bilstm_usable(c, c->enc_lean, B)) return enqueue_lean_bilstm(c, s, c->enc_lean, x, B, Tv, c->w_cenc, c->w_enc, tlen);
