@@ -487,12 +487,18 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
     // logical chunk (l % 8) ^ (l / 8) -> position l % 8
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(wt), 0, 0x7FFFF000, 0x00020000);
     const uint32_t lds_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)Bs;
-    const uint32_t wvoff = (uint32_t)(((lane >> 3) * A.ldk + (((lane & 7) ^ (lane >> 3)) * 8)) * 2);
+    // (round 6: the swizzle is (column / 2) % 8, not column % 8 -- a ds_read_b128 is served in four groups of 16 NON-contiguous lanes
+    // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32) over 64 banks: with column % 8 every fragment read of the slab was 2-way
+    // conflicted, which is what "bound by its fragment reads" (round 5) really was.  A group of 8 columns starts at a multiple of 8, so
+    // its swizzles are ((r0 / 2) % 8) + (lane / 16): two per-thread offsets, by the parity of the instruction's column group.)
+    const uint32_t wvoff0 = (uint32_t)(((lane >> 3) * A.ldk + (((lane & 7) ^ (lane >> 4)) * 8)) * 2);
+    const uint32_t wvoff1 = (uint32_t)(((lane >> 3) * A.ldk + (((lane & 7) ^ (4 + (lane >> 4))) * 8)) * 2);
     auto dma_b = [&](const int buf, const int tap, const int k0) {
 #pragma unroll
         for (int i = 0; i < BN / 64; ++i) {
-            const int r0 = (__builtin_amdgcn_readfirstlane(wave) * (BN / 64) + i) * 8;
-            gt_lds_dma16(rs_w, lds_b + (uint32_t)((buf * BN + r0) * C5_LDB * 2), wvoff, (uint32_t)((((size_t)(n0 + r0)) * A.ldk + tap * A.Cin + k0) * 2));
+            const int g8 = __builtin_amdgcn_readfirstlane(wave) * (BN / 64) + i, r0 = g8 * 8;
+            gt_lds_dma16(rs_w, lds_b + (uint32_t)((buf * BN + r0) * C5_LDB * 2), (g8 & 1) ? wvoff1 : wvoff0,
+                         (uint32_t)((((size_t)(n0 + r0)) * A.ldk + tap * A.Cin + k0) * 2));
         }
     };
     auto load_a = [&](const int k0, const int half) {
@@ -573,8 +579,8 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
 #pragma unroll
             for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * C5_LD + ks * 16);
 #pragma unroll
-            for (int j = 0; j < RN; ++j)        // (DMA: chunk 2 ks + kh of column .. + l31 sits at position (2 ks + kh) ^ (l31 % 8): j * 32 keeps the column's low bits)
-                bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * C5_LDB + (GT_C5_DMA ? (((2 * ks + kh) ^ (l31 & 7)) * 8) : ks * 16));
+            for (int j = 0; j < RN; ++j)        // (DMA: chunk 2 ks + kh of column .. + l31 sits at position (2 ks + kh) ^ ((l31 / 2) % 8): j * 32 keeps the column's low bits)
+                bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * C5_LDB + (GT_C5_DMA ? (((2 * ks + kh) ^ ((l31 >> 1) & 7)) * 8) : ks * 16));
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
