@@ -800,8 +800,10 @@ bool lean_bilstm_usable(const gsttaco_ctx* c, const gsttaco_ctx::LeanBiLstm& L, 
 }
 
 // x: [B*T, C] rows; cstate: [2, B, H] (zeroed by the caller); out: [B, T, 2H]
+// join: an event the stream waits for BEHIND the hoisted GEMM, in front of the recurrence (the forked GST branch: the GEMM fills the chip
+// for ~80 us and the branch's last small launches finish beside it instead of in front of it)
 int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBiLstm& L, const float* x, int B, int Tn, float* cstate,
-                        float* out, const int32_t* row_len) {
+                        float* out, const int32_t* row_len, hipEvent_t join = nullptr) {
     const int H = L.H, EO = 2 * H, MT = (B + 15) / 16;
     ConvGemmArgs a{};
     a.x = x; a.w = L.xw; a.shift = L.xb;
@@ -809,6 +811,7 @@ int enqueue_lean_bilstm(gsttaco_ctx* c, hipStream_t s, const gsttaco_ctx::LeanBi
     a.B = B; a.T = Tn; a.Cin = L.C; a.N = 8 * H; a.taps = 1; a.pad_before = 0; a.act = ACT_NONE;
     a.gemm_s = L.xw_s; a.wino_npad = L.xw_npad;         // (round 6: on the bf16 matrix pipe as split-bf16 x6 where the grid allows)
     if (c->enc_part != 2) HIPCHECK(c, launch_conv(c, a, s));
+    if (join) HIPCHECK(c, hipStreamWaitEvent(s, join, 0));
     if (c->enc_part == 1) return 0;
     // One persistent launch for the whole sequence, one (direction, 16 utterances) group per XCD (skinny_gemm.hip
     // gt_bilstm_persist_kernel; same arithmetic, bitwise the same outputs); GSTTACO_BILSTM_PERSIST=0 keeps the launch per step.
@@ -905,9 +908,16 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
     const int H = g.enc_rnn, C = c->conv_c, EO = c->enc_out;
     // (joining BEHIND the BiLSTM instead measured 10.83-10.86 against 10.85-10.89 ms per Inference_Step: not worth GST kernels lingering
     // beside a launch that needs its members co-resident)
-    if (gst_Tref1 > 0 && c->enc_part == 0) { join_guard.armed = false; HIPCHECK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
+    const bool lean_enc = lean_bilstm_usable(c, c->enc_lean, B);
+    const bool join_here = gst_Tref1 > 0 && c->enc_part == 0;
+    // (the lean BiLSTM joins behind its hoisted GEMM, see enqueue_lean_bilstm; the guard covers its error returns in front of that)
+    if (join_here && !lean_enc) { join_guard.armed = false; HIPCHECK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
     if (c->enc_part != 2) HIPCHECK(c, gt_launch_zero(c->w_cenc, (size_t)2 * B * H, s));
-    if (lean_bilstm_usable(c, c->enc_lean, B)) return enqueue_lean_bilstm(c, s, c->enc_lean, x, B, Tv, c->w_cenc, c->w_enc, tlen);
+    if (lean_enc) {
+        const int rl = enqueue_lean_bilstm(c, s, c->enc_lean, x, B, Tv, c->w_cenc, c->w_enc, tlen, join_here ? c->ev_join : nullptr);
+        if (!rl) join_guard.armed = false;          // (joined inside)
+        return rl;
+    }
     for (int t = 0; t < Tv; ++t) {
         SkinnyArgs a[2];
         for (int d = 0; d < 2; ++d) {
