@@ -147,6 +147,11 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     // transform + split (~10 vector instructions, independent of them) behind the segment's MFMAs: on the bf16 pipe a wave's vector
     // instructions run under its own MFMAs (under fp32 MFMAs they do not: tools/mfma_rate.hip).  Left to the scheduler -- also with
     // sched_group_barrier pipelines -- all of it lands behind the twelfth MFMA.
+    // (Tried and removed, round 6: the workgroup as 32 tiles x 128 columns on 4 waves, B planes one step ahead in two stages = 63 KB of LDS, so
+    // that TWO unsynchronised workgroups share a CU and one's MFMA phase runs beside the other's loads and LDS traffic -- inside one
+    // workgroup the per-step barrier keeps every wave in the same phase and the step is the SUM of its MFMA, LDS and vector time.  Bitwise
+    // the same results, 300 against 250 us per 512 -> 512 layer (postnet 1.15 against 0.99 ms): every B byte is then fetched for 32 tile
+    // rows instead of 64, and the B planes' way into LDS is what the skeleton is bound by.)
     // (Tried and removed, tools/wino_split_bench -DWS_STAGGER, profiles/r06_wino_stagger.txt: the two waves of a SIMD running the step's halves
     // in opposite order -- one its twelve MFMAs first, the other its transform + split + store first -- instead of both interleaving them:
     // 457 against 250 us per 512 -> 512 layer.)
