@@ -897,8 +897,10 @@ int enqueue_encoder(gsttaco_ctx* c, hipStream_t s, int B, int Tv, bool masked, i
         // 128 workgroups of F(2,5) -- half the chip, where the fp32 Winograd kernel lost to the implicit GEMM (275 against 136 us) --
         // enc_wino: 0 = implicit GEMM, 2 = F(2,5), 4 = F(4,5) where its grid reaches 60 workgroups
         if (c->enc_wino && !tok && L.wino_s) {
-            a.wino_u = L.wino_u; a.wino_u4 = c->enc_wino == 4 ? L.wino_u4 : nullptr; a.wino_cin = L.wino_cin;
-            a.wino_s = L.wino_s; a.wino_s4 = c->enc_wino == 4 ? L.wino_s4 : nullptr; a.wino_npad = L.wino_npad;
+            // (F(4,5) where ITS grid fills the chip -- batches of 128 utterances --, else F(2,5) down to 100 workgroups)
+            const bool f4 = c->enc_wino == 4 || ((B * ((Tv + 3) / 4) + 63) / 64) * ((L.cout + 127) / 128) >= 240;
+            a.wino_u = L.wino_u; a.wino_u4 = f4 ? L.wino_u4 : nullptr; a.wino_cin = L.wino_cin;
+            a.wino_s = L.wino_s; a.wino_s4 = f4 ? L.wino_s4 : nullptr; a.wino_npad = L.wino_npad;
             a.wino_min_wgs = c->enc_wino == 4 ? 60 : 100;
         }
         HIPCHECK(c, launch_conv(c, a, s));
