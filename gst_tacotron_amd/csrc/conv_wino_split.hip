@@ -182,13 +182,16 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
         constexpr int XI2 = (XI + 2) % AL;                                                                         \
         /* B planes of step g + 2 into the stage step g - 1 read (three stages: a step is ~0.5 us, shorter than an L2 round trip under */ \
         /* load -- requested one step ahead, the wait at the end of every step exposed it: 169 us of the 253 per 512 -> 512 layer) */ \
-        dma_b(bnx, XI2, min((s_) + (XI + 2 >= AL ? 1 : 0), nsl - 1) * WS_BK);                                      \
-        if constexpr (XI == 0) wino_issue_taps<MO>(A, rs_x, voff, first, len, min((s_) + 1, nsl - 1) * WS_BK, (s_) + 1 < nsl, DNXT); \
         const __bf16* ab_ = As + cur * WS_A_STAGE + a_rd;                                                          \
         const __bf16* bb_ = Bs + bcur * WS_B_STAGE + bc * WS_BK;                                                   \
         bf16x8 a_[2][3], b_[2][3];                                                                                 \
         bf16x2 h_[2], m_[2], l_[2];                                                                                \
         WS_BODY(XI, XI1, DX)                                                                                       \
+        /* The step's requests go out at its END: the compiler counts only the loads it knows (the taps) and asks for "all but the n */ \
+        /* youngest" when it consumes them -- with this step's DMAs already in the queue that wait covered them too (vmcnt(1) in */ \
+        /* front of the slice's last transform: a DMA's whole latency, exposed in two or three of eight steps). */ \
+        dma_b(bnx, XI2, min((s_) + (XI + 2 >= AL ? 1 : 0), nsl - 1) * WS_BK);                                      \
+        if constexpr (XI == 0) wino_issue_taps<MO>(A, rs_x, voff, first, len, min((s_) + 1, nsl - 1) * WS_BK, (s_) + 1 < nsl, DNXT); \
         /* the NEXT step's B planes have landed (requested a step ago; loads complete in order): what may still be in flight is this */ \
         /* step's three DMAs and, at XI == 0 and 1, the next slice's AL tap loads requested behind XI == 0's DMAs */ \
         if constexpr (XI <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + AL) : "memory");                      \

@@ -568,9 +568,11 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
         // the other A buffer was last read in the previous slice)
         const int sn = min(s + 1, nsteps - 1);
         load_b(sn % 5, (sn / 5) * C5_BK);
-        // (DMA: into the other slab, last read in step s - 1 -- every wave is past that step's barrier)
-        if (GT_C5_DMA) dma_b((s + 1) & 1, sn % 5, (sn / 5) * C5_BK);
         if (tap == 0 || tap == 2) load_a(min(sl + 1, nslices - 1) * C5_BK, tap >> 1);
+        // (DMA: into the other slab, last read in step s - 1 -- every wave is past that step's barrier.  BEHIND the row requests since round 6:
+        // before the compiler re-uses the rows' registers it waits for the loads it knows with vmcnt(4) .. vmcnt(0) -- which, with this step's
+        // four DMAs already queued, waited for THEM: a DMA's whole latency exposed at taps 0 and 2 of every slice)
+        if (GT_C5_DMA) dma_b((s + 1) & 1, sn % 5, (sn / 5) * C5_BK);
         const __bf16* Ab = As + ((sl & 1) * C5_AR + wm * 64 + l31 + tap) * C5_LD + kh * 8;
         const __bf16* Bb = Bs + ((s & 1) * BN + wn * RN * 32 + l31) * C5_LDB + (GT_C5_DMA ? 0 : kh * 8);
 #pragma unroll
