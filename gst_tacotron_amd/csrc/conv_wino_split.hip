@@ -49,9 +49,13 @@ __device__ __forceinline__ void ws_split(const float v, __bf16& h, __bf16& m, __
     l = (__bf16)r2;
 }
 
-template <int MO>
+// X3 (knob GSTTACO_WINO_SPLIT=3, NOT the default): only the planes hi and mid of both operands and the products hh, hm, mh -- what the review
+// priced as "three products = 5.3 x at ~2^-16": half the MFMAs, two thirds of the plane traffic; what is dropped (mm, hl, lh) is ~2^-17 of
+// |a b| per product, 9.3 units of 2^-24 sum|a b| on K = 2 048 dot products against x6's 3.0 and the fp32 chain's 2.7 (tools/split_bf16.hip).
+template <int MO, bool X3>
 __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, const __bf16* __restrict__ Us, const int npad) {
     constexpr int AL = Wino<MO>::ALPHA;
+    constexpr int NPL = X3 ? 2 : 3;             // planes moved and multiplied
     extern __shared__ __attribute__((aligned(16))) __bf16 ws_lds[];
     __bf16* As = ws_lds;                            // [2][3][64][WS_LDA]
     __bf16* Bs = ws_lds + 2 * WS_A_STAGE;           // [3][3][128][32]
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     const int a_st = (tid >> 3) * WS_LDA + (tid & 7) * 4;
     auto dma_b = [&](const int st, const int xi, const int c0) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
             ws_lds_dma16(rs_u, lds_b + (uint32_t)((st * WS_B_STAGE + p * WS_BN * WS_BK) * 2), vb, (uint32_t)((((size_t)(xi * 3 + p) * npad) * A.wino_cin + c0) * 2));
     };
     // the NEXT step's A planes, in four pieces that are dealt between the current step's MFMAs below: transform of channels (0, 1) /
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
         __bf16* as = As + st * WS_A_STAGE + a_st;
         *reinterpret_cast<bf16x4*>(as) = bf16x4{h[0][0], h[0][1], h[1][0], h[1][1]};
         *reinterpret_cast<bf16x4*>(as + WS_BMP * WS_LDA) = bf16x4{m[0][0], m[0][1], m[1][0], m[1][1]};
-        *reinterpret_cast<bf16x4*>(as + 2 * WS_BMP * WS_LDA) = bf16x4{l[0][0], l[0][1], l[1][0], l[1][1]};
+        if (!X3) *reinterpret_cast<bf16x4*>(as + 2 * WS_BMP * WS_LDA) = bf16x4{l[0][0], l[0][1], l[1][0], l[1][1]};
     };
     // one step's products: per 16 k the three A and three B plane fragments, then hh, hm, mh, mm, hl, lh into the GEMM's accumulator
     const int a_rd = (wm * 32 + l31) * WS_LDA + kh * 8;
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
 #else
 #define WS_MFMA(ACC, x, y) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, ACC, 0, 0, 0)
 #endif
+#define WS_MFMA6(ACC, x, y) do { if (!X3) WS_MFMA(ACC, x, y); } while (0)      /* (the products x6 has and x3 drops) */
 #define WS_FENCE() __builtin_amdgcn_sched_barrier(0)
     // The step as four fenced segments of three dependent MFMAs each (96 cycles of the matrix pipe) with a quarter of the NEXT step's
     // transform + split (~10 vector instructions, independent of them) behind the segment's MFMAs: on the bf16 pipe a wave's vector
@@ -156,20 +161,20 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
     // in opposite order -- one its twelve MFMAs first, the other its transform + split + store first -- instead of both interleaving them:
     // 457 against 250 us per 512 -> 512 layer.)
 #define WS_BODY_INTERLEAVED(XI, XI1, DX)                                                                           \
-        WS_RD(0, 0, 3); WS_RD(0, 1, 3); WS_RD(0, 2, 3);                                                            \
+        WS_RD(0, 0, 3); WS_RD(0, 1, 3); if (!X3) WS_RD(0, 2, 3);                                                   \
         WS_FENCE();                                                                                               \
         WS_MFMA(M[XI], a_[0][0], b_[0][0]); WS_MFMA(M[XI], a_[0][0], b_[0][1]); WS_MFMA(M[XI], a_[0][1], b_[0][0]); \
         const f32x2 v0_ = xform2(std::integral_constant<int, XI1>{}, std::integral_constant<int, 0>{}, DX);        \
         WS_FENCE();                                                                                               \
-        WS_MFMA(M[XI], a_[0][1], b_[0][1]); WS_MFMA(M[XI], a_[0][0], b_[0][2]); WS_MFMA(M[XI], a_[0][2], b_[0][0]); \
+        WS_MFMA6(M[XI], a_[0][1], b_[0][1]); WS_MFMA6(M[XI], a_[0][0], b_[0][2]); WS_MFMA6(M[XI], a_[0][2], b_[0][0]); \
         WS_RD(1, 0, 3); WS_RD(1, 1, 3);       /* (the second 16 k: the low planes a segment later -- 16 registers less at the peak) */ \
         split2(v0_, h_[0], m_[0], l_[0]);                                                                          \
         WS_FENCE();                                                                                               \
         WS_MFMA(M[XI], a_[1][0], b_[1][0]); WS_MFMA(M[XI], a_[1][0], b_[1][1]); WS_MFMA(M[XI], a_[1][1], b_[1][0]); \
-        WS_RD(1, 2, 3);                                                                                            \
+        if (!X3) WS_RD(1, 2, 3);                                                                                   \
         const f32x2 v1_ = xform2(std::integral_constant<int, XI1>{}, std::integral_constant<int, 1>{}, DX);        \
         WS_FENCE();                                                                                               \
-        WS_MFMA(M[XI], a_[1][1], b_[1][1]); WS_MFMA(M[XI], a_[1][0], b_[1][2]); WS_MFMA(M[XI], a_[1][2], b_[1][0]); \
+        WS_MFMA6(M[XI], a_[1][1], b_[1][1]); WS_MFMA6(M[XI], a_[1][0], b_[1][2]); WS_MFMA6(M[XI], a_[1][2], b_[1][0]); \
         split2(v1_, h_[1], m_[1], l_[1]);                                                                          \
         store_planes(cur ^ 1, h_, m_, l_);                                                                         \
         WS_FENCE();
@@ -194,8 +199,8 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
         if constexpr (XI == 0) wino_issue_taps<MO>(A, rs_x, voff, first, len, min((s_) + 1, nsl - 1) * WS_BK, (s_) + 1 < nsl, DNXT); \
         /* the NEXT step's B planes have landed (requested a step ago; loads complete in order): what may still be in flight is this */ \
         /* step's three DMAs and, at XI == 0 and 1, the next slice's AL tap loads requested behind XI == 0's DMAs */ \
-        if constexpr (XI <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 + AL) : "memory");                      \
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                     \
+        if constexpr (XI <= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL + AL) : "memory");                    \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPL) : "memory");                                           \
         __syncthreads();                                                                                          \
         cur ^= 1;                                                                                                 \
         bcur = bcur == 2 ? 0 : bcur + 1;                                                                           \
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(WT, 2) void gt_conv_wino5s_kernel(ConvGemmArgs A, c
 #undef WS_BODY_INTERLEAVED
 #undef WS_RD
 #undef WS_MFMA
+#undef WS_MFMA6
 #undef WS_FENCE
 
     // epilogue (the fp32 kernel's); 32x32 C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); tile row -> MO output rows
@@ -400,8 +406,9 @@ __global__ __launch_bounds__(WT, 2) void gt_gemm_split_kernel(ConvGemmArgs A, co
 
 hipError_t gt_conv_wino5s_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_gemm_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv_wino5s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv_wino5s_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+#define WS_ATTR(MO, X3) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gt_conv_wino5s_kernel<MO, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+    WS_ATTR(4, false) WS_ATTR(2, false) WS_ATTR(4, true) WS_ATTR(2, true)
+#undef WS_ATTR
     return e;
 }
 
@@ -410,8 +417,14 @@ hipError_t gt_launch_conv_wino5s(const ConvGemmArgs& a, int mo, hipStream_t stre
     const int nb = (a.N + WS_BN - 1) / WS_BN;
     const int P = a.B * ((a.T + mo - 1) / mo);
     const dim3 grid(8 * (((P + WS_BMP - 1) / WS_BMP + 7) / 8) * nb);
-    if (mo == 4) hipLaunchKernelGGL(gt_conv_wino5s_kernel<4>, grid, dim3(WT), WS_LDS_BYTES, stream, a, reinterpret_cast<const __bf16*>(a.wino_s4), a.wino_npad);
-    else hipLaunchKernelGGL(gt_conv_wino5s_kernel<2>, grid, dim3(WT), WS_LDS_BYTES, stream, a, reinterpret_cast<const __bf16*>(a.wino_s), a.wino_npad);
+    const __bf16* planes = reinterpret_cast<const __bf16*>(mo == 4 ? a.wino_s4 : a.wino_s);
+    if (a.wino_x3) {        // (the knob's reduced form: two planes, three products)
+        if (mo == 4) hipLaunchKernelGGL((gt_conv_wino5s_kernel<4, true>), grid, dim3(WT), WS_LDS_BYTES, stream, a, planes, a.wino_npad);
+        else hipLaunchKernelGGL((gt_conv_wino5s_kernel<2, true>), grid, dim3(WT), WS_LDS_BYTES, stream, a, planes, a.wino_npad);
+        return hipGetLastError();
+    }
+    if (mo == 4) hipLaunchKernelGGL((gt_conv_wino5s_kernel<4, false>), grid, dim3(WT), WS_LDS_BYTES, stream, a, planes, a.wino_npad);
+    else hipLaunchKernelGGL((gt_conv_wino5s_kernel<2, false>), grid, dim3(WT), WS_LDS_BYTES, stream, a, planes, a.wino_npad);
     return hipGetLastError();
 }
 

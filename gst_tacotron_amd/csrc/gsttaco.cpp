@@ -165,6 +165,7 @@ struct gsttaco_ctx {
     int proj_both_m = 0;         // projection launch at 17..32 rows: one workgroup per tile over both M-tiles (GSTTACO_PROJ_BOTH_M, debug builds)
     int wino = 4;                // Winograd for the 5-tap Conv1D layers that fill the chip: 4 = F(4,5) where its grid fills the chip and F(2,5)
                                  // otherwise, 2 = F(2,5) only, 0 = implicit GEMM only (GSTTACO_WINO)
+    bool wino_x3 = false;        // GSTTACO_WINO_SPLIT=3: the postnet's split kernel with two planes and three products (~2^-16; NOT fp32-accurate)
     bool wino_split = true;      // the Winograd layers' transform-domain GEMMs as split-bf16 x6 on the bf16 matrix pipe, fp32 accuracy
                                  // (conv_wino_split.hip; GSTTACO_WINO_SPLIT=0: the fp32-MFMA Winograd kernel)
     int enc_wino = 2;            // the text encoder's five-tap layers behind the token gather on the split-bf16 Winograd kernel (GSTTACO_ENC_WINO)
@@ -1424,7 +1425,7 @@ int enqueue_postnet(gsttaco_ctx* c, hipStream_t s, int B, int Tf, const float* p
         ConvGemmArgs a{};
         a.x = x; a.w = L.w; a.scale = L.scale; a.shift = L.shift;
         a.wino_u = L.wino_u; a.wino_u4 = L.wino_u4; a.wino_cin = L.wino_cin;
-        a.wino_s = L.wino_s; a.wino_s4 = L.wino_s4; a.wino_npad = L.wino_npad;
+        a.wino_s = L.wino_s; a.wino_s4 = L.wino_s4; a.wino_npad = L.wino_npad; a.wino_x3 = c->wino_x3 ? 1 : 0;
         a.out = last ? out : c->w_post[cur]; a.ldo = L.cout;
         a.res = last ? pre : nullptr;                       // post = postnet(x) + x (Taco2.py:230)
         a.B = B; a.T = Tf; a.Cin = L.cin; a.N = L.cout; a.taps = L.taps;
@@ -1896,6 +1897,7 @@ int gsttaco_create(const gsttaco_config* cfg, gsttaco_ctx** out) {
     c->wino = env_int("GSTTACO_WINO", 4);
     if (c->wino != 0 && c->wino != 2) c->wino = 4;      // {0, 2, 4}; any other non-zero value (the old boolean's 1 included) means the default
     c->wino_split = env_int("GSTTACO_WINO_SPLIT", 1) != 0;
+    c->wino_x3 = env_int("GSTTACO_WINO_SPLIT", 1) == 3;
     c->enc_wino = env_int("GSTTACO_ENC_WINO", 2);
     if (c->enc_wino != 0 && c->enc_wino != 4) c->enc_wino = 2;
     c->pad_dec = env_int("GSTTACO_PAD_DECODER", 1) != 0;

@@ -210,6 +210,7 @@ struct ConvGemmArgs {
     int wino_npad;          // N rounded up to the kernel's 128-column block
     const void* gemm_s;     // taps == 1: W itself as three bf16 planes [plane][wino_npad][Cin], k contiguous -> the plain split-bf16 GEMM
                             // (conv_wino_split.hip gt_gemm_split_kernel), or NULL
+    int wino_x3;            // 1 = the split Winograd kernel's reduced form (two planes, products hh hm mh: ~2^-16, GSTTACO_WINO_SPLIT=3)
     int wino_min_wgs;       // 0 = the default grid-fill rule (Winograd only where >= 240 workgroups); else the caller's threshold -- the
                             // split-bf16 kernel also pays on the encoder's 4 096-row layers, whose F(2,5) grid is 128 workgroups
     float* out;             // [B*T, ldo]

@@ -219,7 +219,10 @@ def test_winograd_postnet_matches_the_oracle_and_the_implicit_gemm(monkeypatch):
                           ("F(2,5) split-bf16 x6", {"GSTTACO_WINO": "2", "GSTTACO_WINO_SPLIT": "1"}),
                           ("F(4,5)|F(2,5) fp32 MFMA", {"GSTTACO_WINO": "4", "GSTTACO_WINO_SPLIT": "0"}),
                           ("F(2,5) fp32 MFMA", {"GSTTACO_WINO": "2", "GSTTACO_WINO_SPLIT": "0"}),
-                          ("implicit GEMM", {"GSTTACO_WINO": "0", "GSTTACO_WINO_SPLIT": "0"})):
+                          ("implicit GEMM", {"GSTTACO_WINO": "0", "GSTTACO_WINO_SPLIT": "0"}),
+                          # the knob's reduced form (two planes, products hh hm mh: ~2^-16 per product) -- NOT the default; measured and held to
+                          # its own, looser bound below
+                          ("F(4,5)|F(2,5) split-bf16 x3 (knob)", {"GSTTACO_WINO": "4", "GSTTACO_WINO_SPLIT": "3"})):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             hpv = dict(hp); hpv["Max_Step"] = 1024
@@ -228,7 +231,9 @@ def test_winograd_postnet_matches_the_oracle_and_the_implicit_gemm(monkeypatch):
         ref = oracle_np.postnet(hp, w64, x.astype(np.float64), np.float64)
         errs = {k: float(np.abs(v - ref).max()) for k, v in outs.items()}
         print("postnet", B, T, "max-abs error vs the float64 oracle:", errs)
+        x3 = errs.pop("F(4,5)|F(2,5) split-bf16 x3 (knob)")
         assert max(errs.values()) <= TOL
+        assert x3 <= 20 * TOL           # (BAR = 1e-3 is the north star's; the default forms above are held to 5e-5)
 
 
 def test_persistent_bilstm_is_bitwise_the_per_step_bilstm(monkeypatch):

@@ -27,7 +27,7 @@ int main() {
     CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(u, hu.data(), hu.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(us, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
     ConvGemmArgs a{}; a.x = x; a.out = out; a.ldo = N; a.B = B; a.T = T; a.Cin = C; a.N = N; a.taps = 5; a.pad_before = 2; a.act = ACT_NONE;
-    a.wino_u4 = u; a.wino_u = u; a.wino_cin = C; a.wino_s4 = us; a.wino_s = us; a.wino_npad = N;
+    a.wino_u4 = u; a.wino_u = u; a.wino_cin = C; a.wino_s4 = us; a.wino_s = us; a.wino_npad = N; a.wino_x3 = getenv("WINO_X3") ? 1 : 0;
     CK(gt_conv_wino5s_init());
     const int P4 = B * ((T + 3) / 4);
     const dim3 grid(8 * (((P4 + 63) / 64 + 7) / 8) * 4);
