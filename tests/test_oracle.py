@@ -280,3 +280,92 @@ def test_bf16_rounding_emulation():
     assert not oracle_np.MIXED
     d = np.abs(f[0] - mx[0]).max()
     assert 0 < d < 0.2
+
+
+@pytest.mark.parametrize("att_type", ["SMA", "BMA", "LSA"])
+def test_zero_padding_a_smaller_decoder_is_exact_on_the_oracle(att_type):
+    """The library embeds a decoder smaller than the reference's in a reference-sized one with zeros (gsttaco.cpp pad_decoder) and claims
+    that is EXACT: a padded prenet unit is relu(0), a padded attention channel adds tanh(0) v = 0 to every score and a zero context column,
+    a padded LSTM unit has i = f = o = 1/2 and c~ = 0, so c and h stay 0.  Checked here on the float64 oracle alone, with the same row /
+    column maps (Dense kernels [in, out]; LSTM kernels gate-major; LSTM 1's input [prenet | context], the projection's [h2 | context])."""
+    import copy
+    from gst_tacotron_amd import synthetic, weights
+    from oracle import oracle_np
+    hp = synthetic.tiny_hp(att_type, r=2, gst=True, max_step=16)
+    dec = hp["Tacotron2"]["Decoder"]
+    if att_type == "LSA":
+        dec["Attention"] = {"Type": "LSA", "Size": 16, "Conv": {"Filters": 4, "Kernel_Size": 5}}
+    p0, p1 = dec["Prenet"]["Size"]
+    a, (h1, h2) = dec["Attention"]["Size"], dec["RNN"]["Size"]
+    P0, P1, A, H1, H2 = p0 + 16, p1 + 32, a + 16, h1 + 32, h2 + 16           # (any larger sizes: the C side pads to 256 / 256 / 128 / 1024 / 1024)
+    w = weights.synthetic_weights(hp, seed=11)
+    big = copy.deepcopy(hp)
+    bd = big["Tacotron2"]["Decoder"]
+    bd["Prenet"]["Size"] = [P0, P1]
+    bd["Attention"]["Size"] = A
+    bd["RNN"]["Size"] = [H1, H2]
+
+    def embed(name, shape, rmap=lambda r: r, cmap=lambda c: c):
+        src = np.asarray(w[name])
+        out = np.zeros(shape, src.dtype)
+        if src.ndim == 1:
+            for c in range(src.shape[0]):
+                out[cmap(c)] = src[c]
+        else:
+            rows = np.array([rmap(r) for r in range(src.shape[0])])
+            cols = np.array([cmap(c) for c in range(src.shape[1])])
+            out[np.ix_(rows, cols)] = src
+        return out
+    gate = lambda h, H: (lambda c: (c // h) * H + c % h)
+    cat = lambda n, N: (lambda r: r if r < n else N + (r - n))
+    mem = np.asarray(w["decoder.attention.value.kernel"]).shape[0]
+    mel, out_cols = hp["Sound"]["Mel_Dim"], np.asarray(w["decoder.projection.kernel"]).shape[1]
+    wb = dict(w)
+    wb["decoder.prenet0.kernel"] = embed("decoder.prenet0.kernel", (mel, P0))
+    wb["decoder.prenet0.bias"] = embed("decoder.prenet0.bias", (P0,))
+    wb["decoder.prenet1.kernel"] = embed("decoder.prenet1.kernel", (P0, P1))
+    wb["decoder.prenet1.bias"] = embed("decoder.prenet1.bias", (P1,))
+    wb["decoder.attention.query.kernel"] = embed("decoder.attention.query.kernel", (P1, A))
+    wb["decoder.attention.query.bias"] = embed("decoder.attention.query.bias", (A,))
+    wb["decoder.attention.value.kernel"] = embed("decoder.attention.value.kernel", (mem, A))
+    wb["decoder.attention.value.bias"] = embed("decoder.attention.value.bias", (A,))
+    if att_type == "LSA":
+        f = np.asarray(w["decoder.attention.location_dense.kernel"]).shape[0]
+        wb["decoder.attention.location_dense.kernel"] = embed("decoder.attention.location_dense.kernel", (f, A))
+        wb["decoder.attention.location_dense.bias"] = embed("decoder.attention.location_dense.bias", (A,))
+        wb["decoder.attention.bias"] = embed("decoder.attention.bias", (A,))
+    else:
+        wb["decoder.attention.v"] = embed("decoder.attention.v", (A,))
+    wb["decoder.lstm0.kernel"] = embed("decoder.lstm0.kernel", (P1 + A, 4 * H1), cat(p1, P1), gate(h1, H1))
+    wb["decoder.lstm0.recurrent_kernel"] = embed("decoder.lstm0.recurrent_kernel", (H1, 4 * H1), cmap=gate(h1, H1))
+    wb["decoder.lstm0.bias"] = embed("decoder.lstm0.bias", (4 * H1,), cmap=gate(h1, H1))
+    wb["decoder.lstm1.kernel"] = embed("decoder.lstm1.kernel", (H1, 4 * H2), cmap=gate(h2, H2))
+    wb["decoder.lstm1.recurrent_kernel"] = embed("decoder.lstm1.recurrent_kernel", (H2, 4 * H2), cmap=gate(h2, H2))
+    wb["decoder.lstm1.bias"] = embed("decoder.lstm1.bias", (4 * H2,), cmap=gate(h2, H2))
+    wb["decoder.projection.kernel"] = embed("decoder.projection.kernel", (H2 + A, out_cols), rmap=cat(h2, H2))
+    rng = np.random.default_rng(3)
+    B, Tv, Tref, steps = 2, 9, 40, 8
+    tokens, tl = synthetic.make_tokens(rng, B, Tv)
+    mels, ml = synthetic.make_ref_mels(rng, B, Tref, mel=mel)
+    masks, noise = synthetic.make_randomness(rng, steps, B, Tv, [p0, p1])
+    # the padded model's masks: the caller's columns, ones in the padding (what the library's re-layout kernel writes)
+    mb = np.ones((steps, B * (P0 + P1)), np.float32)
+    m0, m1 = mb[:, :B * P0].reshape(steps, B, P0), mb[:, B * P0:].reshape(steps, B, P1)
+    m0[:, :, :p0] = masks[:, 0]; m1[:, :, :p1] = masks[:, 1]
+    small = oracle_np.inference_step(hp, w, tokens, mels, ml, masks, noise, steps=steps, dt=np.float64)
+    if P0 == P1:
+        padded_masks = np.stack([m0, m1], axis=1)
+    else:       # (the oracle takes a stacked tensor: equal sizes only -- pad the smaller prenet layer's mask with more ones)
+        Pm = max(P0, P1)
+        padded_masks = np.ones((steps, 2, B, Pm), np.float32)
+        padded_masks[:, 0, :, :P0] = m0; padded_masks[:, 1, :, :P1] = m1
+        bd["Prenet"]["Size"] = [Pm, Pm]
+        wb["decoder.prenet0.kernel"] = embed("decoder.prenet0.kernel", (mel, Pm)); wb["decoder.prenet0.bias"] = embed("decoder.prenet0.bias", (Pm,))
+        wb["decoder.prenet1.kernel"] = embed("decoder.prenet1.kernel", (Pm, Pm)); wb["decoder.prenet1.bias"] = embed("decoder.prenet1.bias", (Pm,))
+        wb["decoder.attention.query.kernel"] = embed("decoder.attention.query.kernel", (Pm, A))
+        wb["decoder.lstm0.kernel"] = embed("decoder.lstm0.kernel", (Pm + A, 4 * H1), cat(p1, Pm), gate(h1, H1))
+    big_out = oracle_np.inference_step(big, wb, tokens, mels, ml, padded_masks, noise, steps=steps, dt=np.float64)
+    for x, y in zip(small[:4], big_out[:4]):            # (mels, stops, spectrograms (None here), alignments; [4] is a dict of intermediates)
+        if x is None:
+            continue
+        assert np.abs(np.asarray(x) - np.asarray(y)).max() <= 1e-12, att_type       # (float64 BLAS blocks the longer sums differently: not a bit pattern, but 1e-12)
