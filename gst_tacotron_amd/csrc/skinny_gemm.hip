@@ -697,7 +697,9 @@ __global__ __launch_bounds__(NW * 64) void gt_bilstm_lean_kernel(BiLstmArgs A) {
 // slot held before differs in the tag.  Three slots, not two: a member overwrites slot t % 3 at step t + 3, for which it needs step
 // t + 2 of its four source members, who needed step t + 1 of EVERY member, who had therefore all finished reading step t (with two
 // slots nothing orders a producer behind a reader it does not depend on).  The LDS partial sums alternate between two buffers by step
-// parity, so the one barrier per step (spill -> reduce) also orders their re-use.  Waits are bounded (error word instead of a hung GPU).
+// parity, so the one barrier per step (spill -> reduce) also orders their re-use.  Waits are bounded (error word instead of a hung GPU) --
+// which is also what a NaN / Inf state ends in (their exponent has bit 30 set: the tag can no longer be told; a model that produces them
+// is reported as a give-up instead of silently propagating them).
 //
 // Arithmetic = gt_bilstm_lean_kernel<8, 2>'s exactly (k-block kb on wave kb % 8, ascending; partial sums added over waves in
 // ascending order after the hoisted input half): bitwise equal outputs, which is what the GPU test checks.
