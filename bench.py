@@ -659,11 +659,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.mixed else "f32", "data": "synthetic",
-            # what the dtype's arithmetic runs on: since round 6 the fp32 path's Winograd-domain GEMMs (postnet, two encoder layers) run on the
+            # what the dtype's arithmetic runs on: since round 6 the fp32 path's Winograd-domain GEMMs (postnet, encoder) and tall plain GEMMs run on the
             # bf16 matrix pipe as split-bf16 x6 (three bf16 planes per fp32 operand, six plane products, fp32 accumulation: the fp32 MFMA
             # chain's accuracy -- tools/split_bf16.hip, profiles/r06_split_bf16.txt); everything else of the fp32 path on fp32 MFMA / VALU
             "arith": ("bf16 operands, fp32 accumulate (Use_Mixed_Precision)" if args.mixed else
-                      "fp32; five-tap Conv1D layers (postnet, encoder convs 2-3): Winograd-domain GEMMs as split-bf16 x6, fp32 accumulate"
+                      "fp32; the decode step on fp32 MFMA / VALU; the tall GEMMs around it (five-tap Conv1D layers of the postnet and the encoder as Winograd, "
+                      "BiLSTM input halves, Value projection) as split-bf16 x6 on the bf16 matrix pipe, fp32 accumulate"
                       if os.environ.get("GSTTACO_WINO_SPLIT", "1") != "0" else "fp32"),
             "config": {"workload": ("" if args.batch_per_gpu == BATCH_PER_GPU and not args.mixed else "NOT THE HEADLINE CONFIGURATION -- ") +
                                    "BASELINE configs[1]: GST on, batch {} per GPU, 128-token utterances, ".format(args.batch_per_gpu) +
