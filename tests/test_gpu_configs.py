@@ -622,3 +622,36 @@ def test_smaller_decoders_take_the_persistent_launch_zero_padded(monkeypatch, pr
     d = [float(np.abs(a - b).max()) for a, b in zip(outs["1"], outs["0"])]
     print(prenet, att, rnn, att_type, "padded persistent launch vs the unpadded launch path:", d)
     assert max(d) <= TOL
+
+
+def test_encoder_on_the_bf16_pipe_matches_the_oracle_at_the_headline_shape(monkeypatch):
+    """Round 6's encoder at 32 x 128 tokens -- embedding rows, three convolutions on the Winograd split kernel (F(2,5), 128 workgroups), the
+    BiLSTM's hoisted input halves on the plain split-bf16 GEMM, the persistent BiLSTM with its tagged state -- against the float64 oracle at the
+    suite's 5e-5, and against the round-5 forms of the same layers (implicit GEMM on the fp32 pipe) at the same bar; 128 utterances take F(4,5)."""
+    import gc
+    import torch
+    from gst_tacotron_amd import synthetic, weights
+    from oracle import oracle_np
+    hp = synthetic.config_hp("cfg2")
+    w = weights.synthetic_weights(hp, seed=13)
+    w64 = oracle_np.cast_weights(w, np.float64)
+    rng = np.random.default_rng(14)
+    tokens, _ = synthetic.make_tokens(rng, 32, 128)
+    ref = oracle_np.encoder(hp, w64, tokens, np.float64, None)
+    outs = {}
+    for name, env in (("split", {"GSTTACO_WINO_SPLIT": "1", "GSTTACO_ENC_WINO": "2"}), ("fp32 pipe", {"GSTTACO_WINO_SPLIT": "0", "GSTTACO_ENC_WINO": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gc.collect()
+        m = _model(hp, w, 128, 128, 4)
+        outs[name] = m.encode(tokens).cpu().numpy()
+        if name == "split":
+            big_tokens, _ = synthetic.make_tokens(rng, 128, 128)
+            big = m.encode(big_tokens).cpu().numpy()
+        else:
+            big_ref = m.encode(big_tokens).cpu().numpy()
+        assert m.handoff_error() == 0
+        del m
+    errs = {k: float(np.abs(v - ref).max()) for k, v in outs.items()}
+    print("encoder 32 x 128 max-abs error vs the float64 oracle:", errs, "| 128 x 128, split vs fp32 pipe:", float(np.abs(big - big_ref).max()))
+    assert max(errs.values()) <= TOL and np.abs(big - big_ref).max() <= TOL
