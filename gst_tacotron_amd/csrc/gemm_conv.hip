@@ -551,7 +551,11 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
         }
     };
 
+#ifdef C5_NO_LOOP
+    const int nslices = 0, nsteps = 0;       // (tools/conv5_bench.hip: the kernel's fixed part -- prologue + epilogue -- alone)
+#else
     const int nslices = (A.Cin + C5_BK - 1) / C5_BK, nsteps = nslices * 5;
+#endif
     load_a(0, 0);
     store_a(0, 0);
     load_a(0, 1);
@@ -568,28 +572,52 @@ __global__ __launch_bounds__(512) void gt_conv5_bf16_kernel(ConvGemmArgs A) {
         // the other A buffer was last read in the previous slice)
         const int sn = min(s + 1, nsteps - 1);
         load_b(sn % 5, (sn / 5) * C5_BK);
+#ifndef C5_NO_A
         if (tap == 0 || tap == 2) load_a(min(sl + 1, nslices - 1) * C5_BK, tap >> 1);
+#endif
         // (DMA: into the other slab, last read in step s - 1 -- every wave is past that step's barrier.  BEHIND the row requests since round 6:
         // before the compiler re-uses the rows' registers it waits for the loads it knows with vmcnt(4) .. vmcnt(0) -- which, with this step's
-        // four DMAs already queued, waited for THEM: a DMA's whole latency exposed at taps 0 and 2 of every slice)
+        // four DMAs already queued, waited for THEM: a DMA's whole latency exposed at taps 0 and 2 of every slice.  Also measured: the requests
+        // behind the step's first / second / last eight MFMAs instead of in front of its fragment reads -- no difference, tools/conv5_bench.hip)
+#ifndef C5_NO_DMA
         if (GT_C5_DMA) dma_b((s + 1) & 1, sn % 5, (sn / 5) * C5_BK);
+#endif
         const __bf16* Ab = As + ((sl & 1) * C5_AR + wm * 64 + l31 + tap) * C5_LD + kh * 8;
         const __bf16* Bb = Bs + ((s & 1) * BN + wn * RN * 32 + l31) * C5_LDB + (GT_C5_DMA ? 0 : kh * 8);
 #pragma unroll
         for (int ks = 0; ks < C5_BK / 16; ++ks) {
             bf16x8 av[RM], bv[RN];
+            // (ablation switches of tools/conv5_bench.hip: -DC5_NO_READS_A / _B -- one fragment read per step instead of one per 16 k --,
+            // -DC5_NO_MFMA, -DC5_NO_DMA, -DC5_NO_A; the product compiles the plain forms)
+#ifdef C5_NO_READS_A
+#pragma unroll
+            for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * C5_LD);
+#else
 #pragma unroll
             for (int i = 0; i < RM; ++i) av[i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * C5_LD + ks * 16);
+#endif
+#ifdef C5_NO_READS_B
+#pragma unroll
+            for (int j = 0; j < RN; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * C5_LDB);
+#else
 #pragma unroll
             for (int j = 0; j < RN; ++j)        // (DMA: chunk 2 ks + kh of column .. + l31 sits at position (2 ks + kh) ^ ((l31 / 2) % 8): j * 32 keeps the column's low bits)
                 bv[j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * C5_LDB + (GT_C5_DMA ? (((2 * ks + kh) ^ ((l31 >> 1) & 7)) * 8) : ks * 16));
+#endif
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
-                for (int j = 0; j < RN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < RN; ++j)
+#ifdef C5_NO_MFMA
+                    acc[i][j][ks] += (float)av[i][0] + (float)bv[j][1];
+#else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+#endif
         }
         store_b((s + 1) & 1);           // (after the last step: written, never read)
+#ifndef C5_NO_A
         if (tap == 1 || tap == 3) store_a((sl + 1) & 1, tap >> 1);
+#endif
         if (GT_C5_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the next slab has landed -- requested a step's MFMAs ago)
         __syncthreads();
     }
